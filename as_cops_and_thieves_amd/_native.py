@@ -1,0 +1,104 @@
+"""ctypes binding of libcat_sim.so (include/cat_sim.h).  No CPU fallback: if the shared library
+is missing, or no HIP device is usable, every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+from .config import C_FIELDS_F64, C_FIELDS_I32
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+LIB_PATH = PKG / "libcat_sim.so"
+SRC = PKG / "csrc" / "cat_sim.hip"
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared"]
+
+OUT_FIELDS = ("obs_distance", "obs_type", "hit_shape", "shared_distance", "shared_type",
+              "team_positions", "reward", "terminated", "truncated", "winner")
+STATE_FIELDS = ("pos", "vel", "vbias", "tc", "leaf_bb", "wall_shape", "wall_age", "wall_jn",
+                "pair_age", "pair_jn", "step_count", "reset_count")
+WALL_CACHE = 8
+
+ERRORS = {-1: "CAT_ERR_BAD_CONFIG", -2: "CAT_ERR_BAD_MAP", -3: "CAT_ERR_BAD_SLOT_MAP",
+          -4: "CAT_ERR_NO_DEVICE", -5: "CAT_ERR_HIP", -6: "CAT_ERR_BAD_ARG"}
+
+
+class CatConfig(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in C_FIELDS_I32] + [("env_id_offset", C.c_int64), ("seed", C.c_uint64)]
+                + [(n, C.c_double) for n in C_FIELDS_F64])
+
+
+class CatTables(C.Structure):
+    _fields_ = [("ray_dx", C.c_void_p), ("ray_dy", C.c_void_p), ("cop_reward_lut", C.c_void_p),
+                ("thief_reward_lut", C.c_void_p)]
+
+
+class CatOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in OUT_FIELDS]
+
+
+class CatState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in STATE_FIELDS]
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP extension in-tree for gfx950 (works without a GPU: hipcc cross-compiles)."""
+    hdr = ROOT / "include" / "cat_sim.h"
+    stale = (not LIB_PATH.exists()
+             or LIB_PATH.stat().st_mtime < SRC.stat().st_mtime
+             or LIB_PATH.stat().st_mtime < hdr.stat().st_mtime)
+    if force or stale:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", "-o", str(LIB_PATH), str(SRC)]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or res.returncode != 0:
+            print(" ".join(cmd))
+            print(res.stdout, res.stderr)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed building libcat_sim.so")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the env core.")
+    L = C.CDLL(str(LIB_PATH))
+    vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
+    L.cat_abi_version.restype = i32
+    L.cat_last_error.restype = C.c_char_p
+    L.cat_last_error.argtypes = [vp]
+    L.cat_create.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp]
+    L.cat_destroy.argtypes = [vp]
+    L.cat_reset.argtypes = [vp, vp, vp, vp, vp]
+    L.cat_reset_done.argtypes = [vp, vp, vp]
+    L.cat_step.argtypes = [vp, vp, vp, vp]
+    L.cat_get_state.argtypes = [vp, vp, vp]
+    L.cat_set_state.argtypes = [vp, vp, vp]
+    L.cat_random_actions.argtypes = [vp, u64, vp, vp]
+    L.cat_num_agents.argtypes = [vp]
+    L.cat_num_shapes.argtypes = [vp, i32]
+    L.cat_selftest_arith.argtypes = [i32, vp, vp, vp, i32, i32, vp]
+    for name in ("cat_create", "cat_destroy", "cat_reset", "cat_reset_done", "cat_step", "cat_get_state",
+                 "cat_set_state", "cat_random_actions", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith"):
+        getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = ("cat_abi_version", "cat_last_error", "cat_create", "cat_destroy", "cat_reset",
+                    "cat_reset_done", "cat_step", "cat_get_state", "cat_set_state", "cat_random_actions",
+                    "cat_num_agents", "cat_num_shapes", "cat_selftest_arith")

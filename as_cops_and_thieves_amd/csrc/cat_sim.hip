@@ -1,0 +1,1193 @@
+// cat_sim.hip -- MI355X (gfx950 / CDNA4) batched Cops-and-Thieves env core + its C ABI.
+//
+// One 64-lane wavefront advances one env; a 256-thread workgroup = 4 envs that share one map,
+// whose geometry (hull planes + shape bbs) is staged once per workgroup in LDS.  All body state
+// and ray arithmetic is FP64 with contraction off, so results are bit-comparable with a non-FMA
+// CPU evaluation of the same formulas.  No MFMA: the path is geometry/indexing, bounded by FP64
+// VALU issue and LDS latency (DESIGN.md "Kernels").
+//
+// What each device function reproduces (paths relative to the reference repo; [CP x] = the
+// Chipmunk2D 7.0.x function of that name, a third-party dependency of the reference whose
+// published algorithm is followed -- SURVEY.md appendix A):
+//   tick_kernel   BaseEnv.step                       src/environments/base_env.py:354-413
+//   reset_kernel  BaseEnv.reset                      src/environments/base_env.py:286-352
+//   observe_*     Entity.get_observation/_query_body src/agents/entity.py:159-241
+//   rewards       Cop.reward / Thief.reward          src/agents/cop.py:49-75, thief.py:48-69
+//   shared obs    get_shared_observations            src/environments/observation_spaces.py:67-131
+//   physics_step  pymunk Space.step -> [CP cpSpaceStep]  (call site base_env.py:392)
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "cat_sim.h"
+
+namespace {
+
+constexpr int kWaves = 4;           // envs per workgroup
+constexpr int kLanes = 64;          // gfx950 wavefront
+constexpr int kK = CAT_WALL_CACHE;
+constexpr unsigned kBlobMagic = 0x31544143u;
+
+struct MapDesc {
+    int S, P, A, n_regions;
+    int f64_off;   // into geo_f64: [bb 4S][planes 8P][start 2A][regions 4Rg]
+    int i32_off;   // into geo_i32: [first S][count S][region_off A+1]
+    int pad0, pad1;
+};
+
+struct Params {
+    int N, A, n_cops, R, max_step, iterations, persistence, gate, NP, maxc;
+    long long env_id_offset;
+    unsigned long long seed;
+    double dt, bias_coef, slop, ray_length, ray_radius, rc, mass, impulse, max_speed, term_radius, wall_r;
+    const double *ray_dx, *ray_dy;
+    const float *cop_lut, *thief_lut;
+    const MapDesc *maps;
+    const double *geo_f64;
+    const int *geo_i32;
+    const int *work_env;    // [n_blocks*kWaves] env slot or -1
+    const int *block_map;   // [n_blocks]
+    double *pos, *vel, *vbias, *tc, *leaf, *wjn, *pjn;
+    int *wsh, *wag, *pag, *step_count, *reset_count;
+    unsigned char *done;
+    cat_outputs out;
+    const int *actions;
+    const unsigned char *mask;
+    const double *positions;
+    int use_done_mask;
+    // LDS carve (bytes)
+    int lds_map_bytes, lds_wave_bytes;
+};
+
+// ------------------------------------------------------------------ small helpers -----------
+__device__ __forceinline__ double fmax2(double a, double b) { return (a > b) ? a : b; }  // [CP cpfmax]
+__device__ __forceinline__ double fmin2(double a, double b) { return (a < b) ? a : b; }  // [CP cpfmin]
+
+// wave-local ordering of LDS traffic between lanes (one wave owns its scratch; no s_barrier)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// round-to-nearest-even f64 -> f16 bits: NumPy's cast for np.array(points, dtype=np.float16)
+// (entity.py:206) and for the weak python-float origin (entity.py:208)
+__device__ __forceinline__ unsigned f64_to_f16(double x)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    unsigned sign = (unsigned)((b >> 48) & 0x8000ull);
+    unsigned long long a = b & 0x7FFFFFFFFFFFFFFFull;
+    if (a >= 0x7FF0000000000000ull) return sign | (a > 0x7FF0000000000000ull ? 0x7E00u : 0x7C00u);
+    if (a == 0) return sign;
+    int e = (int)(a >> 52) - 1023;
+    if (e > 15) return sign | 0x7C00u;
+    unsigned long long M = (a & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+    int shift = 42;
+    if (e < -14) shift += (-14 - e);
+    if (shift > 54) return sign;
+    unsigned long long q = M >> shift;
+    unsigned long long rem = M & ((1ull << shift) - 1);
+    unsigned long long half = 1ull << (shift - 1);
+    if (rem > half || (rem == half && (q & 1))) q++;
+    unsigned bits = (e >= -14) ? (unsigned)(((unsigned)(e + 14) << 10) + q) : (unsigned)q;
+    if (bits >= 0x7C00u) bits = 0x7C00u;
+    return sign | bits;
+}
+
+__device__ __forceinline__ float f16_to_f32(unsigned h)
+{
+    unsigned s = (h >> 15) & 1u, e = (h >> 10) & 31u, m = h & 1023u;
+    float v;
+    if (e == 0) v = (float)m * 5.9604644775390625e-08f;           // m * 2^-24, exact
+    else if (e == 31) v = m ? __int_as_float(0x7FC00000) : __int_as_float(0x7F800000);
+    else v = __int_as_float((int)(((e + 112u) << 23) | (m << 13)));
+    return s ? -v : v;
+}
+
+// entity.py:206-210: f16(point) - f16(origin) in f32 -> f16; np.hypot on f16 = hypotf -> f16
+__device__ __forceinline__ unsigned obs_distance_f16(double px, double py, double ox, double oy)
+{
+    float dx32 = f16_to_f32(f64_to_f16(px)) - f16_to_f32(f64_to_f16(ox));
+    float dy32 = f16_to_f32(f64_to_f16(py)) - f16_to_f32(f64_to_f16(oy));
+    float dx = f16_to_f32(f64_to_f16((double)dx32)), dy = f16_to_f32(f64_to_f16((double)dy32));
+    float hyp = (float)sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+    return f64_to_f16((double)hyp);
+}
+
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                           unsigned k0, unsigned k1, unsigned out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void philox_env(const Params &p, int env, unsigned c1, unsigned c2,
+                                           unsigned c3, unsigned out[4])
+{
+    unsigned long long gid = (unsigned long long)(p.env_id_offset + env);
+    philox4x32((unsigned)gid, c1, c2, c3 ^ ((unsigned)(gid >> 32) << 24), (unsigned)p.seed,
+               (unsigned)(p.seed >> 32), out);
+}
+
+__device__ __forceinline__ double u53(unsigned a, unsigned b)
+{
+    return (double)(((unsigned long long)(a >> 5) << 26) | (unsigned long long)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------------ LDS view ------------------
+struct Lds {
+    const double *bb;      // [S][4]            workgroup-shared
+    const double *planes;  // [P][8]
+    const int *first, *count;
+    // per-wave scratch
+    double *pos, *vel, *vb, *tc, *leaf;  // [A][2] x4, [A][4]
+    double *wjn, *pjn;
+    int *wsh, *wag, *pag;
+    double *conf;   // [maxc][12]
+    int *coni;      // [maxc][4]
+    int *cand;      // [S]
+    unsigned short *od;  // [A*R]
+    unsigned char *ot;   // [A*R]
+    double *spawn;  // [A][2]
+};
+
+__device__ __forceinline__ int align_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------ geometry ------------------
+// [CP cpBBSegmentQuery]; slab test multiplies by 1/delta (DESIGN.md deviation D3)
+__device__ __forceinline__ double bb_segment_query(const double *bb, double ax, double ay, double dx,
+                                                   double dy, double idx, double idy)
+{
+    const double2 lo = *reinterpret_cast<const double2 *>(bb);
+    const double2 hi = *reinterpret_cast<const double2 *>(bb + 2);
+    double tmin = -INFINITY, tmax = INFINITY;
+    if (dx == 0.0) {
+        if (ax < lo.x || hi.x < ax) return INFINITY;
+    } else {
+        double t1 = (lo.x - ax) * idx, t2 = (hi.x - ax) * idx;
+        tmin = fmax2(tmin, fmin2(t1, t2));
+        tmax = fmin2(tmax, fmax2(t1, t2));
+    }
+    if (dy == 0.0) {
+        if (ay < lo.y || hi.y < ay) return INFINITY;
+    } else {
+        double t1 = (lo.y - ay) * idy, t2 = (hi.y - ay) * idy;
+        tmin = fmax2(tmin, fmin2(t1, t2));
+        tmax = fmin2(tmax, fmax2(t1, t2));
+    }
+    if (tmin <= tmax && 0.0 <= tmax && tmin <= 1.0) return fmax2(tmin, 0.0);
+    return INFINITY;
+}
+
+struct SegInfo { int hit; double alpha, px, py; };
+
+// [CP CircleSegmentQuery]
+__device__ __forceinline__ void circle_segment_query(double cx, double cy, double r1, double ax, double ay,
+                                                     double bx, double by, double r2, SegInfo &info)
+{
+    double dax = ax - cx, day = ay - cy, dbx = bx - cx, dby = by - cy;
+    double rsum = r1 + r2;
+    double dada = dax * dax + day * day, dadb = dax * dbx + day * dby, dbdb = dbx * dbx + dby * dby;
+    double qa = dada - 2.0 * dadb + dbdb;
+    double qb = dadb - dada;
+    double det = qb * qb - qa * (dada - rsum * rsum);
+    if (det >= 0.0) {
+        double t = (-qb - sqrt(det)) / qa;
+        if (0.0 <= t && t <= 1.0) {
+            double lx = dax * (1.0 - t) + dbx * t, ly = day * (1.0 - t) + dby * t;
+            double inv = 1.0 / (sqrt(lx * lx + ly * ly) + DBL_MIN);
+            double nx = lx * inv, ny = ly * inv;
+            info.hit = 1;
+            info.alpha = t;
+            info.px = (ax * (1.0 - t) + bx * t) - nx * r2;
+            info.py = (ay * (1.0 - t) + by * t) - ny * r2;
+        }
+    }
+}
+
+// [CP cpPolyShapeSegmentQuery]; plane record = n.x n.y v0.x v0.y dot(v0,n) dtMin dtMax pad
+__device__ __forceinline__ void poly_segment_query(const Lds &L, int sh, double r, double ax, double ay,
+                                                   double bx, double by, double r2, SegInfo &info)
+{
+    const int first = L.first[sh], count = L.count[sh];
+    const double rsum = r + r2;
+    for (int i = 0; i < count; i++) {
+        const double *pl = L.planes + 8 * (first + i);
+        const double2 n = *reinterpret_cast<const double2 *>(pl);
+        const double2 e0 = *reinterpret_cast<const double2 *>(pl + 4);  // vn, dtMin
+        double an = ax * n.x + ay * n.y;
+        double d = an - e0.x - rsum;
+        if (d < 0.0) continue;
+        double bn = bx * n.x + by * n.y;
+        double den = fmax2(an - bn, DBL_MIN);
+        if (d > den) continue;  // <=> fl(d/den) > 1: exact pre-reject before the division
+        double t = d / den;
+        if (t < 0.0 || 1.0 < t) continue;
+        double ptx = ax * (1.0 - t) + bx * t, pty = ay * (1.0 - t) + by * t;
+        double dtv = n.x * pty - n.y * ptx;
+        if (e0.y <= dtv && dtv <= pl[6]) {
+            info.hit = 1;
+            info.alpha = t;
+            info.px = ptx - n.x * r2;
+            info.py = pty - n.y * r2;
+        }
+    }
+    if (rsum > 0.0) {
+        for (int i = 0; i < count; i++) {
+            const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + i) + 2);
+            SegInfo ci = {0, 1.0, bx, by};
+            circle_segment_query(v.x, v.y, r, ax, ay, bx, by, r2, ci);
+            if (ci.alpha < info.alpha) info = ci;
+        }
+    }
+}
+
+// [CP cpPolyShapePointQuery] -> signed distance to the rounded surface
+__device__ __forceinline__ double poly_point_distance(const Lds &L, int sh, double r, double px, double py)
+{
+    const int first = L.first[sh], count = L.count[sh];
+    const double *last = L.planes + 8 * (first + count - 1);
+    double v0x = last[2], v0y = last[3];
+    double minDist = INFINITY;
+    bool outside = false;
+    for (int i = 0; i < count; i++) {
+        const double *pl = L.planes + 8 * (first + i);
+        const double2 n = *reinterpret_cast<const double2 *>(pl);
+        const double2 v1 = *reinterpret_cast<const double2 *>(pl + 2);
+        outside = outside || (n.x * (px - v1.x) + n.y * (py - v1.y) > 0.0);
+        double dx = v0x - v1.x, dy = v0y - v1.y;  // [CP cpClosetPointOnSegment]
+        double t = (dx * (px - v1.x) + dy * (py - v1.y)) / (dx * dx + dy * dy);
+        t = fmax2(0.0, fmin2(t, 1.0));
+        double cx = v1.x + dx * t, cy = v1.y + dy * t;
+        double ex = px - cx, ey = py - cy;
+        double dist = sqrt(ex * ex + ey * ey);
+        if (dist < minDist) minDist = dist;
+        v0x = v1.x; v0y = v1.y;
+    }
+    double dist = outside ? minDist : -minDist;
+    return dist - r;
+}
+
+// ------------------------------------------------------------------ ray fan -------------------
+// Per agent: candidate walls = those whose bb the agent's reach box touches (exact superset of
+// every shape a ray of this agent can visit), bit 16 set when the ray origin lies within the ray
+// radius of the wall surface ([CP cpShapeSegmentQuery] alpha = 0 rule).  Lanes stride shapes.
+__device__ __forceinline__ int build_candidates(const Lds &L, const Params &p, int S, int lane,
+                                                double ax, double ay, double reach, double r2)
+{
+    int n = 0;
+    for (int base = 0; base < S; base += kLanes) {
+        int s = base + lane;
+        bool in = false;
+        int near = 0;
+        if (s < S) {
+            const double *bb = L.bb + 4 * s;
+            in = (bb[0] <= ax + reach) && (ax - reach <= bb[2]) && (bb[1] <= ay + reach) && (ay - reach <= bb[3]);
+            if (in) {
+                double m = r2 + 1e-6;
+                bool close = (bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m);
+                if (close) near = poly_point_distance(L, s, p.wall_r, ax, ay) <= r2;
+            }
+        }
+        unsigned long long mask = __ballot(in);
+        int pos = n + __popcll(mask & ((1ull << lane) - 1ull));
+        if (in) L.cand[pos] = s | (near << 16);
+        n += __popcll(mask);
+    }
+    wave_sync();
+    return n;
+}
+
+// [CP cpSpaceSegmentQueryFirst] over a linear index: candidate walls in index order, then the
+// other agents' cached circles (entity.py:118-123 group filter rejects only the agent's own).
+__device__ __forceinline__ int segment_query_first(const Lds &L, const Params &p, int A, int S, int ncand,
+                                                   int self, double ax, double ay, double bx, double by,
+                                                   double r2, SegInfo &out)
+{
+    int best = -1;
+    out.hit = 0; out.alpha = 1.0; out.px = bx; out.py = by;
+    const double dx = bx - ax, dy = by - ay;
+    const double idx = 1.0 / dx, idy = 1.0 / dy;
+    double t_exit = 1.0;
+    for (int c = 0; c < ncand; c++) {
+        const int e = L.cand[c];
+        const int sh = e & 0xFFFF;
+        if (p.gate) {
+            double tbb = bb_segment_query(L.bb + 4 * sh, ax, ay, dx, dy, idx, idy);
+            if (!(tbb < t_exit)) continue;
+        }
+        SegInfo info = {0, 1.0, bx, by};
+        if (e >> 16) { info.hit = 1; info.alpha = 0.0; }
+        else poly_segment_query(L, sh, p.wall_r, ax, ay, bx, by, r2, info);
+        if (info.hit && info.alpha < out.alpha) { out = info; best = sh; }
+        t_exit = fmin2(t_exit, out.alpha);
+    }
+    for (int j = 0; j < A; j++) {
+        if (j == self) continue;
+        const double tcx = L.tc[2 * j], tcy = L.tc[2 * j + 1];
+        if (p.gate) {
+            double tbb = bb_segment_query(L.leaf + 4 * j, ax, ay, dx, dy, idx, idy);
+            if (!(tbb < t_exit)) continue;
+        }
+        SegInfo info = {0, 1.0, bx, by};
+        double ex = ax - tcx, ey = ay - tcy;
+        if (sqrt(ex * ex + ey * ey) - p.rc <= r2) { info.hit = 1; info.alpha = 0.0; }  // [CP cpCircleShapePointQuery]
+        else circle_segment_query(tcx, tcy, p.rc, ax, ay, bx, by, r2, info);
+        if (info.hit && info.alpha < out.alpha) { out = info; best = S + j; }
+        t_exit = fmin2(t_exit, out.alpha);
+    }
+    return best;
+}
+
+// Entity.get_observation for every agent of the env + rewards + team-shared channels.
+// rew_mode: 0 = no rewards (reset), 1 = step (captured/timeout known).
+__device__ void observe_env(const Lds &L, const Params &p, int env, int lane, int S, int rew_mode,
+                            int captured, int timeout)
+{
+    const int A = p.A, R = p.R;
+    const unsigned d_empty = f64_to_f16(p.ray_length);  // np.full(R, ray_length, float16) entity.py:200
+    const double reach = p.ray_length + p.ray_radius + 1e-6;
+    for (int i = 0; i < A; i++) {
+        const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];  // fresh body.position (entity.py:186)
+        const int ncand = build_candidates(L, p, S, lane, ax, ay, reach, p.ray_radius);
+        const bool is_cop = i < p.n_cops;
+        const unsigned want = is_cop ? CAT_THIEF : CAT_COP;
+        unsigned dmin = 0x10000u;
+        for (int k0 = 0; k0 < R; k0 += kLanes) {
+            const int k = k0 + lane;
+            const bool active = k < R;
+            const int kk = active ? k : 0;
+            const double bx = ax + p.ray_dx[kk], by = ay + p.ray_dy[kk];  // entity.py:191-193
+            SegInfo o;
+            int sh = segment_query_first(L, p, A, S, ncand, i, ax, ay, bx, by, p.ray_radius, o);
+            unsigned d16 = d_empty, ty = CAT_EMPTY;
+            if (sh >= 0) {
+                d16 = obs_distance_f16(o.px, o.py, ax, ay);
+                ty = (sh < S) ? CAT_WALL : ((sh - S) >= p.n_cops ? CAT_THIEF : CAT_COP);  // entity.py:222-241
+            }
+            if (active) {
+                const int q = i * R + k;
+                L.od[q] = (unsigned short)d16;
+                L.ot[q] = (unsigned char)ty;
+                const size_t g = (size_t)env * A * R + q;
+                if (p.out.obs_distance) p.out.obs_distance[g] = (unsigned short)d16;
+                if (p.out.obs_type) p.out.obs_type[g] = (unsigned char)ty;
+                if (p.out.hit_shape) p.out.hit_shape[g] = sh;
+                if (ty == want && d16 < dmin) dmin = d16;  // non-negative f16: bit order = value order
+            }
+        }
+        if (rew_mode) {  // cop.py:49-75 / thief.py:48-69
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                unsigned o2 = (unsigned)__shfl_xor((int)dmin, off);
+                dmin = o2 < dmin ? o2 : dmin;
+            }
+            float r;
+            if (captured) r = is_cop ? 1.0f : -1.0f;
+            else if (timeout) r = is_cop ? -1.0f : 1.0f;
+            else if (dmin < 0x10000u) r = (is_cop ? p.cop_lut : p.thief_lut)[dmin & 0x7FFFu];
+            else r = is_cop ? (float)(-0.02 - 0.02) : (float)0.15;
+            if (lane == 0 && p.out.reward) p.out.reward[(size_t)env * A + i] = r;
+        }
+        wave_sync();  // cand[] is rebuilt for the next agent
+    }
+    // get_shared_observations (observation_spaces.py:98-129): first team member, roster order,
+    // with a non-EMPTY ray supplies (type, distance); else EMPTY with the last member's distance
+    for (int k = lane; k < R; k += kLanes) {
+        for (int team = 0; team < 2; team++) {
+            const int lo = team ? p.n_cops : 0, hi = team ? A : p.n_cops;
+            unsigned ty = CAT_EMPTY, d = 0;
+            for (int i = lo; i < hi; i++)
+                if (ty == CAT_EMPTY) { ty = L.ot[i * R + k]; d = L.od[i * R + k]; }
+            const size_t g = (size_t)env * 2 * R + team * R + k;
+            if (p.out.shared_type) p.out.shared_type[g] = (unsigned char)ty;
+            if (p.out.shared_distance) p.out.shared_distance[g] = (unsigned short)d;
+        }
+    }
+    if (lane < 2 * A && p.out.team_positions)  // observation_spaces.py:92-95
+        p.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)f64_to_f16(L.pos[lane]);
+}
+
+// ------------------------------------------------------------------ termination ---------------
+// BaseEnv._termination_criterion (base_env.py:521-554).  The wall-only LOS query is only consulted
+// for pairs inside the capture radius, so it is evaluated only there; lanes stride the walls.
+__device__ int termination_captured(const Lds &L, const Params &p, int S, int lane)
+{
+    const int A = p.A, nc = p.n_cops;
+    for (int t = nc; t < A; t++) {
+        for (int c = 0; c < nc; c++) {
+            const double ax = L.pos[2 * t], ay = L.pos[2 * t + 1], bx = L.pos[2 * c], by = L.pos[2 * c + 1];
+            const double ddx = ax - bx, ddy = ay - by;  // Vec2d.get_distance
+            if (!(sqrt(ddx * ddx + ddy * ddy) < p.term_radius)) continue;
+            const double dx = bx - ax, dy = by - ay, idx = 1.0 / dx, idy = 1.0 / dy;
+            bool any = false;
+            for (int base = 0; base < S; base += kLanes) {
+                const int s = base + lane;
+                bool hit = false;
+                if (s < S) {
+                    bool visit = true;
+                    if (p.gate) visit = bb_segment_query(L.bb + 4 * s, ax, ay, dx, dy, idx, idy) < 1.0;
+                    if (visit) {
+                        SegInfo info = {0, 1.0, bx, by};
+                        if (poly_point_distance(L, s, p.wall_r, ax, ay) <= 0.0) { info.hit = 1; info.alpha = 0.0; }
+                        else poly_segment_query(L, s, p.wall_r, ax, ay, bx, by, 0.0, info);
+                        hit = info.hit && info.alpha < 1.0;
+                    }
+                }
+                any = any || (__ballot(hit) != 0ull);
+            }
+            if (!any) return 1;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ physics -------------------
+__device__ __forceinline__ int pair_index(int A, int i, int j) { return i * A - i * (i + 1) / 2 + (j - i - 1); }
+
+// closest hull feature + [CP ClosestPointsNew] -> contact of [CP CircleToPoly]
+__device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, double cy, double rc,
+                                   double &nx, double &ny, double &p1x, double &p1y, double &p2x, double &p2y)
+{
+    const int first = L.first[sh], count = L.count[sh];
+    int best = -1, sepi = 0;
+    double bestd = INFINITY, bt = 0, bpx = 0, bpy = 0, maxsep = -INFINITY;
+    bool inside = true;
+    for (int i = 0; i < count; i++) {
+        const double *pl = L.planes + 8 * (first + i);
+        const double *pv = L.planes + 8 * (first + (i - 1 + count) % count);
+        double sep = pl[0] * (cx - pl[2]) + pl[1] * (cy - pl[3]);
+        if (sep > 0.0) inside = false;
+        if (sep > maxsep) { maxsep = sep; sepi = i; }
+        double ax_ = pl[2] - cx, ay_ = pl[3] - cy, bx_ = pv[2] - cx, by_ = pv[3] - cy;
+        double dx = bx_ - ax_, dy = by_ - ay_;
+        double t = -fmin2(fmax2((dx * (ax_ + bx_) + dy * (ay_ + by_)) / (dx * dx + dy * dy), -1.0), 1.0);  // [CP ClosestT]
+        double ht = 0.5 * t;                                                                                  // [CP LerpT]
+        double px = ax_ * (0.5 - ht) + bx_ * (0.5 + ht), py = ay_ * (0.5 - ht) + by_ * (0.5 + ht);
+        double dd = px * px + py * py;
+        if (dd < bestd) { bestd = dd; best = i; bt = t; bpx = px; bpy = py; }
+    }
+    if (inside) {  // centre inside the hull: least-penetration plane (deviation D4)
+        const double *pl = L.planes + 8 * (first + sepi);
+        double d = maxsep;
+        if (!(d <= rc + rp)) return 0;
+        nx = -pl[0]; ny = -pl[1];
+        p1x = cx + nx * rc; p1y = cy + ny * rc;
+        double qx = cx - pl[0] * d, qy = cy - pl[1] * d;
+        p2x = qx + nx * (-rp); p2y = qy + ny * (-rp);
+        return 1;
+    }
+    const double *pl = L.planes + 8 * (first + best);
+    const double *pv = L.planes + 8 * (first + (best - 1 + count) % count);
+    double ax_ = pl[2] - cx, ay_ = pl[3] - cy, bx_ = pv[2] - cx, by_ = pv[3] - cy;
+    double t = bt, ht = 0.5 * t;
+    double pax = cx * (0.5 - ht) + cx * (0.5 + ht), pay = cy * (0.5 - ht) + cy * (0.5 + ht);
+    double pbx = pl[2] * (0.5 - ht) + pv[2] * (0.5 + ht), pby = pl[3] * (0.5 - ht) + pv[3] * (0.5 + ht);
+    double dx = bx_ - ax_, dy = by_ - ay_;
+    double rx = dy, ry = -dx;
+    double inv = 1.0 / (sqrt(rx * rx + ry * ry) + DBL_MIN);
+    double n_x = rx * inv, n_y = ry * inv;
+    double d = n_x * bpx + n_y * bpy;
+    if (!(d <= 0.0 || (-1.0 < t && t < 1.0))) {
+        double d2 = sqrt(bpx * bpx + bpy * bpy);
+        double inv2 = 1.0 / (d2 + DBL_MIN);
+        n_x = bpx * inv2; n_y = bpy * inv2;
+        d = d2;
+    }
+    if (!(d <= rc + rp)) return 0;
+    nx = n_x; ny = n_y;
+    p1x = pax + n_x * rc; p1y = pay + n_y * rc;
+    p2x = pbx + n_x * (-rp); p2y = pby + n_y * (-rp);
+    return 1;
+}
+
+// contact record in LDS: conf[q*12 + ..] = nx ny r1x r1y r2x r2y nMass bias jBias jnAcc bounce -
+//                        coni[q*4 + ..] = a b first cache_index (wall: i*K+slot, pair: 1<<20 | pi)
+// [CP cpSpaceStep] for one env.  Executed wave-uniformly (every lane computes the same values and
+// stores them to the same LDS words) except the bb-overlap test, where lanes stride the walls.
+__device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
+{
+    const int A = p.A;
+    const double dt = p.dt, rc = p.rc;
+    for (int i = 0; i < A; i++) {
+        // [CP cpBodyUpdatePosition]
+        double px = L.pos[2 * i] + (L.vel[2 * i] + L.vb[2 * i]) * dt;
+        double py = L.pos[2 * i + 1] + (L.vel[2 * i + 1] + L.vb[2 * i + 1]) * dt;
+        L.pos[2 * i] = px; L.pos[2 * i + 1] = py;
+        L.vb[2 * i] = 0.0; L.vb[2 * i + 1] = 0.0;
+        L.tc[2 * i] = px; L.tc[2 * i + 1] = py;  // [CP cpCircleShapeCacheData]
+        double bl = px - rc, bb_ = py - rc, br = px + rc, bt = py + rc;
+        double *lf = L.leaf + 4 * i;             // [CP LeafUpdate] / [CP GetBB]
+        if (!(lf[0] <= bl && lf[2] >= br && lf[1] <= bb_ && lf[3] >= bt)) {
+            double x = (br - bl) * 0.1, y = (bt - bb_) * 0.1;
+            double vx = L.vel[2 * i] * 0.1, vy = L.vel[2 * i + 1] * 0.1;
+            lf[0] = bl + fmin2(-x, vx); lf[1] = bb_ + fmin2(-y, vy);
+            lf[2] = br + fmax2(x, vx); lf[3] = bt + fmax2(y, vy);
+        }
+    }
+    int nc = 0;
+    unsigned long long seen_w = 0ull;  // bit i*K+slot (A*K <= 64)
+    unsigned seen_p = 0u;
+    for (int i = 0; i < A; i++) {
+        const double cx = L.tc[2 * i], cy = L.tc[2 * i + 1];
+        const double bl = cx - rc, bb_ = cy - rc, br = cx + rc, bt = cy + rc;
+        for (int base = 0; base < S; base += kLanes) {
+            const int s = base + lane;
+            bool ov = false;
+            if (s < S) {
+                const double *sb = L.bb + 4 * s;  // [CP cpBBIntersects]
+                ov = (bl <= sb[2] && sb[0] <= br && bb_ <= sb[3] && sb[1] <= bt);
+            }
+            unsigned long long m = __ballot(ov);
+            while (m) {
+                const int sh = base + __builtin_ctzll(m);
+                m &= m - 1;
+                double nx, ny, p1x, p1y, p2x, p2y;
+                if (!circle_poly_contact(L, sh, p.wall_r, cx, cy, rc, nx, ny, p1x, p1y, p2x, p2y)) continue;
+                int slot = -1;
+                for (int k = 0; k < kK; k++) if (slot < 0 && L.wsh[i * kK + k] == sh) slot = k;
+                int first;
+                if (slot < 0) {
+                    first = 1;
+                    for (int k = 0; k < kK; k++) if (slot < 0 && L.wsh[i * kK + k] < 0) slot = k;
+                    if (slot < 0) {
+                        int oldest = -1;
+                        for (int k = 0; k < kK; k++)
+                            if (!((seen_w >> (i * kK + k)) & 1ull) && (oldest < 0 || L.wag[i * kK + k] > L.wag[i * kK + oldest])) oldest = k;
+                        if (oldest < 0) continue;
+                        slot = oldest;
+                    }
+                    L.wsh[i * kK + slot] = sh; L.wjn[i * kK + slot] = 0.0; L.wag[i * kK + slot] = 0;
+                } else {
+                    first = L.wag[i * kK + slot] > 0;
+                }
+                seen_w |= 1ull << (i * kK + slot);
+                double *cf = L.conf + 12 * nc;
+                int *ci = L.coni + 4 * nc;
+                cf[0] = nx; cf[1] = ny;
+                cf[2] = p1x - L.pos[2 * i]; cf[3] = p1y - L.pos[2 * i + 1];
+                cf[4] = p2x - 0.0; cf[5] = p2y - 0.0;
+                cf[9] = L.wjn[i * kK + slot];
+                ci[0] = i; ci[1] = -1; ci[2] = first; ci[3] = i * kK + slot;
+                nc++;
+            }
+        }
+    }
+    for (int i = 0; i < A; i++) {
+        for (int j = i + 1; j < A; j++) {  // [CP CircleToCircle]
+            double mindist = rc + rc;
+            double dx = L.tc[2 * j] - L.tc[2 * i], dy = L.tc[2 * j + 1] - L.tc[2 * i + 1];
+            double distsq = dx * dx + dy * dy;
+            if (!(distsq < mindist * mindist)) continue;
+            double dist = sqrt(distsq);
+            double nx = 1.0, ny = 0.0;
+            if (dist != 0.0) { double inv = 1.0 / dist; nx = dx * inv; ny = dy * inv; }
+            const int pi = pair_index(A, i, j);
+            int first;
+            if (L.pag[pi] < 0) { first = 1; L.pjn[pi] = 0.0; }
+            else first = L.pag[pi] > 0;
+            L.pag[pi] = 0; seen_p |= 1u << pi;
+            double *cf = L.conf + 12 * nc;
+            int *ci = L.coni + 4 * nc;
+            double p1x = L.tc[2 * i] + nx * rc, p1y = L.tc[2 * i + 1] + ny * rc;
+            double p2x = L.tc[2 * j] + nx * (-rc), p2y = L.tc[2 * j + 1] + ny * (-rc);
+            cf[0] = nx; cf[1] = ny;
+            cf[2] = p1x - L.pos[2 * i]; cf[3] = p1y - L.pos[2 * i + 1];
+            cf[4] = p2x - L.pos[2 * j]; cf[5] = p2y - L.pos[2 * j + 1];
+            cf[9] = L.pjn[pi];
+            ci[0] = i; ci[1] = j; ci[2] = first; ci[3] = (1 << 20) | pi;
+            nc++;
+        }
+    }
+    // [CP cpSpaceArbiterSetFilter]: age / expire
+    for (int q = 0; q < A * kK; q++) {
+        if (L.wsh[q] < 0) continue;
+        if ((seen_w >> q) & 1ull) L.wag[q] = 0;
+        else {
+            int a = L.wag[q] + 1;
+            if (a >= p.persistence) { L.wsh[q] = -1; L.wag[q] = 0; L.wjn[q] = 0.0; }
+            else L.wag[q] = a;
+        }
+    }
+    for (int q = 0; q < p.NP; q++) {
+        if (L.pag[q] < 0 || ((seen_p >> q) & 1u)) continue;
+        int a = L.pag[q] + 1;
+        if (a >= p.persistence) { L.pag[q] = -1; L.pjn[q] = 0.0; }
+        else L.pag[q] = a;
+    }
+    if (nc == 0) return;
+    const double m_inv = 1.0 / p.mass;
+    for (int q = 0; q < nc; q++) {  // [CP cpArbiterPreStep]
+        double *cf = L.conf + 12 * q;
+        const int *ci = L.coni + 4 * q;
+        const int a = ci[0], b = ci[1];
+        double mib = (b < 0) ? 0.0 : m_inv;
+        cf[6] = 1.0 / (m_inv + mib);
+        double bpx = (b < 0) ? 0.0 : L.pos[2 * b], bpy = (b < 0) ? 0.0 : L.pos[2 * b + 1];
+        double bdx = bpx - L.pos[2 * a], bdy = bpy - L.pos[2 * a + 1];
+        double dist = ((cf[4] - cf[2]) + bdx) * cf[0] + ((cf[5] - cf[3]) + bdy) * cf[1];
+        cf[7] = -p.bias_coef * fmin2(0.0, dist + p.slop) / dt;
+        cf[8] = 0.0;
+        double vbx = (b < 0) ? 0.0 : L.vel[2 * b], vby = (b < 0) ? 0.0 : L.vel[2 * b + 1];
+        cf[10] = ((vbx - L.vel[2 * a]) * cf[0] + (vby - L.vel[2 * a + 1]) * cf[1]) * 0.0;
+    }
+    for (int q = 0; q < nc; q++) {  // [CP cpArbiterApplyCachedImpulse], dt_coef = 1
+        const double *cf = L.conf + 12 * q;
+        const int *ci = L.coni + 4 * q;
+        if (ci[2]) continue;
+        const int a = ci[0], b = ci[1];
+        double jx = (cf[0] * cf[9] - cf[1] * 0.0) * 1.0, jy = (cf[0] * 0.0 + cf[1] * cf[9]) * 1.0;
+        L.vel[2 * a] = L.vel[2 * a] + (-jx) * m_inv; L.vel[2 * a + 1] = L.vel[2 * a + 1] + (-jy) * m_inv;
+        if (b >= 0) { L.vel[2 * b] = L.vel[2 * b] + jx * m_inv; L.vel[2 * b + 1] = L.vel[2 * b + 1] + jy * m_inv; }
+    }
+    for (int it = 0; it < p.iterations; it++) {  // [CP cpArbiterApplyImpulse]
+        for (int q = 0; q < nc; q++) {
+            double *cf = L.conf + 12 * q;
+            const int *ci = L.coni + 4 * q;
+            const int a = ci[0], b = ci[1];
+            const double nx = cf[0], ny = cf[1];
+            double vbbx = (b < 0) ? 0.0 : L.vb[2 * b], vbby = (b < 0) ? 0.0 : L.vb[2 * b + 1];
+            double vvbx = (b < 0) ? 0.0 : L.vel[2 * b], vvby = (b < 0) ? 0.0 : L.vel[2 * b + 1];
+            double vbax = L.vb[2 * a], vbay = L.vb[2 * a + 1], vax = L.vel[2 * a], vay = L.vel[2 * a + 1];
+            double vbn = (vbbx - vbax) * nx + (vbby - vbay) * ny;
+            double vrn = (vvbx - vax) * nx + (vvby - vay) * ny;
+            double jbn = (cf[7] - vbn) * cf[6];
+            double jbnOld = cf[8];
+            double jBias = fmax2(jbnOld + jbn, 0.0);
+            cf[8] = jBias;
+            double jn = -(cf[10] + vrn) * cf[6];
+            double jnOld = cf[9];
+            double jnAcc = fmax2(jnOld + jn, 0.0);
+            cf[9] = jnAcc;
+            double jbx = nx * (jBias - jbnOld), jby = ny * (jBias - jbnOld);
+            double dj = jnAcc - jnOld;
+            double jx = nx * dj - ny * 0.0, jy = nx * 0.0 + ny * dj;
+            L.vb[2 * a] = vbax + (-jbx) * m_inv; L.vb[2 * a + 1] = vbay + (-jby) * m_inv;
+            L.vel[2 * a] = vax + (-jx) * m_inv; L.vel[2 * a + 1] = vay + (-jy) * m_inv;
+            if (b >= 0) {
+                L.vb[2 * b] = vbbx + jbx * m_inv; L.vb[2 * b + 1] = vbby + jby * m_inv;
+                L.vel[2 * b] = vvbx + jx * m_inv; L.vel[2 * b + 1] = vvby + jy * m_inv;
+            }
+        }
+    }
+    for (int q = 0; q < nc; q++) {
+        const int idx = L.coni[4 * q + 3];
+        if (idx & (1 << 20)) L.pjn[idx & 0xFFFFF] = L.conf[12 * q + 9];
+        else L.wjn[idx] = L.conf[12 * q + 9];
+    }
+}
+
+// ------------------------------------------------------------------ kernel plumbing -----------
+__device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc &md, int wave)
+{
+    Lds L;
+    const int S = md.S, P = md.P;
+    L.bb = reinterpret_cast<const double *>(smem);
+    L.planes = L.bb + 4 * S;
+    L.first = reinterpret_cast<const int *>(L.planes + 8 * P);
+    L.count = L.first + S;
+    char *w = smem + p.lds_map_bytes + wave * p.lds_wave_bytes;
+    const int A = p.A;
+    double *d = reinterpret_cast<double *>(w);
+    L.pos = d; d += 2 * A; L.vel = d; d += 2 * A; L.vb = d; d += 2 * A; L.tc = d; d += 2 * A;
+    L.leaf = d; d += 4 * A; L.spawn = d; d += 2 * A;
+    L.wjn = d; d += A * kK; L.pjn = d; d += (p.NP > 0 ? p.NP : 1);
+    L.conf = d; d += 12 * p.maxc;
+    int *iv = reinterpret_cast<int *>(d);
+    L.wsh = iv; iv += A * kK; L.wag = iv; iv += A * kK; L.pag = iv; iv += (p.NP > 0 ? p.NP : 1);
+    L.coni = iv; iv += 4 * p.maxc; L.cand = iv; iv += CAT_MAX_SHAPES;
+    L.od = reinterpret_cast<unsigned short *>(iv);
+    L.ot = reinterpret_cast<unsigned char *>(L.od + align_up(A * p.R, 4));
+    return L;
+}
+
+__device__ __forceinline__ void stage_map(const Params &p, char *smem, const MapDesc &md)
+{
+    const int nf = 4 * md.S + 8 * md.P;
+    double *dst = reinterpret_cast<double *>(smem);
+    const double *src = p.geo_f64 + md.f64_off;
+    for (int i = threadIdx.x; i < nf; i += blockDim.x) dst[i] = src[i];
+    int *di = reinterpret_cast<int *>(dst + nf);
+    const int *si = p.geo_i32 + md.i32_off;
+    for (int i = threadIdx.x; i < 2 * md.S; i += blockDim.x) di[i] = si[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void load_state(const Lds &L, const Params &p, int env, int lane)
+{
+    const int A = p.A;
+    const size_t b2 = (size_t)env * A * 2, b4 = (size_t)env * A * 4, bk = (size_t)env * A * kK;
+    if (lane < 2 * A) {
+        L.pos[lane] = p.pos[b2 + lane]; L.vel[lane] = p.vel[b2 + lane];
+        L.vb[lane] = p.vbias[b2 + lane]; L.tc[lane] = p.tc[b2 + lane];
+    }
+    if (lane < 4 * A) L.leaf[lane] = p.leaf[b4 + lane];
+    if (lane < A * kK) { L.wsh[lane] = p.wsh[bk + lane]; L.wag[lane] = p.wag[bk + lane]; L.wjn[lane] = p.wjn[bk + lane]; }
+    if (lane < p.NP) { L.pag[lane] = p.pag[(size_t)env * p.NP + lane]; L.pjn[lane] = p.pjn[(size_t)env * p.NP + lane]; }
+    wave_sync();
+}
+
+__device__ __forceinline__ void store_state(const Lds &L, const Params &p, int env, int lane, bool physics)
+{
+    const int A = p.A;
+    const size_t b2 = (size_t)env * A * 2, b4 = (size_t)env * A * 4, bk = (size_t)env * A * kK;
+    wave_sync();
+    if (lane < 2 * A) {
+        p.pos[b2 + lane] = L.pos[lane]; p.vel[b2 + lane] = L.vel[lane];
+        if (physics) { p.vbias[b2 + lane] = L.vb[lane]; p.tc[b2 + lane] = L.tc[lane]; }
+    }
+    if (physics) {
+        if (lane < 4 * A) p.leaf[b4 + lane] = L.leaf[lane];
+        if (lane < A * kK) { p.wsh[bk + lane] = L.wsh[lane]; p.wag[bk + lane] = L.wag[lane]; p.wjn[bk + lane] = L.wjn[lane]; }
+        if (lane < p.NP) { p.pag[(size_t)env * p.NP + lane] = L.pag[lane]; p.pjn[(size_t)env * p.NP + lane] = L.pjn[lane]; }
+    }
+}
+
+// BaseEnv.step (base_env.py:354-413), one wave per env
+__global__ __launch_bounds__(kWaves *kLanes) void tick_kernel(const Params p)
+{
+    extern __shared__ __align__(16) char smem[];
+    const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
+    const MapDesc md = p.maps[p.block_map[blockIdx.x]];
+    stage_map(p, smem, md);
+    const int env = p.work_env[blockIdx.x * kWaves + wave];
+    if (env < 0) return;
+    const Lds L = carve(p, smem, md, wave);
+    const int S = md.S, A = p.A;
+    load_state(L, p, env, lane);
+
+    const int step = p.step_count[env] + 1;                       // :372
+    const int captured = termination_captured(L, p, S, lane);     // :378
+    const int timeout = (!captured && step >= p.max_step) ? 1 : 0;
+
+    // Entity._perform_action (entity.py:126-134), every lane computes all agents identically
+    const double m_inv = 1.0 / p.mass;
+    for (int i = 0; i < A; i++) {
+        const int act = p.actions[(size_t)env * A + i];
+        double jx = 0.0, jy = 0.0;
+        if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
+        else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
+        double vx = L.vel[2 * i] + jx * m_inv, vy = L.vel[2 * i + 1] + jy * m_inv;
+        double len = sqrt(vx * vx + vy * vy);
+        if (len > p.max_speed) { vx = vx / len * p.max_speed; vy = vy / len * p.max_speed; }
+        L.vel[2 * i] = vx; L.vel[2 * i + 1] = vy;
+    }
+
+    observe_env(L, p, env, lane, S, 1, captured, timeout);        // entity.py:143-144, :388-390
+    physics_env(L, p, S, lane);                                   // :392
+    store_state(L, p, env, lane, true);
+    if (lane == 0) {
+        p.step_count[env] = step;
+        const unsigned char term = (unsigned char)(captured || timeout);
+        p.done[env] = term;
+        if (p.out.terminated) p.out.terminated[env] = term;       // entity.py:146
+        if (p.out.truncated) p.out.truncated[env] = (unsigned char)timeout;  // :397
+        if (p.out.winner) p.out.winner[env] = (signed char)(captured ? 0 : (timeout ? 1 : -1));  // :399-406
+    }
+}
+
+// BaseEnv.reset (base_env.py:286-352) for masked envs
+__global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params p)
+{
+    extern __shared__ __align__(16) char smem[];
+    const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
+    const MapDesc md = p.maps[p.block_map[blockIdx.x]];
+    stage_map(p, smem, md);
+    const int env = p.work_env[blockIdx.x * kWaves + wave];
+    if (env < 0) return;
+    if (p.use_done_mask) { if (!p.done[env]) return; }
+    else if (p.mask && !p.mask[env]) return;
+    const Lds L = carve(p, smem, md, wave);
+    const int S = md.S, A = p.A;
+    load_state(L, p, env, lane);
+    const unsigned rc = (unsigned)(p.reset_count[env] + 1);
+    const double *start = p.geo_f64 + md.f64_off + 4 * md.S + 8 * md.P;
+    const double *regions = start + 2 * md.A;
+    const int *region_off = p.geo_i32 + md.i32_off + 2 * md.S;
+
+    for (int i = 0; i < A; i++) {
+        double sx, sy;
+        if (p.positions) {
+            sx = p.positions[((size_t)env * A + i) * 2]; sy = p.positions[((size_t)env * A + i) * 2 + 1];
+        } else {
+            const int r0 = region_off[i], nr = region_off[i + 1] - r0;
+            if (nr <= 0) { sx = start[2 * i]; sy = start[2 * i + 1]; }      // :323-332 Entity.reset()
+            else {
+                unsigned rnd[4];
+                philox_env(p, env, rc, (unsigned)i, 0x100u, rnd);
+                const double *rg = regions + 4 * (r0 + (int)(rnd[0] % (unsigned)nr));  // :144-145
+                const double rgx = rg[0], rgy = rg[1], rgw = rg[2], rgh = rg[3];
+                bool ok = false;
+                sx = rgx + rgw / 2; sy = rgy + rgh / 2;                     // :163-166 fallback
+                for (int att = 0; att < 20 && !ok; att++) {                 // :151
+                    philox_env(p, env, rc, (unsigned)i, 0x200u + (unsigned)att, rnd);
+                    const double x = rgx + ((rgx + rgw) - rgx) * u53(rnd[0], rnd[1]);  // map_utils.py:9-10
+                    const double y = rgy + ((rgy + rgh) - rgy) * u53(rnd[2], rnd[3]);
+                    // Space.point_query_nearest(pos, radius, ray_filter) is None  (:154-157)
+                    bool any = false;
+                    for (int j = 0; j < A; j++) {
+                        if (j == i) continue;
+                        double ex = x - L.tc[2 * j], ey = y - L.tc[2 * j + 1];
+                        if (sqrt(ex * ex + ey * ey) - p.rc < p.rc) any = true;
+                    }
+                    for (int base = 0; base < S && !any; base += kLanes) {
+                        const int s = base + lane;
+                        bool hit = false;
+                        if (s < S) {
+                            const double *bb = L.bb + 4 * s;
+                            const double m = p.rc + 1e-6;
+                            if ((bb[0] - m <= x) && (x <= bb[2] + m) && (bb[1] - m <= y) && (y <= bb[3] + m))
+                                hit = poly_point_distance(L, s, p.wall_r, x, y) < p.rc;
+                        }
+                        any = (__ballot(hit) != 0ull);
+                    }
+                    if (!any) { sx = x; sy = y; ok = true; }
+                }
+            }
+        }
+        L.spawn[2 * i] = sx; L.spawn[2 * i + 1] = sy;
+    }
+    for (int i = 0; i < A; i++) {  // Entity.reset (entity.py:148-157); shape caches stay stale (Q1)
+        L.pos[2 * i] = L.spawn[2 * i]; L.pos[2 * i + 1] = L.spawn[2 * i + 1];
+        L.vel[2 * i] = 0.0; L.vel[2 * i + 1] = 0.0;
+    }
+    observe_env(L, p, env, lane, S, 0, 0, 0);   // :334-344
+    store_state(L, p, env, lane, false);
+    if (lane == 0) { p.step_count[env] = 0; p.reset_count[env] = (int)rc; p.done[env] = 0; }  // :350
+}
+
+__global__ void random_actions_kernel(const Params p, unsigned long long tick, int *actions)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.N * p.A) return;
+    const int env = idx / p.A, i = idx % p.A;
+    unsigned rnd[4];
+    philox_env(p, env, (unsigned)tick, (unsigned)i, 0xAC710u, rnd);
+    actions[idx] = (int)(rnd[0] & 3u);
+}
+
+__global__ void selftest_kernel(int op, const double *a, const double *b, double *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r = 0.0;
+    if (op == 0) r = sqrt(a[i]);
+    else if (op == 1) r = a[i] / b[i];
+    else if (op == 2) r = (double)f64_to_f16(a[i]);
+    else if (op == 3) r = (double)obs_distance_f16(a[i], b[i], 0.0, 0.0);
+    out[i] = r;
+}
+
+thread_local char g_create_err[256] = "";
+
+}  // namespace
+
+// ====================================================================== host side ============
+struct cat_sim {
+    Params p;
+    int device;
+    int n_blocks;
+    size_t lds_bytes;
+    std::vector<MapDesc> maps;
+    std::vector<void *> allocs;
+    char err[256];
+};
+
+#define HIP_TRY(sim, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            snprintf((sim)->err, sizeof((sim)->err), "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            return CAT_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(cat_sim *s, T **ptr, size_t count, const void *init)
+{
+    void *d = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_TRY(s, hipMalloc(&d, bytes));
+    s->allocs.push_back(d);
+    if (init) HIP_TRY(s, hipMemcpy(d, init, count * sizeof(T), hipMemcpyHostToDevice));
+    else HIP_TRY(s, hipMemset(d, 0, bytes));
+    *ptr = static_cast<T *>(d);
+    return CAT_OK;
+}
+
+extern "C" int cat_abi_version(void) { return CAT_ABI_VERSION; }
+extern "C" const char *cat_last_error(const cat_sim *sim) { return sim ? sim->err : g_create_err; }
+extern "C" int cat_num_agents(const cat_sim *sim) { return sim ? sim->p.A : CAT_ERR_BAD_ARG; }
+extern "C" int cat_num_shapes(const cat_sim *sim, int m)
+{
+    if (!sim || m < 0 || m >= (int)sim->maps.size()) return CAT_ERR_BAD_ARG;
+    return sim->maps[m].S;
+}
+
+extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const void *const *blobs,
+                          const size_t *sizes, int n_maps, const int32_t *slot_map_ids, int device,
+                          cat_sim **out)
+{
+    if (!cfg || !tab || !blobs || !sizes || !out || n_maps < 1) {
+        snprintf(g_create_err, sizeof g_create_err, "null argument");
+        return CAT_ERR_BAD_ARG;
+    }
+    const int A = cfg->n_cops + cfg->n_thieves;
+    if (A < 1 || A > CAT_MAX_AGENTS || cfg->n_cops < 0 || cfg->n_thieves < 0 || cfg->n_rays < 1 ||
+        cfg->n_rays > CAT_MAX_RAYS || cfg->n_envs < 1 || A * kK > 64) {
+        snprintf(g_create_err, sizeof g_create_err, "bad config: agents=%d rays=%d envs=%d", A, cfg->n_rays, cfg->n_envs);
+        return CAT_ERR_BAD_CONFIG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) {
+        snprintf(g_create_err, sizeof g_create_err, "no usable HIP device (count=%d, requested %d): this library has no CPU path", ndev, device);
+        return CAT_ERR_NO_DEVICE;
+    }
+    // ---- parse blobs into one packed geometry buffer
+    std::vector<MapDesc> descs((size_t)n_maps);
+    std::vector<double> geo_f;
+    std::vector<int> geo_i;
+    int maxS = 0, maxP = 0;
+    for (int m = 0; m < n_maps; m++) {
+        const unsigned char *b = static_cast<const unsigned char *>(blobs[m]);
+        int32_t h[16];
+        if (sizes[m] < 64) { snprintf(g_create_err, sizeof g_create_err, "map blob %d too small", m); return CAT_ERR_BAD_MAP; }
+        memcpy(h, b, 64);
+        MapDesc d{};
+        d.S = h[2]; d.P = h[3]; d.A = h[4]; d.n_regions = h[7];
+        const size_t nf = 2 + 4 * (size_t)d.S + 8 * (size_t)d.P + 2 * (size_t)d.A + 4 * (size_t)d.n_regions;
+        const size_t ni = 2 * (size_t)d.S + (size_t)d.A + 1;
+        if ((unsigned)h[0] != kBlobMagic || h[1] != 1 || sizes[m] != 64 + nf * 8 + ni * 4 || d.A != A ||
+            h[5] != cfg->n_cops || d.S < 1 || d.S > CAT_MAX_SHAPES) {
+            snprintf(g_create_err, sizeof g_create_err, "map blob %d invalid, roster mismatch or more than %d shapes", m, CAT_MAX_SHAPES);
+            return CAT_ERR_BAD_MAP;
+        }
+        std::vector<double> f(nf);
+        std::vector<int> iv(ni);
+        memcpy(f.data(), b + 64, nf * 8);
+        memcpy(iv.data(), b + 64 + nf * 8, ni * 4);
+        d.f64_off = (int)geo_f.size();
+        geo_f.insert(geo_f.end(), f.begin() + 2, f.end());  // drop window w,h
+        d.i32_off = (int)geo_i.size();
+        geo_i.insert(geo_i.end(), iv.begin(), iv.end());
+        if (geo_f.size() & 1) geo_f.push_back(0.0);  // keep 16-byte alignment of each map's base
+        descs[m] = d;
+        maxS = d.S > maxS ? d.S : maxS;
+        maxP = d.P > maxP ? d.P : maxP;
+    }
+    const int N = cfg->n_envs;
+    std::vector<int> slot((size_t)N, 0);
+    for (int e = 0; e < N; e++) {
+        if (slot_map_ids) slot[e] = slot_map_ids[e];
+        if (slot[e] < 0 || slot[e] >= n_maps) {
+            snprintf(g_create_err, sizeof g_create_err, "slot_map_ids[%d]=%d out of range", e, slot[e]);
+            return CAT_ERR_BAD_SLOT_MAP;
+        }
+    }
+    // ---- work list: workgroups are map-homogeneous; env slots grouped by map, padded with -1
+    std::vector<int> work, block_map;
+    for (int m = 0; m < n_maps; m++) {
+        int cnt = 0;
+        for (int e = 0; e < N; e++)
+            if (slot[e] == m) {
+                if (cnt % kWaves == 0) block_map.push_back(m);
+                work.push_back(e);
+                cnt++;
+            }
+        while (cnt % kWaves) { work.push_back(-1); cnt++; }
+    }
+
+    cat_sim *s = new cat_sim();
+    s->err[0] = 0;
+    s->device = device;
+    s->maps = descs;
+    s->n_blocks = (int)block_map.size();
+    if (hipSetDevice(device) != hipSuccess) {
+        snprintf(g_create_err, sizeof g_create_err, "hipSetDevice(%d) failed", device);
+        delete s;
+        return CAT_ERR_NO_DEVICE;
+    }
+    Params &p = s->p;
+    memset(&p, 0, sizeof p);
+    p.N = N; p.A = A; p.n_cops = cfg->n_cops; p.R = cfg->n_rays; p.max_step = cfg->max_step_count;
+    p.iterations = cfg->iterations; p.persistence = cfg->persistence; p.gate = cfg->bbtree_gate;
+    p.NP = A * (A - 1) / 2; p.maxc = A * kK + p.NP;
+    p.env_id_offset = cfg->env_id_offset; p.seed = cfg->seed;
+    p.dt = cfg->dt; p.bias_coef = cfg->bias_coef; p.slop = cfg->slop; p.ray_length = cfg->ray_length;
+    p.ray_radius = cfg->ray_radius; p.rc = cfg->agent_radius; p.mass = cfg->agent_mass; p.impulse = cfg->impulse;
+    p.max_speed = cfg->max_speed; p.term_radius = cfg->termination_radius; p.wall_r = cfg->wall_radius;
+
+    int rc = CAT_OK;
+    auto fail = [&](int code) { strncpy(g_create_err, s->err, sizeof g_create_err - 1); cat_destroy(s); return code; };
+    const size_t NA = (size_t)N * A;
+    std::vector<double> pos0(NA * 2), leaf0(NA * 4);
+    std::vector<int> wsh0(NA * kK, -1), pag0((size_t)N * (p.NP ? p.NP : 1), -1);
+    for (int e = 0; e < N; e++) {
+        const MapDesc &d = descs[slot[e]];
+        const double *start = geo_f.data() + d.f64_off + 4 * d.S + 8 * d.P;
+        for (int i = 0; i < A; i++) {
+            // Entity.__init__ + space.add: caches and BBTree leaf at the start position, v = 0
+            const size_t q = (size_t)e * A + i;
+            const double x = start[2 * i], y = start[2 * i + 1], r = cfg->agent_radius;
+            pos0[2 * q] = x; pos0[2 * q + 1] = y;
+            const double l = x - r, b = y - r, rr = x + r, t = y + r;
+            const double mx = (rr - l) * 0.1, my = (t - b) * 0.1;
+            leaf0[4 * q] = l + (-mx < 0.0 ? -mx : 0.0); leaf0[4 * q + 1] = b + (-my < 0.0 ? -my : 0.0);
+            leaf0[4 * q + 2] = rr + (mx > 0.0 ? mx : 0.0); leaf0[4 * q + 3] = t + (my > 0.0 ? my : 0.0);
+        }
+    }
+#define TRY_ALLOC(call) do { rc = (call); if (rc != CAT_OK) return fail(rc); } while (0)
+    TRY_ALLOC(dev_alloc(s, const_cast<double **>(&p.ray_dx), (size_t)p.R, tab->ray_dx));
+    TRY_ALLOC(dev_alloc(s, const_cast<double **>(&p.ray_dy), (size_t)p.R, tab->ray_dy));
+    TRY_ALLOC(dev_alloc(s, const_cast<float **>(&p.cop_lut), 32768, tab->cop_reward_lut));
+    TRY_ALLOC(dev_alloc(s, const_cast<float **>(&p.thief_lut), 32768, tab->thief_reward_lut));
+    TRY_ALLOC(dev_alloc(s, const_cast<MapDesc **>(&p.maps), descs.size(), descs.data()));
+    TRY_ALLOC(dev_alloc(s, const_cast<double **>(&p.geo_f64), geo_f.size(), geo_f.data()));
+    TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.geo_i32), geo_i.size(), geo_i.data()));
+    TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.work_env), work.size(), work.data()));
+    TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.block_map), block_map.size(), block_map.data()));
+    TRY_ALLOC(dev_alloc(s, &p.pos, NA * 2, pos0.data()));
+    TRY_ALLOC(dev_alloc(s, &p.tc, NA * 2, pos0.data()));
+    TRY_ALLOC(dev_alloc(s, &p.vel, NA * 2, nullptr));
+    TRY_ALLOC(dev_alloc(s, &p.vbias, NA * 2, nullptr));
+    TRY_ALLOC(dev_alloc(s, &p.leaf, NA * 4, leaf0.data()));
+    TRY_ALLOC(dev_alloc(s, &p.wsh, NA * kK, wsh0.data()));
+    TRY_ALLOC(dev_alloc(s, &p.wag, NA * kK, nullptr));
+    TRY_ALLOC(dev_alloc(s, &p.wjn, NA * kK, nullptr));
+    TRY_ALLOC(dev_alloc(s, &p.pag, pag0.size(), pag0.data()));
+    TRY_ALLOC(dev_alloc(s, &p.pjn, pag0.size(), nullptr));
+    TRY_ALLOC(dev_alloc(s, &p.step_count, (size_t)N, nullptr));
+    TRY_ALLOC(dev_alloc(s, &p.reset_count, (size_t)N, nullptr));
+    TRY_ALLOC(dev_alloc(s, &p.done, (size_t)N, nullptr));
+#undef TRY_ALLOC
+    // ---- LDS carve sizes (must match carve())
+    auto up = [](int x, int a) { return (x + a - 1) / a * a; };
+    p.lds_map_bytes = up((4 * maxS + 8 * maxP) * 8 + 2 * maxS * 4, 16);
+    const int NPs = p.NP > 0 ? p.NP : 1;
+    int wb = (2 * A * 4 + 4 * A + 2 * A + A * kK + NPs + 12 * p.maxc) * 8;
+    wb += (A * kK * 2 + NPs + 4 * p.maxc + CAT_MAX_SHAPES) * 4;
+    wb += up(A * p.R, 4) * 2 + up(A * p.R, 16);
+    p.lds_wave_bytes = up(wb, 16);
+    s->lds_bytes = (size_t)p.lds_map_bytes + (size_t)kWaves * p.lds_wave_bytes;
+    if (s->lds_bytes > 160 * 1024) {
+        snprintf(s->err, sizeof s->err, "LDS budget exceeded: %zu bytes", s->lds_bytes);
+        return fail(CAT_ERR_BAD_CONFIG);
+    }
+    if (s->lds_bytes > 64 * 1024) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(tick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            snprintf(s->err, sizeof s->err, "cannot raise dynamic LDS limit to %zu", s->lds_bytes);
+            return fail(CAT_ERR_HIP);
+        }
+    }
+    *out = s;
+    return CAT_OK;
+}
+
+extern "C" int cat_destroy(cat_sim *s)
+{
+    if (!s) return CAT_ERR_BAD_ARG;
+    (void)hipSetDevice(s->device);
+    for (void *d : s->allocs) (void)hipFree(d);
+    delete s;
+    return CAT_OK;
+}
+
+static int launch_reset(cat_sim *s, const uint8_t *mask, const double *positions, const cat_outputs *out,
+                        int use_done, void *stream)
+{
+    if (!s) return CAT_ERR_BAD_ARG;
+    HIP_TRY(s, hipSetDevice(s->device));
+    Params p = s->p;
+    if (out) p.out = *out;
+    p.mask = mask; p.positions = positions; p.use_done_mask = use_done;
+    hipLaunchKernelGGL(reset_kernel, dim3(s->n_blocks), dim3(kWaves * kLanes), s->lds_bytes,
+                       static_cast<hipStream_t>(stream), p);
+    HIP_TRY(s, hipGetLastError());
+    return CAT_OK;
+}
+
+extern "C" int cat_reset(cat_sim *s, const uint8_t *mask, const double *positions, const cat_outputs *out, void *stream)
+{
+    return launch_reset(s, mask, positions, out, 0, stream);
+}
+
+extern "C" int cat_reset_done(cat_sim *s, const cat_outputs *out, void *stream)
+{
+    return launch_reset(s, nullptr, nullptr, out, 1, stream);
+}
+
+extern "C" int cat_step(cat_sim *s, const int32_t *actions, const cat_outputs *out, void *stream)
+{
+    if (!s || !actions) { if (s) snprintf(s->err, sizeof s->err, "cat_step: actions is NULL"); return CAT_ERR_BAD_ARG; }
+    HIP_TRY(s, hipSetDevice(s->device));
+    Params p = s->p;
+    if (out) p.out = *out;
+    p.actions = actions;
+    hipLaunchKernelGGL(tick_kernel, dim3(s->n_blocks), dim3(kWaves * kLanes), s->lds_bytes,
+                       static_cast<hipStream_t>(stream), p);
+    HIP_TRY(s, hipGetLastError());
+    return CAT_OK;
+}
+
+extern "C" int cat_random_actions(cat_sim *s, uint64_t tick, int32_t *actions, void *stream)
+{
+    if (!s || !actions) return CAT_ERR_BAD_ARG;
+    HIP_TRY(s, hipSetDevice(s->device));
+    const int n = s->p.N * s->p.A;
+    hipLaunchKernelGGL(random_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       s->p, (unsigned long long)tick, actions);
+    HIP_TRY(s, hipGetLastError());
+    return CAT_OK;
+}
+
+static int copy_state(cat_sim *s, const cat_state *v, bool get, void *stream)
+{
+    if (!s || !v) return CAT_ERR_BAD_ARG;
+    HIP_TRY(s, hipSetDevice(s->device));
+    const Params &p = s->p;
+    const size_t NA = (size_t)p.N * p.A;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define CP(field, internal, bytes)                                                                        \
+    if (v->field) HIP_TRY(s, hipMemcpyAsync(get ? (void *)v->field : (void *)internal,                    \
+                                            get ? (const void *)internal : (const void *)v->field, bytes, \
+                                            hipMemcpyDeviceToDevice, st))
+    CP(pos, p.pos, NA * 16); CP(vel, p.vel, NA * 16); CP(vbias, p.vbias, NA * 16); CP(tc, p.tc, NA * 16);
+    CP(leaf_bb, p.leaf, NA * 32); CP(wall_shape, p.wsh, NA * kK * 4); CP(wall_age, p.wag, NA * kK * 4);
+    CP(wall_jn, p.wjn, NA * kK * 8);
+    if (p.NP > 0) { CP(pair_age, p.pag, (size_t)p.N * p.NP * 4); CP(pair_jn, p.pjn, (size_t)p.N * p.NP * 8); }
+    CP(step_count, p.step_count, (size_t)p.N * 4); CP(reset_count, p.reset_count, (size_t)p.N * 4);
+#undef CP
+    return CAT_OK;
+}
+
+extern "C" int cat_get_state(cat_sim *s, const cat_state *dst, void *stream) { return copy_state(s, dst, true, stream); }
+extern "C" int cat_set_state(cat_sim *s, const cat_state *src, void *stream) { return copy_state(s, src, false, stream); }
+
+extern "C" int cat_selftest_arith(int op, const double *a, const double *b, double *out, int n, int device, void *stream)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) {
+        snprintf(g_create_err, sizeof g_create_err, "no usable HIP device");
+        return CAT_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) return CAT_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), op, a, b, out, n);
+    return hipGetLastError() == hipSuccess ? CAT_OK : CAT_ERR_HIP;
+}

@@ -1,0 +1,149 @@
+"""`CatSim`: thin owner of one libcat_sim handle on one GPU, with torch tensors as the caller-owned
+device buffers.  torch is plumbing here (device memory, streams); every computation of the env
+tick happens inside the HIP kernels behind the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import tables
+from .config import C_FIELDS_F64, C_FIELDS_I32, SimConfig
+from .maps import CompiledMap
+
+_OUT_SPEC = {  # name -> (shape fn, torch dtype)
+    "obs_distance": (lambda N, A, R: (N, A, R), torch.float16),
+    "obs_type": (lambda N, A, R: (N, A, R), torch.uint8),
+    "hit_shape": (lambda N, A, R: (N, A, R), torch.int32),
+    "shared_distance": (lambda N, A, R: (N, 2, R), torch.float16),
+    "shared_type": (lambda N, A, R: (N, 2, R), torch.uint8),
+    "team_positions": (lambda N, A, R: (N, A, 2), torch.float16),
+    "reward": (lambda N, A, R: (N, A), torch.float32),
+    "terminated": (lambda N, A, R: (N,), torch.uint8),
+    "truncated": (lambda N, A, R: (N,), torch.uint8),
+    "winner": (lambda N, A, R: (N,), torch.int8),
+}
+
+
+def _state_spec(N: int, A: int):
+    NP = A * (A - 1) // 2
+    K = nat.WALL_CACHE
+    f, i = torch.float64, torch.int32
+    return {"pos": ((N, A, 2), f), "vel": ((N, A, 2), f), "vbias": ((N, A, 2), f), "tc": ((N, A, 2), f),
+            "leaf_bb": ((N, A, 4), f), "wall_shape": ((N, A, K), i), "wall_age": ((N, A, K), i),
+            "wall_jn": ((N, A, K), f), "pair_age": ((N, NP), i), "pair_jn": ((N, NP), f),
+            "step_count": ((N,), i), "reset_count": ((N,), i)}
+
+
+class CatSimError(RuntimeError):
+    pass
+
+
+class CatSim:
+    def __init__(self, cfg: SimConfig, maps: Sequence[CompiledMap], slot_map_ids=None,
+                 device: Optional[torch.device | int | str] = None, debug_hit_shape: bool = False):
+        self._h = None
+        self._L = nat.lib()  # raises NativeLibraryMissing when the extension is not built
+        if not torch.cuda.is_available():
+            raise CatSimError("no HIP device visible to torch: libcat_sim has no CPU path")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise CatSimError(f"device must be a GPU, got {dev}")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.cfg, self.N, self.A, self.R = cfg, cfg.n_envs, cfg.n_agents, cfg.n_rays
+        self.maps = list(maps)
+        c = nat.CatConfig()
+        for n in C_FIELDS_I32 + C_FIELDS_F64:
+            setattr(c, n, getattr(cfg, n))
+        c.env_id_offset, c.seed = cfg.env_id_offset, cfg.seed
+        dx, dy = tables.ray_table(cfg.sensor)
+        host = [dx, dy, tables.cop_reward_lut(), tables.thief_reward_lut()]
+        t = nat.CatTables(*[a.ctypes.data_as(C.c_void_p) for a in host])
+        blobs = [m.to_blob() for m in self.maps]
+        arr = (C.c_char_p * len(blobs))(*blobs)
+        sizes = (C.c_size_t * len(blobs))(*[len(b) for b in blobs])
+        ids = None if slot_map_ids is None else np.ascontiguousarray(slot_map_ids, np.int32)
+        h = C.c_void_p()
+        rc = self._L.cat_create(C.byref(c), C.byref(t), arr, sizes, len(blobs),
+                                None if ids is None else ids.ctypes.data_as(C.c_void_p), dev.index, C.byref(h))
+        if rc != 0:
+            raise CatSimError(f"cat_create: {nat.ERRORS.get(rc, rc)}: {self._L.cat_last_error(None).decode()}")
+        self._h = h
+        with torch.cuda.device(dev):
+            self.out: Dict[str, torch.Tensor] = {
+                k: torch.zeros(fn(self.N, self.A, self.R), dtype=dt, device=dev)
+                for k, (fn, dt) in _OUT_SPEC.items() if (k != "hit_shape" or debug_hit_shape)}
+        self._out_struct = nat.CatOutputs(*[self.out[k].data_ptr() if k in self.out else None
+                                            for k in nat.OUT_FIELDS])
+
+    # ------------------------------------------------------------------------------------
+    def close(self) -> None:
+        if self._h is not None:
+            self._L.cat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise CatSimError(f"{what}: {nat.ERRORS.get(rc, rc)}: {self._L.cat_last_error(self._h).decode()}")
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def reset(self, mask: Optional[torch.Tensor] = None, positions: Optional[torch.Tensor] = None):
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            assert mask.shape == (self.N,)
+        if positions is not None:
+            positions = positions.to(device=self.device, dtype=torch.float64).contiguous()
+            assert positions.shape == (self.N, self.A, 2)
+        self._check(self._L.cat_reset(self._h, None if mask is None else mask.data_ptr(),
+                                      None if positions is None else positions.data_ptr(),
+                                      C.byref(self._out_struct), self._stream()), "cat_reset")
+        return self.out
+
+    def reset_done(self):
+        self._check(self._L.cat_reset_done(self._h, C.byref(self._out_struct), self._stream()), "cat_reset_done")
+        return self.out
+
+    def step(self, actions: torch.Tensor):
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        if actions.shape != (self.N, self.A):
+            raise ValueError(f"actions must have shape {(self.N, self.A)}, got {tuple(actions.shape)}")
+        self._check(self._L.cat_step(self._h, actions.data_ptr(), C.byref(self._out_struct), self._stream()), "cat_step")
+        return self.out
+
+    def random_actions(self, tick: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty((self.N, self.A), dtype=torch.int32, device=self.device)
+        self._check(self._L.cat_random_actions(self._h, int(tick), out.data_ptr(), self._stream()), "cat_random_actions")
+        return out
+
+    def get_state(self) -> Dict[str, torch.Tensor]:
+        st = {k: torch.zeros(shape, dtype=dt, device=self.device) for k, (shape, dt) in _state_spec(self.N, self.A).items()}
+        view = nat.CatState(*[st[k].data_ptr() if st[k].numel() else None for k in nat.STATE_FIELDS])
+        self._check(self._L.cat_get_state(self._h, C.byref(view), self._stream()), "cat_get_state")
+        return st
+
+    def set_state(self, **arrays) -> None:
+        spec = _state_spec(self.N, self.A)
+        keep = {}
+        for k, v in arrays.items():
+            shape, dt = spec[k]
+            t = torch.as_tensor(v).to(device=self.device, dtype=dt).contiguous()
+            assert tuple(t.shape) == tuple(shape), (k, t.shape, shape)
+            keep[k] = t
+        view = nat.CatState(*[keep[k].data_ptr() if k in keep and keep[k].numel() else None for k in nat.STATE_FIELDS])
+        self._check(self._L.cat_set_state(self._h, C.byref(view), self._stream()), "cat_set_state")
+        torch.cuda.current_stream(self.device).synchronize()  # sources may be temporaries

@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the batched Cops-and-Thieves env core on MI355X.
+
+One "step" = one tick of the whole env batch on every GPU: synthetic Philox actions -> cat_step
+(the full BaseEnv.step pipeline) -> cat_reset_done (auto-reset of finished episodes).  Workload =
+BASELINE.json configs[1]: 2 cops vs 1 thief, labyrinth map, 4096 envs per GPU, 64 rays/agent.
+Env slots shard across GPUs with no data-path collective (weak scaling); only the timing uses a
+barrier + MAX all-reduce.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(A: int, R: int) -> int:
+    """actions 4A + body state r/w 2*48A + counters 8 + obs 3AR +
+    team-shared 6R + team positions 4A + rewards 4A."""
+    return 108 * A + 3 * A * R + 6 * R + 8
+
+
+def cpu_baseline(cfg, cmap, budget_s: float = 12.0):
+    """Times the CPU oracle (a port, not Pymunk: pymunk is not installable here) on this host:
+    single thread (the like-for-like of the reference's single process), then all cores."""
+    import numpy as np
+    from dataclasses import replace
+    from oracle import cat_oracle
+    n = 256
+    c = replace(cfg, n_envs=n)
+    res = {}
+    for label, threads in (("1core", 1), ("allcores", os.cpu_count() or 1)):
+        cat_oracle.lib().cato_set_threads(threads)
+        sim = cat_oracle.OracleSim(c, [cmap])
+        sim.reset()
+        acts = [sim.random_actions(t) for t in range(64)]
+        t0 = time.perf_counter()
+        ticks = 0
+        while time.perf_counter() - t0 < budget_s / 2:
+            out = sim.step(acts[ticks % 64])
+            sim.reset(mask=out["terminated"].copy())
+            ticks += 1
+        dt = time.perf_counter() - t0
+        res[label] = (n * ticks / dt, threads, ticks)
+    cat_oracle.lib().cato_set_threads(1)
+    v1, _, ticks1 = res["1core"]
+    va, ca, _ = res["allcores"]
+    return {"value": v1, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} envs x {ticks1} ticks of the same workload, CPU restatement (not Pymunk), 1 thread",
+            "allcores": {"value": va, "cores": ca}}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=4096, help="env slots per GPU")
+    ap.add_argument("--rays", type=int, default=64)
+    ap.add_argument("--map", default="labyrinth")
+    ap.add_argument("--cops", type=int, default=2)
+    ap.add_argument("--thieves", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.maps import load_preset
+    from as_cops_and_thieves_amd.sim import CatSim
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    cmap = load_preset(args.map, args.cops, args.thieves).compile()
+    cfg = SimConfig(n_envs=args.envs, n_cops=args.cops, n_thieves=args.thieves, n_rays=args.rays,
+                    max_step_count=400, seed=0, env_id_offset=rank * args.envs)
+    sim = CatSim(cfg, [cmap], device=dev)
+    sim.reset()
+    acts = torch.empty((cfg.n_envs, cfg.n_agents), dtype=torch.int32, device=dev)
+
+    def one_step(t: int) -> None:
+        sim.random_actions(t, out=acts)
+        sim.step(acts)
+        sim.reset_done()
+
+    for t in range(args.warmup):
+        one_step(t)
+
+    def fence() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        t = args.warmup + k
+        sim.random_actions(t, out=acts)
+        ev[k][0].record()           # HIP events on the stream the kernels are launched on
+        sim.step(acts)
+        ev[k][1].record()
+        sim.reset_done()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    tick_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    episodes = int(sim.get_state()["reset_count"].sum().item())
+
+    if rank == 0:
+        A, R = cfg.n_agents, cfg.n_rays
+        bytes_launch = algorithmic_bytes_per_env_step(A, R) * cfg.n_envs
+        achieved = bytes_launch / (tick_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/sec (whole node) at 4096 parallel envs, 2v1 agents, 64-ray sensors",
+            "value": world * cfg.n_envs * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.cops} cops vs {args.thieves} thieves, {args.map} map "
+                                   f"({cmap.n_shapes} hull walls / {cmap.n_planes} planes), {cfg.n_envs} envs per GPU, "
+                                   f"{R} rays/agent, dt=1/60, max_step_count=400, Philox random actions, auto-reset",
+                       "envs_per_gpu": cfg.n_envs, "rays": R, "agents": A, "map": args.map,
+                       "parallelism": f"env-sharded x{world}, no data-path collective",
+                       "episodes_reset_per_gpu": episodes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "tick_kernel", "kernel_ms": tick_ms,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "note": "path is FP64-VALU/LDS bound, not HBM bound (SURVEY 8d); fraction reported as contracted"},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, cmap)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sim.close()
+
+
+if __name__ == "__main__":
+    main()

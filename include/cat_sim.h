@@ -1,0 +1,165 @@
+/*
+ * cat_sim.h -- C ABI of libcat_sim.so, the MI355X (gfx950) batched Cops-and-Thieves env core.
+ *
+ * The reference has no FFI: its hot path sits behind the PettingZoo ParallelEnv Python API
+ * (SURVEY.md section 8b).  This ABI is what a binding for that path binds instead of Pymunk;
+ * each entry point names the reference interface it replaces (paths relative to
+ * /root/reference).  Conventions: opaque handle, int status (0 ok, <0 error; message from
+ * cat_last_error), no exceptions across the boundary, CALLER-OWNED DEVICE buffers, explicit
+ * hipStream_t passed as void* (NULL = default stream), one host thread per handle, handles are
+ * independent (one per GPU / per process).  There is no CPU fallback: every compute entry fails
+ * with CAT_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef CAT_SIM_H
+#define CAT_SIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAT_ABI_VERSION 1
+#define CAT_MAX_AGENTS 8
+#define CAT_MAX_RAYS 512
+#define CAT_MAX_SHAPES 256
+#define CAT_WALL_CACHE 8        /* cached wall arbiters per agent */
+
+enum {
+    CAT_OK = 0,
+    CAT_ERR_BAD_CONFIG = -1,
+    CAT_ERR_BAD_MAP = -2,
+    CAT_ERR_BAD_SLOT_MAP = -3,
+    CAT_ERR_NO_DEVICE = -4,
+    CAT_ERR_HIP = -5,
+    CAT_ERR_BAD_ARG = -6
+};
+
+/* ObjectType -- src/utils/object_types.py:4-9 */
+enum { CAT_WALL = 0, CAT_COP = 1, CAT_THIEF = 2, CAT_MOVABLE = 3, CAT_EMPTY = 4 };
+
+/* Replaces the constructor arguments of SimpleEnv/BaseEnv (src/environments/simple_env.py:14-38,
+   base_env.py:51-58), the constants of pyproject.toml:12-19, the sensor literals of
+   src/agents/entity.py:84-86,196 and Chipmunk2D's cpSpace defaults (base_env.py:77). */
+typedef struct cat_config {
+    int32_t n_envs;
+    int32_t n_cops;
+    int32_t n_thieves;
+    int32_t n_rays;
+    int32_t max_step_count;
+    int32_t iterations;
+    int32_t persistence;
+    int32_t bbtree_gate;          /* 1 = Chipmunk BBTree visiting rule for segment queries */
+    int64_t env_id_offset;        /* global id of env slot 0 (env sharding across GPUs) */
+    uint64_t seed;                /* Philox4x32-10 key */
+    double dt;
+    double bias_coef;             /* 1 - pow(collisionBias, dt), computed by the host */
+    double slop;
+    double ray_length;
+    double ray_radius;
+    double agent_radius;
+    double agent_mass;
+    double impulse;
+    double max_speed;
+    double termination_radius;
+    double wall_radius;
+} cat_config;
+
+/* HOST pointers, copied at create.  ray_dx/dy[k] = ray_length * cos/sin(2*pi*k/R) built with
+   NumPy as entity.py:182-193 builds them; reward LUTs indexed by float16 bits (cop.py:69-74,
+   thief.py:63-69 evaluated by NumPy per float16 value). */
+typedef struct cat_tables {
+    const double *ray_dx;         /* [R] */
+    const double *ray_dy;         /* [R] */
+    const float *cop_reward_lut;  /* [32768] */
+    const float *thief_reward_lut;/* [32768] */
+} cat_tables;
+
+/* DEVICE pointers; any may be NULL (that output is skipped). */
+typedef struct cat_outputs {
+    uint16_t *obs_distance;       /* [N,A,R] float16 bits -- Entity.get_observation "distance" */
+    uint8_t *obs_type;            /* [N,A,R]              -- "object_type" */
+    int32_t *hit_shape;           /* [N,A,R] -1 none, s wall, S+j agent j (parity/debug) */
+    uint16_t *shared_distance;    /* [N,2,R] team 0 cops / 1 thieves -- distance_shared */
+    uint8_t *shared_type;         /* [N,2,R]                          -- object_type_shared */
+    uint16_t *team_positions;     /* [N,A,2] float16 bits             -- team_positions */
+    float *reward;                /* [N,A] */
+    uint8_t *terminated;          /* [N] capture or timeout (entity.py:146) */
+    uint8_t *truncated;           /* [N] timeout only (base_env.py:397) */
+    int8_t *winner;               /* [N] -1 none, 0 cop, 1 thief (base_env.py:399-406) */
+} cat_outputs;
+
+/* DEVICE pointers for state get/set (env checkpointing, parity tests); any may be NULL. */
+typedef struct cat_state {
+    double *pos;                  /* [N,A,2] body.position */
+    double *vel;                  /* [N,A,2] body.velocity */
+    double *vbias;                /* [N,A,2] Chipmunk v_bias */
+    double *tc;                   /* [N,A,2] cached circle centre (stale after reset) */
+    double *leaf_bb;              /* [N,A,4] BBTree leaf bb */
+    int32_t *wall_shape;          /* [N,A,CAT_WALL_CACHE] */
+    int32_t *wall_age;            /* [N,A,CAT_WALL_CACHE] */
+    double *wall_jn;              /* [N,A,CAT_WALL_CACHE] */
+    int32_t *pair_age;            /* [N,A(A-1)/2] */
+    double *pair_jn;              /* [N,A(A-1)/2] */
+    int32_t *step_count;          /* [N] */
+    int32_t *reset_count;         /* [N] */
+} cat_state;
+
+typedef struct cat_sim cat_sim;
+
+/* Replaces BaseEnv.__init__ (base_env.py:51-121): pymunk.Space(), Map.populate_space
+   (src/maps/map.py:119-128, via compiled map blobs), _init_cops/_init_thieves (:168-214) and
+   Entity.__init__ (entity.py:41-124).  map_blobs are HOST pointers to blobs produced by
+   as_cops_and_thieves_amd.maps.CompiledMap.to_blob(); slot_map_ids[N] (HOST, NULL = all 0)
+   selects the map of each env slot.  device = HIP device ordinal. */
+int cat_create(const cat_config *cfg, const cat_tables *tables, const void *const *map_blobs,
+               const size_t *blob_sizes, int n_maps, const int32_t *slot_map_ids, int device,
+               cat_sim **out);
+int cat_destroy(cat_sim *sim);
+/* sim may be NULL: message of the last failed cat_create on this thread's library. */
+const char *cat_last_error(const cat_sim *sim);
+
+/* Replaces BaseEnv.reset (base_env.py:286-352) incl. _get_non_colliding_position (:123-166),
+   Entity.reset (entity.py:148-157) and Space.point_query_nearest (call site :154).  mask
+   (DEVICE, [N] u8, NULL = all) selects envs; positions (DEVICE, [N,A,2] f64, NULL = Philox
+   spawn sampling) injects spawn positions.  Writes the post-reset observations. */
+int cat_reset(cat_sim *sim, const uint8_t *mask, const double *positions, const cat_outputs *out,
+              void *stream);
+/* Same, with mask = "terminated flag set by the previous cat_step" (kept on device, no host
+   sync): the auto-reset of the batched env. */
+int cat_reset_done(cat_sim *sim, const cat_outputs *out, void *stream);
+
+/* Replaces BaseEnv.step (base_env.py:354-413): _termination_criterion (:521-554),
+   Entity.step/_perform_action/get_observation/_query_body (entity.py:126-241), Cop.reward /
+   Thief.reward (cop.py:49-75, thief.py:48-69), get_shared_observations
+   (src/environments/observation_spaces.py:67-131) and pymunk Space.step (call site :392).
+   actions: DEVICE [N,A] int32 in {0,1,2,3}. */
+int cat_step(cat_sim *sim, const int32_t *actions, const cat_outputs *out, void *stream);
+
+/* Env-state access (the reference cannot checkpoint env state). D2D copies. */
+int cat_get_state(cat_sim *sim, const cat_state *dst, void *stream);
+int cat_set_state(cat_sim *sim, const cat_state *src, void *stream);
+
+/* Synthetic uniform actions (driver.py:68 samples action_space(agent) per agent):
+   Philox(key = seed, counter = (env_global, tick, agent, 0xAC710)) & 3 -> DEVICE [N,A] int32. */
+int cat_random_actions(cat_sim *sim, uint64_t tick, int32_t *actions, void *stream);
+
+/* Introspection */
+int cat_abi_version(void);
+int cat_num_agents(const cat_sim *sim);
+int cat_num_shapes(const cat_sim *sim, int map_index);
+/* Timing hook for bench.py: seconds spent in the last n recorded step launches are measured by
+   the caller with HIP events on `stream`; this returns the stream the handle would use for
+   NULL (always the device's default stream). */
+
+/* Device arithmetic self-test used by tests: out[i] = op(in_a[i], in_b[i]) evaluated on the GPU
+   with the same primitives the kernels use (op 0 sqrt(a), 1 a/b, 2 f64->f16 bits of a,
+   3 obs-distance f16 bits of (a,b) relative to the origin (0,0)).  DEVICE pointers. */
+int cat_selftest_arith(int op, const double *in_a, const double *in_b, double *out, int n, int device,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,152 @@
+"""GPU parity: the HIP env core (through the C ABI) against the CPU oracle, bit for bit.
+
+Integer/byte outputs (ray classes, hit shape indices, f16 distance bits, flags, winner) and the
+f64 body state are compared for exact equality on identical seeded inputs: both sides evaluate
+the same formulas with contraction off, so even positions/velocities must agree to the last bit
+(north_star asks 1e-5; exact is the bar here).  Oracle parity against Pymunk itself is UNPINNED
+(see oracle/cat_oracle.h).
+"""
+import numpy as np
+import pytest
+
+from tests.util import (assert_outputs_equal, assert_state_equal, compiled, free_positions, to_np)
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(cfg, maps, slot=None):
+    import torch
+    from as_cops_and_thieves_amd.sim import CatSim
+    from oracle.cat_oracle import OracleSim
+    return CatSim(cfg, maps, slot, device="cuda:0", debug_hit_shape=True), OracleSim(cfg, maps, slot)
+
+
+def _run(cfg, maps, slot, ticks, rng, spread=None, check_every=1, auto_reset=False):
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    gpu, cpu = _pair(cfg, maps, slot)
+    pos = free_positions(cpu, maps[0] if slot is None else maps[int(slot[0])], rng, spread=spread) \
+        if slot is None else None
+    if pos is not None:
+        g = gpu.reset(positions=torch.from_numpy(pos)); c = cpu.reset(positions=pos)
+    else:
+        g = gpu.reset(); c = cpu.reset()
+    torch.cuda.synchronize()
+    assert_outputs_equal(to_np(g), c, keys=("obs_distance", "obs_type", "hit_shape", "shared_distance",
+                                            "shared_type", "team_positions"), ctx="reset")
+    assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx="reset")
+    n_contacts = n_captured = n_done = 0
+    for t in range(ticks):
+        a = cpu.random_actions(t)
+        ag = gpu.random_actions(t)
+        assert np.array_equal(ag.cpu().numpy(), a), "device Philox actions differ from the oracle's"
+        g = gpu.step(ag); c = cpu.step(a)
+        if t % check_every == 0 or t == ticks - 1:
+            torch.cuda.synchronize()
+            assert_outputs_equal(to_np(g), c, ctx=f"tick {t}")
+            st = cpu.get_state()
+            assert_state_equal(to_np(gpu.get_state()), st, ctx=f"tick {t}")
+            n_contacts += int((st["wall_shape"] >= 0).sum() + (st["pair_age"] >= 0).sum())
+        n_captured += int((c["winner"] == 0).sum())
+        n_done += int(c["terminated"].sum())
+        if auto_reset:
+            done = c["terminated"].copy()
+            gpu.reset_done()
+            cpu.reset(mask=done)
+            if done.any():
+                torch.cuda.synchronize()
+                assert_outputs_equal(to_np(gpu.out), cpu.out, keys=("obs_distance", "obs_type", "hit_shape",
+                                     "shared_distance", "shared_type", "team_positions"), ctx=f"auto-reset {t}")
+                assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"auto-reset {t}")
+    gpu.close()
+    return dict(contacts=n_contacts, captured=n_captured, done=n_done)
+
+
+@pytest.mark.parametrize("name,rays", [("squarinth", 90), ("lbirinth", 90), ("labyrinth", 64),
+                                         ("grandbyrinth", 64), ("agh-map", 90)])
+def test_step_parity_injected_positions(name, rays):
+    from as_cops_and_thieves_amd.config import SimConfig
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    m = compiled(name)
+    cfg = SimConfig(n_envs=32, n_rays=rays, max_step_count=60, seed=7)
+    stats = _run(cfg, [m], None, ticks=80, rng=rng, spread=40.0)
+    assert stats["done"] > 0          # timeouts reached (and rewards/winner paths exercised)
+
+
+def test_contacts_and_captures_are_exercised():
+    from as_cops_and_thieves_amd.config import SimConfig
+    rng = np.random.default_rng(3)
+    m = compiled("lbirinth")
+    cfg = SimConfig(n_envs=64, n_rays=90, max_step_count=400, seed=11)
+    stats = _run(cfg, [m], None, ticks=150, rng=rng, spread=25.0)
+    assert stats["contacts"] > 0 and stats["captured"] > 0
+
+
+def test_philox_spawn_reset_and_autoreset_parity():
+    from as_cops_and_thieves_amd.config import SimConfig
+    rng = np.random.default_rng(5)
+    m = compiled("squarinth")
+    cfg = SimConfig(n_envs=48, n_rays=64, max_step_count=25, seed=99)
+    stats = _run(cfg, [m], np.zeros(48, np.int32), ticks=70, rng=rng, auto_reset=True)
+    assert stats["done"] >= 48 * 2
+
+
+def test_three_vs_two_roster():
+    from as_cops_and_thieves_amd.config import SimConfig
+    rng = np.random.default_rng(6)
+    m = compiled("grandbyrinth", 3, 2)
+    cfg = SimConfig(n_envs=16, n_cops=3, n_thieves=2, n_rays=64, max_step_count=50, seed=5)
+    _run(cfg, [m], None, ticks=60, rng=rng, spread=30.0)
+
+
+def test_mixed_map_batch_ragged():
+    """BASELINE config 5 shape: all five maps interleaved across env slots (slot mod 5), with a
+    slot count that does not divide the workgroup's env count."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    rng = np.random.default_rng(8)
+    maps = [compiled(n) for n in ("agh-map", "grandbyrinth", "labyrinth", "lbirinth", "squarinth")]
+    N = 37
+    slot = (np.arange(N) % 5).astype(np.int32)
+    cfg = SimConfig(n_envs=N, n_rays=64, max_step_count=30, seed=21)
+    stats = _run(cfg, maps, slot, ticks=45, rng=rng, auto_reset=True)
+    assert stats["done"] >= N
+
+
+def test_gate_off_parity():
+    from as_cops_and_thieves_amd.config import SimConfig
+    rng = np.random.default_rng(9)
+    m = compiled("labyrinth")
+    cfg = SimConfig(n_envs=8, n_rays=90, max_step_count=100, seed=2, bbtree_gate=0)
+    _run(cfg, [m], None, ticks=30, rng=rng, spread=40.0)
+
+
+def test_device_arithmetic_is_ieee_exact():
+    """sqrt / divide / f16 conversions on the device equal the CPU's correctly rounded results."""
+    import ctypes as C
+    import torch
+    from as_cops_and_thieves_amd import _native as nat
+    from oracle import cat_oracle
+    L, O = nat.lib(), cat_oracle.lib()
+    rng = np.random.default_rng(0)
+    n = 200000
+    a = np.abs(rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n))
+    b = rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    out = torch.empty_like(ta)
+    for op, want in ((0, np.sqrt(a)), (1, a / b)):
+        assert L.cat_selftest_arith(op, ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, 0, None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want.view(np.uint64)), f"op {op}"
+    x = rng.uniform(-70000, 70000, n)
+    tx = torch.from_numpy(x).cuda()
+    assert L.cat_selftest_arith(2, tx.data_ptr(), tb.data_ptr(), out.data_ptr(), n, 0, None) == 0
+    torch.cuda.synchronize()
+    with np.errstate(over="ignore"):
+        assert np.array_equal(out.cpu().numpy().astype(np.uint16), x.astype(np.float16).view(np.uint16))
+    px, py = rng.uniform(-400, 400, n), rng.uniform(-400, 400, n)
+    tpx, tpy = torch.from_numpy(px).cuda(), torch.from_numpy(py).cuda()
+    assert L.cat_selftest_arith(3, tpx.data_ptr(), tpy.data_ptr(), out.data_ptr(), n, 0, None) == 0
+    torch.cuda.synchronize()
+    want = np.array([O.cato_obs_distance_f16(float(u), float(v), 0.0, 0.0) for u, v in zip(px[:20000], py[:20000])])
+    assert np.array_equal(out.cpu().numpy()[:20000].astype(np.uint16), want.astype(np.uint16))
