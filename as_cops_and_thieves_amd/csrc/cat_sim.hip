@@ -62,8 +62,10 @@ struct Params {
     const unsigned char *mask;
     const double *positions;
     int use_done_mask;
+    int item_cap, maxE, ang_ok;
+    float ang0, inv_step;
     // LDS carve (bytes)
-    int lds_map_bytes, lds_wave_bytes;
+    int lds_map_bytes, lds_wave_bytes, lds_union_bytes;
 };
 
 // ------------------------------------------------------------------ small helpers -----------
@@ -160,7 +162,13 @@ struct Lds {
     int *wsh, *wag, *pag;
     double *conf;   // [maxc][12]
     int *coni;      // [maxc][4]
-    int *cand;      // [S]
+    const double *rayd;  // [R][2]  ray offsets (workgroup-shared)
+    double *inv;    // [R][2]  1/(b-a) per ray of the current agent
+    double *ralpha; // [R]     best alpha so far
+    int *rbest, *rfeat;  // [R]
+    int *cid, *ck0, *ccnt, *coff;  // [S+A] candidates of the current agent
+    int *ipack, *ifeat;  // [item_cap] work items (overlay the contact arrays: disjoint phases)
+    double *itbb, *ialpha;
     unsigned short *od;  // [A*R]
     unsigned char *ot;   // [A*R]
     double *spawn;  // [A][2]
@@ -284,74 +292,111 @@ __device__ __forceinline__ double poly_point_distance(const Lds &L, int sh, doub
 }
 
 // ------------------------------------------------------------------ ray fan -------------------
-// Per agent: candidate walls = those whose bb the agent's reach box touches (exact superset of
-// every shape a ray of this agent can visit), bit 16 set when the ray origin lies within the ray
-// radius of the wall surface ([CP cpShapeSegmentQuery] alpha = 0 rule).  Lanes stride shapes.
-__device__ __forceinline__ int build_candidates(const Lds &L, const Params &p, int S, int lane,
-                                                double ax, double ay, double reach, double r2)
+// The A*R segment queries of one env are evaluated as dense (ray, shape) work items:
+//   1. per agent, lanes stride the shapes (walls, then the other agents' circles) and keep those
+//      the agent can reach, with the contiguous range of ray indices whose direction falls inside
+//      the cone the shape's bb subtends (a superset of the rays whose thin segment enters the bb);
+//   2. items (candidate c, ray k) are written shape-major into an LDS list, in batches of at most
+//      item_cap; every lane evaluates one item: the BBTree gate value t_bb and the shape's own
+//      segment query (alpha + which face/vertex was hit);
+//   3. lanes = rays walk the batch's candidates in index order and apply
+//      [CP cpSpaceSegmentQueryFirst]'s sequential rule "visit iff t_bb < best alpha so far, accept
+//      iff alpha < best" -- identical to visiting the shapes one after the other;
+//   4. the hit point is recomputed from (alpha, feature) by the winning ray only.
+constexpr int kFeatNone = -2, kFeatNear = -1;
+
+// [CP cpPolyShapeSegmentQuery] returning (alpha, feature): plane i -> i, vertex i -> count + i
+__device__ __forceinline__ void poly_query_feat(const Lds &L, int sh, double r, double ax, double ay,
+                                                double bx, double by, double r2, double &alpha, int &feat)
 {
-    int n = 0;
-    for (int base = 0; base < S; base += kLanes) {
-        int s = base + lane;
-        bool in = false;
-        int near = 0;
-        if (s < S) {
-            const double *bb = L.bb + 4 * s;
-            in = (bb[0] <= ax + reach) && (ax - reach <= bb[2]) && (bb[1] <= ay + reach) && (ay - reach <= bb[3]);
-            if (in) {
-                double m = r2 + 1e-6;
-                bool close = (bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m);
-                if (close) near = poly_point_distance(L, s, p.wall_r, ax, ay) <= r2;
+    const int first = L.first[sh], count = L.count[sh];
+    const double rsum = r + r2;
+    for (int i = 0; i < count; i++) {
+        const double *pl = L.planes + 8 * (first + i);
+        const double2 n = *reinterpret_cast<const double2 *>(pl);
+        const double2 e0 = *reinterpret_cast<const double2 *>(pl + 4);  // vn, dtMin
+        double an = ax * n.x + ay * n.y;
+        double d = an - e0.x - rsum;
+        if (d < 0.0) continue;
+        double bn = bx * n.x + by * n.y;
+        double den = fmax2(an - bn, DBL_MIN);
+        if (d > den) continue;  // <=> fl(d/den) > 1: exact pre-reject before the division
+        double t = d / den;
+        if (t < 0.0 || 1.0 < t) continue;
+        double ptx = ax * (1.0 - t) + bx * t, pty = ay * (1.0 - t) + by * t;
+        double dtv = n.x * pty - n.y * ptx;
+        if (e0.y <= dtv && dtv <= pl[6]) { alpha = t; feat = i; }
+    }
+    if (rsum > 0.0) {
+        const double rr = rsum * rsum;
+        for (int i = 0; i < count; i++) {  // [CP CircleSegmentQuery] on each bevelled vertex
+            const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + i) + 2);
+            double dax = ax - v.x, day = ay - v.y, dbx = bx - v.x, dby = by - v.y;
+            double dada = dax * dax + day * day, dadb = dax * dbx + day * dby, dbdb = dbx * dbx + dby * dby;
+            double qa = dada - 2.0 * dadb + dbdb;
+            double qb = dadb - dada;
+            double det = qb * qb - qa * (dada - rr);
+            if (det >= 0.0) {
+                double t = (-qb - sqrt(det)) / qa;
+                if (0.0 <= t && t <= 1.0 && t < alpha) { alpha = t; feat = count + i; }
             }
         }
-        unsigned long long mask = __ballot(in);
-        int pos = n + __popcll(mask & ((1ull << lane) - 1ull));
-        if (in) L.cand[pos] = s | (near << 16);
-        n += __popcll(mask);
     }
-    wave_sync();
-    return n;
 }
 
-// [CP cpSpaceSegmentQueryFirst] over a linear index: candidate walls in index order, then the
-// other agents' cached circles (entity.py:118-123 group filter rejects only the agent's own).
-__device__ __forceinline__ int segment_query_first(const Lds &L, const Params &p, int A, int S, int ncand,
-                                                   int self, double ax, double ay, double bx, double by,
-                                                   double r2, SegInfo &out)
+__device__ __forceinline__ void circle_query_feat(double cx, double cy, double rsum, double ax, double ay,
+                                                  double bx, double by, double &alpha, int &feat)
 {
-    int best = -1;
-    out.hit = 0; out.alpha = 1.0; out.px = bx; out.py = by;
-    const double dx = bx - ax, dy = by - ay;
-    const double idx = 1.0 / dx, idy = 1.0 / dy;
-    double t_exit = 1.0;
-    for (int c = 0; c < ncand; c++) {
-        const int e = L.cand[c];
-        const int sh = e & 0xFFFF;
-        if (p.gate) {
-            double tbb = bb_segment_query(L.bb + 4 * sh, ax, ay, dx, dy, idx, idy);
-            if (!(tbb < t_exit)) continue;
-        }
-        SegInfo info = {0, 1.0, bx, by};
-        if (e >> 16) { info.hit = 1; info.alpha = 0.0; }
-        else poly_segment_query(L, sh, p.wall_r, ax, ay, bx, by, r2, info);
-        if (info.hit && info.alpha < out.alpha) { out = info; best = sh; }
-        t_exit = fmin2(t_exit, out.alpha);
+    double dax = ax - cx, day = ay - cy, dbx = bx - cx, dby = by - cy;
+    double dada = dax * dax + day * day, dadb = dax * dbx + day * dby, dbdb = dbx * dbx + dby * dby;
+    double qa = dada - 2.0 * dadb + dbdb;
+    double qb = dadb - dada;
+    double det = qb * qb - qa * (dada - rsum * rsum);
+    if (det >= 0.0) {
+        double t = (-qb - sqrt(det)) / qa;
+        if (0.0 <= t && t <= 1.0) { alpha = t; feat = 0; }
     }
-    for (int j = 0; j < A; j++) {
-        if (j == self) continue;
-        const double tcx = L.tc[2 * j], tcy = L.tc[2 * j + 1];
-        if (p.gate) {
-            double tbb = bb_segment_query(L.leaf + 4 * j, ax, ay, dx, dy, idx, idy);
-            if (!(tbb < t_exit)) continue;
-        }
-        SegInfo info = {0, 1.0, bx, by};
-        double ex = ax - tcx, ey = ay - tcy;
-        if (sqrt(ex * ex + ey * ey) - p.rc <= r2) { info.hit = 1; info.alpha = 0.0; }  // [CP cpCircleShapePointQuery]
-        else circle_segment_query(tcx, tcy, p.rc, ax, ay, bx, by, r2, info);
-        if (info.hit && info.alpha < out.alpha) { out = info; best = S + j; }
-        t_exit = fmin2(t_exit, out.alpha);
+}
+
+// hit point of [CP CircleSegmentQuery]: lerp(a,b,t) - normalize(lerp(da,db,t)) * r2
+__device__ __forceinline__ void circle_hit_point(double cx, double cy, double ax, double ay, double bx, double by,
+                                                 double t, double r2, double &px, double &py)
+{
+    double dax = ax - cx, day = ay - cy, dbx = bx - cx, dby = by - cy;
+    double lx = dax * (1.0 - t) + dbx * t, ly = day * (1.0 - t) + dby * t;
+    double inv = 1.0 / (sqrt(lx * lx + ly * ly) + DBL_MIN);
+    double nx = lx * inv, ny = ly * inv;
+    px = (ax * (1.0 - t) + bx * t) - nx * r2;
+    py = (ay * (1.0 - t) + by * t) - ny * r2;
+}
+
+// contiguous ray-index range [k0, k0+cnt) (mod R) whose directions can enter the box; any
+// superset is correct, the exact decision is the slab test of the item.
+__device__ __forceinline__ void ray_cone(const Params &p, double ax, double ay, double l, double b, double r,
+                                         double t, int R, int &k0, int &cnt)
+{
+    if (!p.ang_ok || (ax >= l && ax <= r && ay >= b && ay <= t)) { k0 = 0; cnt = R; return; }
+    const float x0 = (float)(l - ax), x1 = (float)(r - ax), y0 = (float)(b - ay), y1 = (float)(t - ay);
+    const float thc = atan2f(0.5f * (y0 + y1), 0.5f * (x0 + x1));
+    const float kPi = 3.14159265358979f;
+    float lo = 0.0f, hi = 0.0f;
+    const float xs[4] = {x0, x1, x1, x0}, ys[4] = {y0, y0, y1, y1};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float d = atan2f(ys[q], xs[q]) - thc;
+        if (d > kPi) d -= 2.0f * kPi;
+        if (d < -kPi) d += 2.0f * kPi;
+        lo = fminf(lo, d); hi = fmaxf(hi, d);
     }
-    return best;
+    const float eps = 2e-4f;
+    const float a0 = (thc + lo - eps - p.ang0) * p.inv_step, a1 = (thc + hi + eps - p.ang0) * p.inv_step;
+    const int ka = (int)ceilf(a0), kb = (int)floorf(a1);
+    int c = kb - ka + 1;
+    if (c <= 0) { k0 = 0; cnt = 0; return; }
+    if (c >= R) { k0 = 0; cnt = R; return; }
+    int m = ka % R;
+    k0 = m < 0 ? m + R : m;
+    cnt = c;
 }
 
 // Entity.get_observation for every agent of the env + rewards + team-shared channels.
@@ -360,36 +405,162 @@ __device__ void observe_env(const Lds &L, const Params &p, int env, int lane, in
                             int captured, int timeout)
 {
     const int A = p.A, R = p.R;
+    const double r2 = p.ray_radius;
     const unsigned d_empty = f64_to_f16(p.ray_length);  // np.full(R, ray_length, float16) entity.py:200
-    const double reach = p.ray_length + p.ray_radius + 1e-6;
+    const double reach = p.ray_length + r2 + 1e-6;
+    const double cone_m = p.gate ? 1e-6 : r2 + 1e-6;
+    const int E = S + A;
     for (int i = 0; i < A; i++) {
         const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];  // fresh body.position (entity.py:186)
-        const int ncand = build_candidates(L, p, S, lane, ax, ay, reach, p.ray_radius);
+        // ---- ray setup
+        for (int k = lane; k < R; k += kLanes) {
+            const double bx = ax + L.rayd[2 * k], by = ay + L.rayd[2 * k + 1];  // entity.py:191-193
+            L.inv[2 * k] = 1.0 / (bx - ax);
+            L.inv[2 * k + 1] = 1.0 / (by - ay);
+            L.ralpha[k] = 1.0; L.rbest[k] = -1; L.rfeat[k] = kFeatNone;
+        }
+        // ---- candidates: walls in index order, then the other agents (entity.py:118-123: the ray
+        //      filter shares the agent's group, so only its own circle is rejected)
+        int ncand = 0;
+        for (int base = 0; base < E; base += kLanes) {
+            const int e = base + lane;
+            bool in = false;
+            int near = 0, k0 = 0, cnt = 0;
+            if (e < S) {
+                const double *bb = L.bb + 4 * e;
+                const double l = bb[0], b = bb[1], r = bb[2], t = bb[3];
+                in = (l <= ax + reach) && (ax - reach <= r) && (b <= ay + reach) && (ay - reach <= t);
+                if (in) {
+                    const double m = r2 + 1e-6;
+                    if ((l - m <= ax) && (ax <= r + m) && (b - m <= ay) && (ay <= t + m))
+                        near = poly_point_distance(L, e, p.wall_r, ax, ay) <= r2;  // [CP cpShapeSegmentQuery] alpha = 0 rule
+                    ray_cone(p, ax, ay, l - cone_m, b - cone_m, r + cone_m, t + cone_m, R, k0, cnt);
+                    in = cnt > 0;
+                }
+            } else if (e < E && e - S != i) {
+                const int j = e - S;
+                const double tcx = L.tc[2 * j], tcy = L.tc[2 * j + 1];
+                double l, b, r, t;
+                if (p.gate) { l = L.leaf[4 * j]; b = L.leaf[4 * j + 1]; r = L.leaf[4 * j + 2]; t = L.leaf[4 * j + 3]; }
+                else { l = tcx - p.rc; b = tcy - p.rc; r = tcx + p.rc; t = tcy + p.rc; }
+                in = (l <= ax + reach) && (ax - reach <= r) && (b <= ay + reach) && (ay - reach <= t);
+                if (in) {
+                    const double ex = ax - tcx, ey = ay - tcy;
+                    near = sqrt(ex * ex + ey * ey) - p.rc <= r2;  // [CP cpCircleShapePointQuery]
+                    ray_cone(p, ax, ay, l - cone_m, b - cone_m, r + cone_m, t + cone_m, R, k0, cnt);
+                    in = cnt > 0;
+                }
+            }
+            const unsigned long long mask = __ballot(in);
+            if (in) {
+                const int pos = ncand + __popcll(mask & ((1ull << lane) - 1ull));
+                L.cid[pos] = e | (near << 16); L.ck0[pos] = k0; L.ccnt[pos] = cnt;
+            }
+            ncand += __popcll(mask);
+        }
+        wave_sync();
+        // ---- batches of work items
+        int c0 = 0;
+        while (c0 < ncand) {
+            int n = 0, c1 = c0;
+            while (c1 < ncand) {
+                const int cnt = L.ccnt[c1];
+                if (n + cnt > p.item_cap) break;
+                n += cnt; c1++;
+            }
+            {   // item list, shape-major
+                int off = 0;
+                for (int c = c0; c < c1; c++) {
+                    const int cnt = L.ccnt[c], k0 = L.ck0[c];
+                    if (lane == 0) L.coff[c] = off;
+                    for (int l = lane; l < cnt; l += kLanes) {
+                        int k = k0 + l; if (k >= R) k -= R;
+                        L.ipack[off + l] = c | (k << 16);
+                    }
+                    off += cnt;
+                }
+            }
+            wave_sync();
+            for (int base = 0; base < n; base += kLanes) {
+                const int it = base + lane;
+                if (it < n) {
+                    const int pk = L.ipack[it];
+                    const int c = pk & 0xFFFF, k = pk >> 16;
+                    const int e = L.cid[c];
+                    const int id = e & 0xFFFF;
+                    const double bx = ax + L.rayd[2 * k], by = ay + L.rayd[2 * k + 1];
+                    double tbb = 0.0, alpha = 1.0;
+                    int feat = kFeatNone;
+                    if (p.gate) {
+                        const double *bbp = (id < S) ? (L.bb + 4 * id) : (L.leaf + 4 * (id - S));
+                        tbb = bb_segment_query(bbp, ax, ay, bx - ax, by - ay, L.inv[2 * k], L.inv[2 * k + 1]);
+                    }
+                    if (tbb < 1.0) {
+                        if (e >> 16) { alpha = 0.0; feat = kFeatNear; }
+                        else if (id < S) poly_query_feat(L, id, p.wall_r, ax, ay, bx, by, r2, alpha, feat);
+                        else circle_query_feat(L.tc[2 * (id - S)], L.tc[2 * (id - S) + 1], p.rc + r2, ax, ay, bx, by, alpha, feat);
+                    }
+                    L.itbb[it] = tbb; L.ialpha[it] = alpha; L.ifeat[it] = feat;
+                }
+            }
+            wave_sync();
+            for (int k = lane; k < R; k += kLanes) {  // [CP cpSpaceSegmentQueryFirst] sequential rule
+                double best_a = L.ralpha[k];
+                int best = L.rbest[k], bfeat = L.rfeat[k];
+                for (int c = c0; c < c1; c++) {
+                    int rel = k - L.ck0[c]; if (rel < 0) rel += R;
+                    if (rel < L.ccnt[c]) {
+                        const int it = L.coff[c] + rel;
+                        if (L.itbb[it] < best_a) {         // t_exit == best alpha so far (starts at 1)
+                            const double al = L.ialpha[it];
+                            const int f = L.ifeat[it];
+                            if (f != kFeatNone && al < best_a) { best_a = al; best = L.cid[c] & 0xFFFF; bfeat = f; }
+                        }
+                    }
+                }
+                L.ralpha[k] = best_a; L.rbest[k] = best; L.rfeat[k] = bfeat;
+            }
+            wave_sync();
+            c0 = c1;
+        }
+        // ---- finalize: hit point -> f16 distance and class (entity.py:200-215, :222-241)
         const bool is_cop = i < p.n_cops;
         const unsigned want = is_cop ? CAT_THIEF : CAT_COP;
         unsigned dmin = 0x10000u;
-        for (int k0 = 0; k0 < R; k0 += kLanes) {
-            const int k = k0 + lane;
-            const bool active = k < R;
-            const int kk = active ? k : 0;
-            const double bx = ax + p.ray_dx[kk], by = ay + p.ray_dy[kk];  // entity.py:191-193
-            SegInfo o;
-            int sh = segment_query_first(L, p, A, S, ncand, i, ax, ay, bx, by, p.ray_radius, o);
+        for (int k = lane; k < R; k += kLanes) {
+            const int sh = L.rbest[k];
             unsigned d16 = d_empty, ty = CAT_EMPTY;
             if (sh >= 0) {
-                d16 = obs_distance_f16(o.px, o.py, ax, ay);
-                ty = (sh < S) ? CAT_WALL : ((sh - S) >= p.n_cops ? CAT_THIEF : CAT_COP);  // entity.py:222-241
+                const double t = L.ralpha[k];
+                const int f = L.rfeat[k];
+                const double bx = ax + L.rayd[2 * k], by = ay + L.rayd[2 * k + 1];
+                double px = bx, py = by;  // alpha = 0 hits keep the segment end as their point
+                if (f != kFeatNear) {
+                    if (sh < S) {
+                        const int first = L.first[sh], count = L.count[sh];
+                        if (f < count) {
+                            const double2 n = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f));
+                            px = (ax * (1.0 - t) + bx * t) - n.x * r2;
+                            py = (ay * (1.0 - t) + by * t) - n.y * r2;
+                        } else {
+                            const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f - count) + 2);
+                            circle_hit_point(v.x, v.y, ax, ay, bx, by, t, r2, px, py);
+                        }
+                    } else {
+                        circle_hit_point(L.tc[2 * (sh - S)], L.tc[2 * (sh - S) + 1], ax, ay, bx, by, t, r2, px, py);
+                    }
+                }
+                d16 = obs_distance_f16(px, py, ax, ay);
+                ty = (sh < S) ? CAT_WALL : ((sh - S) >= p.n_cops ? CAT_THIEF : CAT_COP);
             }
-            if (active) {
-                const int q = i * R + k;
-                L.od[q] = (unsigned short)d16;
-                L.ot[q] = (unsigned char)ty;
-                const size_t g = (size_t)env * A * R + q;
-                if (p.out.obs_distance) p.out.obs_distance[g] = (unsigned short)d16;
-                if (p.out.obs_type) p.out.obs_type[g] = (unsigned char)ty;
-                if (p.out.hit_shape) p.out.hit_shape[g] = sh;
-                if (ty == want && d16 < dmin) dmin = d16;  // non-negative f16: bit order = value order
-            }
+            const int q = i * R + k;
+            L.od[q] = (unsigned short)d16;
+            L.ot[q] = (unsigned char)ty;
+            const size_t g = (size_t)env * A * R + q;
+            if (p.out.obs_distance) p.out.obs_distance[g] = (unsigned short)d16;
+            if (p.out.obs_type) p.out.obs_type[g] = (unsigned char)ty;
+            if (p.out.hit_shape) p.out.hit_shape[g] = sh;
+            if (ty == want && d16 < dmin) dmin = d16;  // non-negative f16: bit order = value order
         }
         if (rew_mode) {  // cop.py:49-75 / thief.py:48-69
 #pragma unroll
@@ -404,7 +575,7 @@ __device__ void observe_env(const Lds &L, const Params &p, int env, int lane, in
             else r = is_cop ? (float)(-0.02 - 0.02) : (float)0.15;
             if (lane == 0 && p.out.reward) p.out.reward[(size_t)env * A + i] = r;
         }
-        wave_sync();  // cand[] is rebuilt for the next agent
+        wave_sync();
     }
     // get_shared_observations (observation_spaces.py:98-129): first team member, roster order,
     // with a non-EMPTY ray supplies (type, distance); else EMPTY with the last member's distance
@@ -701,18 +872,28 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.planes = L.bb + 4 * S;
     L.first = reinterpret_cast<const int *>(L.planes + 8 * P);
     L.count = L.first + S;
+    L.rayd = reinterpret_cast<const double *>(smem + p.lds_map_bytes - 16 * p.R);
     char *w = smem + p.lds_map_bytes + wave * p.lds_wave_bytes;
-    const int A = p.A;
+    const int A = p.A, R = p.R, NPs = p.NP > 0 ? p.NP : 1;
     double *d = reinterpret_cast<double *>(w);
     L.pos = d; d += 2 * A; L.vel = d; d += 2 * A; L.vb = d; d += 2 * A; L.tc = d; d += 2 * A;
     L.leaf = d; d += 4 * A; L.spawn = d; d += 2 * A;
-    L.wjn = d; d += A * kK; L.pjn = d; d += (p.NP > 0 ? p.NP : 1);
-    L.conf = d; d += 12 * p.maxc;
-    int *iv = reinterpret_cast<int *>(d);
-    L.wsh = iv; iv += A * kK; L.wag = iv; iv += A * kK; L.pag = iv; iv += (p.NP > 0 ? p.NP : 1);
-    L.coni = iv; iv += 4 * p.maxc; L.cand = iv; iv += CAT_MAX_SHAPES;
+    L.wjn = d; d += A * kK; L.pjn = d; d += NPs;
+    L.inv = d; d += 2 * R; L.ralpha = d; d += R;
+    // union: contact arrays (physics) / work items (ray fan)
+    char *u = reinterpret_cast<char *>(d);
+    L.conf = reinterpret_cast<double *>(u);
+    L.coni = reinterpret_cast<int *>(L.conf + 12 * p.maxc);
+    L.itbb = reinterpret_cast<double *>(u);
+    L.ialpha = L.itbb + p.item_cap;
+    L.ipack = reinterpret_cast<int *>(L.ialpha + p.item_cap);
+    L.ifeat = L.ipack + p.item_cap;
+    int *iv = reinterpret_cast<int *>(u + p.lds_union_bytes);
+    L.wsh = iv; iv += A * kK; L.wag = iv; iv += A * kK; L.pag = iv; iv += NPs;
+    L.rbest = iv; iv += R; L.rfeat = iv; iv += R;
+    L.cid = iv; iv += p.maxE; L.ck0 = iv; iv += p.maxE; L.ccnt = iv; iv += p.maxE; L.coff = iv; iv += p.maxE;
     L.od = reinterpret_cast<unsigned short *>(iv);
-    L.ot = reinterpret_cast<unsigned char *>(L.od + align_up(A * p.R, 4));
+    L.ot = reinterpret_cast<unsigned char *>(L.od + align_up(A * R, 4));
     return L;
 }
 
@@ -725,6 +906,8 @@ __device__ __forceinline__ void stage_map(const Params &p, char *smem, const Map
     int *di = reinterpret_cast<int *>(dst + nf);
     const int *si = p.geo_i32 + md.i32_off;
     for (int i = threadIdx.x; i < 2 * md.S; i += blockDim.x) di[i] = si[i];
+    double *rd = reinterpret_cast<double *>(smem + p.lds_map_bytes - 16 * p.R);
+    for (int i = threadIdx.x; i < p.R; i += blockDim.x) { rd[2 * i] = p.ray_dx[i]; rd[2 * i + 1] = p.ray_dy[i]; }
     __syncthreads();
 }
 
@@ -759,7 +942,7 @@ __device__ __forceinline__ void store_state(const Lds &L, const Params &p, int e
 }
 
 // BaseEnv.step (base_env.py:354-413), one wave per env
-__global__ __launch_bounds__(kWaves *kLanes) void tick_kernel(const Params p)
+__global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params p)
 {
     extern __shared__ __align__(16) char smem[];
     const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
@@ -1075,12 +1258,32 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     TRY_ALLOC(dev_alloc(s, &p.reset_count, (size_t)N, nullptr));
     TRY_ALLOC(dev_alloc(s, &p.done, (size_t)N, nullptr));
 #undef TRY_ALLOC
+    // ---- ray-direction cone parameters: valid when the table is a uniform full circle
+    {
+        const double two_pi = 6.283185307179586;
+        const double a0 = atan2(tab->ray_dy[0], tab->ray_dx[0]);
+        const double step = two_pi / p.R;
+        bool ok = p.R >= 4;
+        for (int k = 0; k < p.R && ok; k++) {
+            double d = atan2(tab->ray_dy[k], tab->ray_dx[k]) - (a0 + k * step);
+            d -= two_pi * floor(d / two_pi + 0.5);
+            if (fabs(d) > 1e-6) ok = false;
+        }
+        p.ang_ok = ok ? 1 : 0;  // otherwise every shape is paired with every ray (still exact)
+        p.ang0 = (float)a0;
+        p.inv_step = (float)(1.0 / step);
+    }
     // ---- LDS carve sizes (must match carve())
     auto up = [](int x, int a) { return (x + a - 1) / a * a; };
-    p.lds_map_bytes = up((4 * maxS + 8 * maxP) * 8 + 2 * maxS * 4, 16);
+    p.item_cap = up(p.R, kLanes) > 128 ? up(p.R, kLanes) : 128;
+    p.maxE = maxS + A;
+    p.lds_map_bytes = up((4 * maxS + 8 * maxP) * 8 + 2 * maxS * 4, 16) + 16 * p.R;
     const int NPs = p.NP > 0 ? p.NP : 1;
-    int wb = (2 * A * 4 + 4 * A + 2 * A + A * kK + NPs + 12 * p.maxc) * 8;
-    wb += (A * kK * 2 + NPs + 4 * p.maxc + CAT_MAX_SHAPES) * 4;
+    const int phys_bytes = 12 * p.maxc * 8 + 4 * p.maxc * 4;
+    const int item_bytes = p.item_cap * 24;
+    p.lds_union_bytes = up(phys_bytes > item_bytes ? phys_bytes : item_bytes, 8);
+    int wb = (2 * A * 4 + 4 * A + 2 * A + A * kK + NPs + 3 * p.R) * 8 + p.lds_union_bytes;
+    wb += (A * kK * 2 + NPs + 2 * p.R + 4 * p.maxE) * 4;
     wb += up(A * p.R, 4) * 2 + up(A * p.R, 16);
     p.lds_wave_bytes = up(wb, 16);
     s->lds_bytes = (size_t)p.lds_map_bytes + (size_t)kWaves * p.lds_wave_bytes;

@@ -37,7 +37,12 @@ def cpu_baseline(cfg, cmap, budget_s: float = 12.0):
     n = 256
     c = replace(cfg, n_envs=n)
     res = {}
-    for label, threads in (("1core", 1), ("allcores", os.cpu_count() or 1)):
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 16))  # the GPU box's CPU share for one GPU is 16
+    for label, threads in (("1core", 1), ("allcores", ncores)):
         cat_oracle.lib().cato_set_threads(threads)
         sim = cat_oracle.OracleSim(c, [cmap])
         sim.reset()
