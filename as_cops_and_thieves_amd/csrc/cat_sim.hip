@@ -33,6 +33,7 @@ namespace {
 constexpr int kWaves = 4;           // envs per workgroup
 constexpr int kLanes = 64;          // gfx950 wavefront
 constexpr int kK = CAT_WALL_CACHE;
+constexpr int kMaxJ = 16;          // per-ray candidate list length per pass
 constexpr unsigned kBlobMagic = 0x31544143u;
 
 struct MapDesc {
@@ -57,15 +58,48 @@ struct Params {
     double *pos, *vel, *vbias, *tc, *leaf, *wjn, *pjn;
     int *wsh, *wag, *pag, *step_count, *reset_count;
     unsigned char *done;
+    int maxE, ang_ok;
+    float ang0, inv_step;
+    // LDS carve (bytes)
+    int lds_map_bytes, lds_wave_bytes, lds_union_bytes;
+};
+
+// Diagnostic build only (-DCAT_PHASE_TIMING): per-phase shader-clock totals, summed over waves
+// into a debug buffer no other kernel code reads.  The shipped library is built without it.
+#ifdef CAT_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[32];
+struct PhaseClock {   // accumulators live in LDS (one row per wave) to keep register pressure unchanged
+    unsigned long long prev;
+    unsigned long long *acc;
+    __device__ PhaseClock()
+    {
+        __shared__ unsigned long long rows[4][24];
+        acc = rows[threadIdx.x / 64];
+        if (threadIdx.x % 64 < 24) acc[threadIdx.x % 64] = 0;
+        prev = __builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void mark(int id)
+    {
+        unsigned long long t = __builtin_readcyclecounter();
+        if (threadIdx.x % 64 == 0) acc[id] += t - prev;
+        prev = t;
+    }
+    __device__ void flush(int lane) { if (lane < 24 && acc[lane]) atomicAdd(&g_phase_cycles[lane], acc[lane]); }
+};
+#define PHASE(pc, id) (pc).mark(id)
+#else
+struct PhaseClock { __device__ __forceinline__ void flush(int) {} };
+#define PHASE(pc, id) do {} while (0)
+#endif
+
+// Per-launch arguments travel by value (kernarg); the static Params live in device memory and are
+// read with scalar loads where needed, which keeps them out of long-lived SGPRs.
+struct LaunchArgs {
     cat_outputs out;
     const int *actions;
     const unsigned char *mask;
     const double *positions;
     int use_done_mask;
-    int item_cap, maxE, ang_ok;
-    float ang0, inv_step;
-    // LDS carve (bytes)
-    int lds_map_bytes, lds_wave_bytes, lds_union_bytes;
 };
 
 // ------------------------------------------------------------------ small helpers -----------
@@ -81,37 +115,33 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // round-to-nearest-even f64 -> f16 bits: NumPy's cast for np.array(points, dtype=np.float16)
-// (entity.py:206) and for the weak python-float origin (entity.py:208)
+// (entity.py:206) and for the weak python-float origin (entity.py:208).  f64 -> f32 with
+// round-to-odd (truncate, then OR the sticky bit into the lsb) followed by the hardware's RNE
+// f32 -> f16 is a correctly rounded single step: 24 bits >= 11 + 2.  Checked bit for bit against
+// NumPy by tests/test_gpu_parity.py::test_device_arithmetic_is_ieee_exact.
+__device__ __forceinline__ unsigned f32_to_f16(float f)
+{
+    _Float16 h = (_Float16)f;  // v_cvt_f16_f32: RNE, f16 denormals enabled
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+
 __device__ __forceinline__ unsigned f64_to_f16(double x)
 {
-    unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    unsigned sign = (unsigned)((b >> 48) & 0x8000ull);
-    unsigned long long a = b & 0x7FFFFFFFFFFFFFFFull;
-    if (a >= 0x7FF0000000000000ull) return sign | (a > 0x7FF0000000000000ull ? 0x7E00u : 0x7C00u);
-    if (a == 0) return sign;
-    int e = (int)(a >> 52) - 1023;
-    if (e > 15) return sign | 0x7C00u;
-    unsigned long long M = (a & 0xFFFFFFFFFFFFFull) | (1ull << 52);
-    int shift = 42;
-    if (e < -14) shift += (-14 - e);
-    if (shift > 54) return sign;
-    unsigned long long q = M >> shift;
-    unsigned long long rem = M & ((1ull << shift) - 1);
-    unsigned long long half = 1ull << (shift - 1);
-    if (rem > half || (rem == half && (q & 1))) q++;
-    unsigned bits = (e >= -14) ? (unsigned)(((unsigned)(e + 14) << 10) + q) : (unsigned)q;
-    if (bits >= 0x7C00u) bits = 0x7C00u;
-    return sign | bits;
+    float r = (float)x;  // v_cvt_f32_f64, RNE
+    const double back = (double)r;
+    if (back != x && !(x != x)) {
+        int bits = __float_as_int(r);
+        // |r| > |x|: step one ulp toward zero to get the truncated value (same sign, r != 0 here)
+        if (fabs(back) > fabs(x)) bits -= 1;
+        bits |= 1;  // inexact -> odd
+        r = __int_as_float(bits);
+    }
+    return f32_to_f16(r);
 }
 
 __device__ __forceinline__ float f16_to_f32(unsigned h)
 {
-    unsigned s = (h >> 15) & 1u, e = (h >> 10) & 31u, m = h & 1023u;
-    float v;
-    if (e == 0) v = (float)m * 5.9604644775390625e-08f;           // m * 2^-24, exact
-    else if (e == 31) v = m ? __int_as_float(0x7FC00000) : __int_as_float(0x7F800000);
-    else v = __int_as_float((int)(((e + 112u) << 23) | (m << 13)));
-    return s ? -v : v;
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)h);  // v_cvt_f32_f16, exact
 }
 
 // entity.py:206-210: f16(point) - f16(origin) in f32 -> f16; np.hypot on f16 = hypotf -> f16
@@ -119,9 +149,9 @@ __device__ __forceinline__ unsigned obs_distance_f16(double px, double py, doubl
 {
     float dx32 = f16_to_f32(f64_to_f16(px)) - f16_to_f32(f64_to_f16(ox));
     float dy32 = f16_to_f32(f64_to_f16(py)) - f16_to_f32(f64_to_f16(oy));
-    float dx = f16_to_f32(f64_to_f16((double)dx32)), dy = f16_to_f32(f64_to_f16((double)dy32));
+    float dx = f16_to_f32(f32_to_f16(dx32)), dy = f16_to_f32(f32_to_f16(dy32));
     float hyp = (float)sqrt((double)dx * (double)dx + (double)dy * (double)dy);
-    return f64_to_f16((double)hyp);
+    return f32_to_f16(hyp);
 }
 
 __device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
@@ -163,12 +193,8 @@ struct Lds {
     double *conf;   // [maxc][12]
     int *coni;      // [maxc][4]
     const double *rayd;  // [R][2]  ray offsets (workgroup-shared)
-    double *inv;    // [R][2]  1/(b-a) per ray of the current agent
-    double *ralpha; // [R]     best alpha so far
-    int *rbest, *rfeat;  // [R]
-    int *cid, *ck0, *ccnt, *coff;  // [S+A] candidates of the current agent
-    int *ipack, *ifeat;  // [item_cap] work items (overlay the contact arrays: disjoint phases)
-    double *itbb, *ialpha;
+    int *cid, *ck0, *ccnt;  // [S+A] candidates of the current agent
+    unsigned short *slot;   // [kMaxJ][64] per-ray candidate lists (overlay the contact arrays)
     unsigned short *od;  // [A*R]
     unsigned char *ot;   // [A*R]
     double *spawn;  // [A][2]
@@ -292,82 +318,23 @@ __device__ __forceinline__ double poly_point_distance(const Lds &L, int sh, doub
 }
 
 // ------------------------------------------------------------------ ray fan -------------------
-// The A*R segment queries of one env are evaluated as dense (ray, shape) work items:
-//   1. per agent, lanes stride the shapes (walls, then the other agents' circles) and keep those
-//      the agent can reach, with the contiguous range of ray indices whose direction falls inside
-//      the cone the shape's bb subtends (a superset of the rays whose thin segment enters the bb);
-//   2. items (candidate c, ray k) are written shape-major into an LDS list, in batches of at most
-//      item_cap; every lane evaluates one item: the BBTree gate value t_bb and the shape's own
-//      segment query (alpha + which face/vertex was hit);
-//   3. lanes = rays walk the batch's candidates in index order and apply
-//      [CP cpSpaceSegmentQueryFirst]'s sequential rule "visit iff t_bb < best alpha so far, accept
-//      iff alpha < best" -- identical to visiting the shapes one after the other;
-//   4. the hit point is recomputed from (alpha, feature) by the winning ray only.
-constexpr int kFeatNone = -2, kFeatNear = -1;
-
-// [CP cpPolyShapeSegmentQuery] returning (alpha, feature): plane i -> i, vertex i -> count + i
-__device__ __forceinline__ void poly_query_feat(const Lds &L, int sh, double r, double ax, double ay,
-                                                double bx, double by, double r2, double &alpha, int &feat)
+// Per agent, lanes stride the shapes (walls, then the other agents' circles) once and keep those
+// the agent can reach, each with the contiguous range of ray indices whose direction falls inside
+// the cone its bb subtends (a superset of the rays whose thin segment can enter the bb).  Then
+// lanes = rays: every ray collects ITS OWN short list of candidates (index order) and walks it
+// with [CP cpSpaceSegmentQueryFirst]'s sequential rule "visit iff t_bb < best alpha so far, accept
+// iff alpha < best" -- the same result as visiting every shape one after the other.
+// atan2 good to ~2e-4 rad (only used for a conservative cone, never for results)
+__device__ __forceinline__ float fast_atan2(float y, float x)
 {
-    const int first = L.first[sh], count = L.count[sh];
-    const double rsum = r + r2;
-    for (int i = 0; i < count; i++) {
-        const double *pl = L.planes + 8 * (first + i);
-        const double2 n = *reinterpret_cast<const double2 *>(pl);
-        const double2 e0 = *reinterpret_cast<const double2 *>(pl + 4);  // vn, dtMin
-        double an = ax * n.x + ay * n.y;
-        double d = an - e0.x - rsum;
-        if (d < 0.0) continue;
-        double bn = bx * n.x + by * n.y;
-        double den = fmax2(an - bn, DBL_MIN);
-        if (d > den) continue;  // <=> fl(d/den) > 1: exact pre-reject before the division
-        double t = d / den;
-        if (t < 0.0 || 1.0 < t) continue;
-        double ptx = ax * (1.0 - t) + bx * t, pty = ay * (1.0 - t) + by * t;
-        double dtv = n.x * pty - n.y * ptx;
-        if (e0.y <= dtv && dtv <= pl[6]) { alpha = t; feat = i; }
-    }
-    if (rsum > 0.0) {
-        const double rr = rsum * rsum;
-        for (int i = 0; i < count; i++) {  // [CP CircleSegmentQuery] on each bevelled vertex
-            const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + i) + 2);
-            double dax = ax - v.x, day = ay - v.y, dbx = bx - v.x, dby = by - v.y;
-            double dada = dax * dax + day * day, dadb = dax * dbx + day * dby, dbdb = dbx * dbx + dby * dby;
-            double qa = dada - 2.0 * dadb + dbdb;
-            double qb = dadb - dada;
-            double det = qb * qb - qa * (dada - rr);
-            if (det >= 0.0) {
-                double t = (-qb - sqrt(det)) / qa;
-                if (0.0 <= t && t <= 1.0 && t < alpha) { alpha = t; feat = count + i; }
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void circle_query_feat(double cx, double cy, double rsum, double ax, double ay,
-                                                  double bx, double by, double &alpha, int &feat)
-{
-    double dax = ax - cx, day = ay - cy, dbx = bx - cx, dby = by - cy;
-    double dada = dax * dax + day * day, dadb = dax * dbx + day * dby, dbdb = dbx * dbx + dby * dby;
-    double qa = dada - 2.0 * dadb + dbdb;
-    double qb = dadb - dada;
-    double det = qb * qb - qa * (dada - rsum * rsum);
-    if (det >= 0.0) {
-        double t = (-qb - sqrt(det)) / qa;
-        if (0.0 <= t && t <= 1.0) { alpha = t; feat = 0; }
-    }
-}
-
-// hit point of [CP CircleSegmentQuery]: lerp(a,b,t) - normalize(lerp(da,db,t)) * r2
-__device__ __forceinline__ void circle_hit_point(double cx, double cy, double ax, double ay, double bx, double by,
-                                                 double t, double r2, double &px, double &py)
-{
-    double dax = ax - cx, day = ay - cy, dbx = bx - cx, dby = by - cy;
-    double lx = dax * (1.0 - t) + dbx * t, ly = day * (1.0 - t) + dby * t;
-    double inv = 1.0 / (sqrt(lx * lx + ly * ly) + DBL_MIN);
-    double nx = lx * inv, ny = ly * inv;
-    px = (ax * (1.0 - t) + bx * t) - nx * r2;
-    py = (ay * (1.0 - t) + by * t) - ny * r2;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-30f));
+    const float s = a * a;
+    float r = ((-0.0464964749f * s + 0.15931422f) * s - 0.327622764f) * s * a + a;
+    if (ay > ax) r = 1.57079637f - r;
+    if (x < 0.0f) r = 3.14159274f - r;
+    return y < 0.0f ? -r : r;
 }
 
 // contiguous ray-index range [k0, k0+cnt) (mod R) whose directions can enter the box; any
@@ -377,18 +344,18 @@ __device__ __forceinline__ void ray_cone(const Params &p, double ax, double ay, 
 {
     if (!p.ang_ok || (ax >= l && ax <= r && ay >= b && ay <= t)) { k0 = 0; cnt = R; return; }
     const float x0 = (float)(l - ax), x1 = (float)(r - ax), y0 = (float)(b - ay), y1 = (float)(t - ay);
-    const float thc = atan2f(0.5f * (y0 + y1), 0.5f * (x0 + x1));
+    const float thc = fast_atan2(0.5f * (y0 + y1), 0.5f * (x0 + x1));
     const float kPi = 3.14159265358979f;
     float lo = 0.0f, hi = 0.0f;
     const float xs[4] = {x0, x1, x1, x0}, ys[4] = {y0, y0, y1, y1};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        float d = atan2f(ys[q], xs[q]) - thc;
+        float d = fast_atan2(ys[q], xs[q]) - thc;
         if (d > kPi) d -= 2.0f * kPi;
         if (d < -kPi) d += 2.0f * kPi;
         lo = fminf(lo, d); hi = fmaxf(hi, d);
     }
-    const float eps = 2e-4f;
+    const float eps = 1.5e-3f;
     const float a0 = (thc + lo - eps - p.ang0) * p.inv_step, a1 = (thc + hi + eps - p.ang0) * p.inv_step;
     const int ka = (int)ceilf(a0), kb = (int)floorf(a1);
     int c = kb - ka + 1;
@@ -401,8 +368,8 @@ __device__ __forceinline__ void ray_cone(const Params &p, double ax, double ay, 
 
 // Entity.get_observation for every agent of the env + rewards + team-shared channels.
 // rew_mode: 0 = no rewards (reset), 1 = step (captured/timeout known).
-__device__ void observe_env(const Lds &L, const Params &p, int env, int lane, int S, int rew_mode,
-                            int captured, int timeout)
+__device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la, int env, int lane, int S,
+                            int rew_mode, int captured, int timeout, PhaseClock &pc)
 {
     const int A = p.A, R = p.R;
     const double r2 = p.ray_radius;
@@ -412,13 +379,6 @@ __device__ void observe_env(const Lds &L, const Params &p, int env, int lane, in
     const int E = S + A;
     for (int i = 0; i < A; i++) {
         const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];  // fresh body.position (entity.py:186)
-        // ---- ray setup
-        for (int k = lane; k < R; k += kLanes) {
-            const double bx = ax + L.rayd[2 * k], by = ay + L.rayd[2 * k + 1];  // entity.py:191-193
-            L.inv[2 * k] = 1.0 / (bx - ax);
-            L.inv[2 * k + 1] = 1.0 / (by - ay);
-            L.ralpha[k] = 1.0; L.rbest[k] = -1; L.rfeat[k] = kFeatNone;
-        }
         // ---- candidates: walls in index order, then the other agents (entity.py:118-123: the ray
         //      filter shares the agent's group, so only its own circle is rejected)
         int ncand = 0;
@@ -459,108 +419,71 @@ __device__ void observe_env(const Lds &L, const Params &p, int env, int lane, in
             ncand += __popcll(mask);
         }
         wave_sync();
-        // ---- batches of work items
-        int c0 = 0;
-        while (c0 < ncand) {
-            int n = 0, c1 = c0;
-            while (c1 < ncand) {
-                const int cnt = L.ccnt[c1];
-                if (n + cnt > p.item_cap) break;
-                n += cnt; c1++;
-            }
-            {   // item list, shape-major
-                int off = 0;
-                for (int c = c0; c < c1; c++) {
-                    const int cnt = L.ccnt[c], k0 = L.ck0[c];
-                    if (lane == 0) L.coff[c] = off;
-                    for (int l = lane; l < cnt; l += kLanes) {
-                        int k = k0 + l; if (k >= R) k -= R;
-                        L.ipack[off + l] = c | (k << 16);
-                    }
-                    off += cnt;
-                }
-            }
-            wave_sync();
-            for (int base = 0; base < n; base += kLanes) {
-                const int it = base + lane;
-                if (it < n) {
-                    const int pk = L.ipack[it];
-                    const int c = pk & 0xFFFF, k = pk >> 16;
-                    const int e = L.cid[c];
-                    const int id = e & 0xFFFF;
-                    const double bx = ax + L.rayd[2 * k], by = ay + L.rayd[2 * k + 1];
-                    double tbb = 0.0, alpha = 1.0;
-                    int feat = kFeatNone;
-                    if (p.gate) {
-                        const double *bbp = (id < S) ? (L.bb + 4 * id) : (L.leaf + 4 * (id - S));
-                        tbb = bb_segment_query(bbp, ax, ay, bx - ax, by - ay, L.inv[2 * k], L.inv[2 * k + 1]);
-                    }
-                    if (tbb < 1.0) {
-                        if (e >> 16) { alpha = 0.0; feat = kFeatNear; }
-                        else if (id < S) poly_query_feat(L, id, p.wall_r, ax, ay, bx, by, r2, alpha, feat);
-                        else circle_query_feat(L.tc[2 * (id - S)], L.tc[2 * (id - S) + 1], p.rc + r2, ax, ay, bx, by, alpha, feat);
-                    }
-                    L.itbb[it] = tbb; L.ialpha[it] = alpha; L.ifeat[it] = feat;
-                }
-            }
-            wave_sync();
-            for (int k = lane; k < R; k += kLanes) {  // [CP cpSpaceSegmentQueryFirst] sequential rule
-                double best_a = L.ralpha[k];
-                int best = L.rbest[k], bfeat = L.rfeat[k];
-                for (int c = c0; c < c1; c++) {
-                    int rel = k - L.ck0[c]; if (rel < 0) rel += R;
-                    if (rel < L.ccnt[c]) {
-                        const int it = L.coff[c] + rel;
-                        if (L.itbb[it] < best_a) {         // t_exit == best alpha so far (starts at 1)
-                            const double al = L.ialpha[it];
-                            const int f = L.ifeat[it];
-                            if (f != kFeatNone && al < best_a) { best_a = al; best = L.cid[c] & 0xFFFF; bfeat = f; }
-                        }
-                    }
-                }
-                L.ralpha[k] = best_a; L.rbest[k] = best; L.rfeat[k] = bfeat;
-            }
-            wave_sync();
-            c0 = c1;
-        }
-        // ---- finalize: hit point -> f16 distance and class (entity.py:200-215, :222-241)
+        PHASE(pc, 4);
         const bool is_cop = i < p.n_cops;
         const unsigned want = is_cop ? CAT_THIEF : CAT_COP;
         unsigned dmin = 0x10000u;
-        for (int k = lane; k < R; k += kLanes) {
-            const int sh = L.rbest[k];
-            unsigned d16 = d_empty, ty = CAT_EMPTY;
-            if (sh >= 0) {
-                const double t = L.ralpha[k];
-                const int f = L.rfeat[k];
-                const double bx = ax + L.rayd[2 * k], by = ay + L.rayd[2 * k + 1];
-                double px = bx, py = by;  // alpha = 0 hits keep the segment end as their point
-                if (f != kFeatNear) {
-                    if (sh < S) {
-                        const int first = L.first[sh], count = L.count[sh];
-                        if (f < count) {
-                            const double2 n = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f));
-                            px = (ax * (1.0 - t) + bx * t) - n.x * r2;
-                            py = (ay * (1.0 - t) + by * t) - n.y * r2;
-                        } else {
-                            const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f - count) + 2);
-                            circle_hit_point(v.x, v.y, ax, ay, bx, by, t, r2, px, py);
+        for (int kb = 0; kb < R; kb += kLanes) {
+            const int k = kb + lane;
+            const bool active = k < R;
+            const int kk = active ? k : 0;
+            const double bx = ax + L.rayd[2 * kk], by = ay + L.rayd[2 * kk + 1];  // entity.py:191-193
+            const double dx = bx - ax, dy = by - ay;
+            const double idx = 1.0 / dx, idy = 1.0 / dy;
+            int best = -1;
+            double best_a = 1.0, bpx = bx, bpy = by;
+            unsigned short *myslot = L.slot + lane;  // slot[j][lane]
+            int cstart = 0;
+            while (cstart < ncand) {
+                // ---- this ray's candidates, in index order, until some lane's list is full
+                int nj = 0, c = cstart;
+                for (; c < ncand; c++) {
+                    const int cnt = L.ccnt[c], k0 = L.ck0[c];
+                    int rel = k - k0; if (rel < 0) rel += R;
+                    const bool inr = active && rel < cnt;
+                    if (__ballot(inr && nj == kMaxJ) != 0ull) break;
+                    if (inr) { myslot[nj * kLanes] = (unsigned short)c; nj++; }
+                }
+                PHASE(pc, 5);
+                // ---- walk the list: [CP cpSpaceSegmentQueryFirst] over this ray's candidates
+                for (int j = 0; __ballot(j < nj) != 0ull; j++) {
+                    if (j < nj) {
+                        const int e = L.cid[myslot[j * kLanes]];
+                        const int id = e & 0xFFFF;
+                        bool visit = true;
+                        if (p.gate) {
+                            const double *bbp = (id < S) ? (L.bb + 4 * id) : (L.leaf + 4 * (id - S));
+                            visit = bb_segment_query(bbp, ax, ay, dx, dy, idx, idy) < best_a;  // t_exit == best alpha
                         }
-                    } else {
-                        circle_hit_point(L.tc[2 * (sh - S)], L.tc[2 * (sh - S) + 1], ax, ay, bx, by, t, r2, px, py);
+                        if (visit) {
+                            SegInfo info = {0, 1.0, bx, by};
+                            if (e >> 16) { info.hit = 1; info.alpha = 0.0; }
+                            else if (id < S) poly_segment_query(L, id, p.wall_r, ax, ay, bx, by, r2, info);
+                            else circle_segment_query(L.tc[2 * (id - S)], L.tc[2 * (id - S) + 1], p.rc, ax, ay, bx, by, r2, info);
+                            if (info.hit && info.alpha < best_a) { best_a = info.alpha; best = id; bpx = info.px; bpy = info.py; }
+                        }
                     }
                 }
-                d16 = obs_distance_f16(px, py, ax, ay);
-                ty = (sh < S) ? CAT_WALL : ((sh - S) >= p.n_cops ? CAT_THIEF : CAT_COP);
+                PHASE(pc, 6);
+                cstart = c;
             }
-            const int q = i * R + k;
-            L.od[q] = (unsigned short)d16;
-            L.ot[q] = (unsigned char)ty;
-            const size_t g = (size_t)env * A * R + q;
-            if (p.out.obs_distance) p.out.obs_distance[g] = (unsigned short)d16;
-            if (p.out.obs_type) p.out.obs_type[g] = (unsigned char)ty;
-            if (p.out.hit_shape) p.out.hit_shape[g] = sh;
-            if (ty == want && d16 < dmin) dmin = d16;  // non-negative f16: bit order = value order
+            // ---- hit point -> f16 distance and class (entity.py:200-215, :222-241)
+            unsigned d16 = d_empty, ty = CAT_EMPTY;
+            if (best >= 0) {
+                d16 = obs_distance_f16(bpx, bpy, ax, ay);
+                ty = (best < S) ? CAT_WALL : ((best - S) >= p.n_cops ? CAT_THIEF : CAT_COP);
+            }
+            if (active) {
+                const int q = i * R + k;
+                L.od[q] = (unsigned short)d16;
+                L.ot[q] = (unsigned char)ty;
+                const size_t g = (size_t)env * A * R + q;
+                if (la.out.obs_distance) la.out.obs_distance[g] = (unsigned short)d16;
+                if (la.out.obs_type) la.out.obs_type[g] = (unsigned char)ty;
+                if (la.out.hit_shape) la.out.hit_shape[g] = best;
+                if (ty == want && d16 < dmin) dmin = d16;  // non-negative f16: bit order = value order
+            }
+            PHASE(pc, 7);
         }
         if (rew_mode) {  // cop.py:49-75 / thief.py:48-69
 #pragma unroll
@@ -573,9 +496,10 @@ __device__ void observe_env(const Lds &L, const Params &p, int env, int lane, in
             else if (timeout) r = is_cop ? -1.0f : 1.0f;
             else if (dmin < 0x10000u) r = (is_cop ? p.cop_lut : p.thief_lut)[dmin & 0x7FFFu];
             else r = is_cop ? (float)(-0.02 - 0.02) : (float)0.15;
-            if (lane == 0 && p.out.reward) p.out.reward[(size_t)env * A + i] = r;
+            if (lane == 0 && la.out.reward) la.out.reward[(size_t)env * A + i] = r;
         }
         wave_sync();
+        PHASE(pc, 8);
     }
     // get_shared_observations (observation_spaces.py:98-129): first team member, roster order,
     // with a non-EMPTY ray supplies (type, distance); else EMPTY with the last member's distance
@@ -586,12 +510,12 @@ __device__ void observe_env(const Lds &L, const Params &p, int env, int lane, in
             for (int i = lo; i < hi; i++)
                 if (ty == CAT_EMPTY) { ty = L.ot[i * R + k]; d = L.od[i * R + k]; }
             const size_t g = (size_t)env * 2 * R + team * R + k;
-            if (p.out.shared_type) p.out.shared_type[g] = (unsigned char)ty;
-            if (p.out.shared_distance) p.out.shared_distance[g] = (unsigned short)d;
+            if (la.out.shared_type) la.out.shared_type[g] = (unsigned char)ty;
+            if (la.out.shared_distance) la.out.shared_distance[g] = (unsigned short)d;
         }
     }
-    if (lane < 2 * A && p.out.team_positions)  // observation_spaces.py:92-95
-        p.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)f64_to_f16(L.pos[lane]);
+    if (lane < 2 * A && la.out.team_positions)  // observation_spaces.py:92-95
+        la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)f64_to_f16(L.pos[lane]);
 }
 
 // ------------------------------------------------------------------ termination ---------------
@@ -879,19 +803,14 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.pos = d; d += 2 * A; L.vel = d; d += 2 * A; L.vb = d; d += 2 * A; L.tc = d; d += 2 * A;
     L.leaf = d; d += 4 * A; L.spawn = d; d += 2 * A;
     L.wjn = d; d += A * kK; L.pjn = d; d += NPs;
-    L.inv = d; d += 2 * R; L.ralpha = d; d += R;
-    // union: contact arrays (physics) / work items (ray fan)
+    // union: contact arrays (physics) / per-ray candidate lists (ray fan)
     char *u = reinterpret_cast<char *>(d);
     L.conf = reinterpret_cast<double *>(u);
     L.coni = reinterpret_cast<int *>(L.conf + 12 * p.maxc);
-    L.itbb = reinterpret_cast<double *>(u);
-    L.ialpha = L.itbb + p.item_cap;
-    L.ipack = reinterpret_cast<int *>(L.ialpha + p.item_cap);
-    L.ifeat = L.ipack + p.item_cap;
+    L.slot = reinterpret_cast<unsigned short *>(u);
     int *iv = reinterpret_cast<int *>(u + p.lds_union_bytes);
     L.wsh = iv; iv += A * kK; L.wag = iv; iv += A * kK; L.pag = iv; iv += NPs;
-    L.rbest = iv; iv += R; L.rfeat = iv; iv += R;
-    L.cid = iv; iv += p.maxE; L.ck0 = iv; iv += p.maxE; L.ccnt = iv; iv += p.maxE; L.coff = iv; iv += p.maxE;
+    L.cid = iv; iv += p.maxE; L.ck0 = iv; iv += p.maxE; L.ccnt = iv; iv += p.maxE;
     L.od = reinterpret_cast<unsigned short *>(iv);
     L.ot = reinterpret_cast<unsigned char *>(L.od + align_up(A * R, 4));
     return L;
@@ -942,17 +861,21 @@ __device__ __forceinline__ void store_state(const Lds &L, const Params &p, int e
 }
 
 // BaseEnv.step (base_env.py:354-413), one wave per env
-__global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params p)
+__global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *__restrict__ pp, const LaunchArgs la)
 {
+    const Params &p = *pp;
     extern __shared__ __align__(16) char smem[];
     const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
+    PhaseClock pc;
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
     stage_map(p, smem, md);
+    PHASE(pc, 0);
     const int env = p.work_env[blockIdx.x * kWaves + wave];
     if (env < 0) return;
     const Lds L = carve(p, smem, md, wave);
     const int S = md.S, A = p.A;
     load_state(L, p, env, lane);
+    PHASE(pc, 1);
 
     const int step = p.step_count[env] + 1;                       // :372
     const int captured = termination_captured(L, p, S, lane);     // :378
@@ -961,7 +884,7 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params p)
     // Entity._perform_action (entity.py:126-134), every lane computes all agents identically
     const double m_inv = 1.0 / p.mass;
     for (int i = 0; i < A; i++) {
-        const int act = p.actions[(size_t)env * A + i];
+        const int act = la.actions[(size_t)env * A + i];
         double jx = 0.0, jy = 0.0;
         if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
         else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
@@ -971,30 +894,36 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params p)
         L.vel[2 * i] = vx; L.vel[2 * i + 1] = vy;
     }
 
-    observe_env(L, p, env, lane, S, 1, captured, timeout);        // entity.py:143-144, :388-390
+    PHASE(pc, 2);
+    observe_env(L, p, la, env, lane, S, 1, captured, timeout, pc);    // entity.py:143-144, :388-390
+    PHASE(pc, 9);
     physics_env(L, p, S, lane);                                   // :392
+    PHASE(pc, 10);
     store_state(L, p, env, lane, true);
     if (lane == 0) {
         p.step_count[env] = step;
         const unsigned char term = (unsigned char)(captured || timeout);
         p.done[env] = term;
-        if (p.out.terminated) p.out.terminated[env] = term;       // entity.py:146
-        if (p.out.truncated) p.out.truncated[env] = (unsigned char)timeout;  // :397
-        if (p.out.winner) p.out.winner[env] = (signed char)(captured ? 0 : (timeout ? 1 : -1));  // :399-406
+        if (la.out.terminated) la.out.terminated[env] = term;       // entity.py:146
+        if (la.out.truncated) la.out.truncated[env] = (unsigned char)timeout;  // :397
+        if (la.out.winner) la.out.winner[env] = (signed char)(captured ? 0 : (timeout ? 1 : -1));  // :399-406
     }
+    PHASE(pc, 11);
+    pc.flush(lane);
 }
 
 // BaseEnv.reset (base_env.py:286-352) for masked envs
-__global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params p)
+__global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__restrict__ pp, const LaunchArgs la)
 {
+    const Params &p = *pp;
     extern __shared__ __align__(16) char smem[];
     const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
     stage_map(p, smem, md);
     const int env = p.work_env[blockIdx.x * kWaves + wave];
     if (env < 0) return;
-    if (p.use_done_mask) { if (!p.done[env]) return; }
-    else if (p.mask && !p.mask[env]) return;
+    if (la.use_done_mask) { if (!p.done[env]) return; }
+    else if (la.mask && !la.mask[env]) return;
     const Lds L = carve(p, smem, md, wave);
     const int S = md.S, A = p.A;
     load_state(L, p, env, lane);
@@ -1005,8 +934,8 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params p)
 
     for (int i = 0; i < A; i++) {
         double sx, sy;
-        if (p.positions) {
-            sx = p.positions[((size_t)env * A + i) * 2]; sy = p.positions[((size_t)env * A + i) * 2 + 1];
+        if (la.positions) {
+            sx = la.positions[((size_t)env * A + i) * 2]; sy = la.positions[((size_t)env * A + i) * 2 + 1];
         } else {
             const int r0 = region_off[i], nr = region_off[i + 1] - r0;
             if (nr <= 0) { sx = start[2 * i]; sy = start[2 * i + 1]; }      // :323-332 Entity.reset()
@@ -1049,13 +978,15 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params p)
         L.pos[2 * i] = L.spawn[2 * i]; L.pos[2 * i + 1] = L.spawn[2 * i + 1];
         L.vel[2 * i] = 0.0; L.vel[2 * i + 1] = 0.0;
     }
-    observe_env(L, p, env, lane, S, 0, 0, 0);   // :334-344
+    PhaseClock pc;
+    observe_env(L, p, la, env, lane, S, 0, 0, 0, pc);   // :334-344
     store_state(L, p, env, lane, false);
     if (lane == 0) { p.step_count[env] = 0; p.reset_count[env] = (int)rc; p.done[env] = 0; }  // :350
 }
 
-__global__ void random_actions_kernel(const Params p, unsigned long long tick, int *actions)
+__global__ void random_actions_kernel(const Params *__restrict__ pp, unsigned long long tick, int *actions)
 {
+    const Params &p = *pp;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.N * p.A) return;
     const int env = idx / p.A, i = idx % p.A;
@@ -1083,6 +1014,7 @@ thread_local char g_create_err[256] = "";
 // ====================================================================== host side ============
 struct cat_sim {
     Params p;
+    Params *dev_p;
     int device;
     int n_blocks;
     size_t lds_bytes;
@@ -1275,15 +1207,14 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     }
     // ---- LDS carve sizes (must match carve())
     auto up = [](int x, int a) { return (x + a - 1) / a * a; };
-    p.item_cap = up(p.R, kLanes) > 128 ? up(p.R, kLanes) : 128;
     p.maxE = maxS + A;
     p.lds_map_bytes = up((4 * maxS + 8 * maxP) * 8 + 2 * maxS * 4, 16) + 16 * p.R;
     const int NPs = p.NP > 0 ? p.NP : 1;
     const int phys_bytes = 12 * p.maxc * 8 + 4 * p.maxc * 4;
-    const int item_bytes = p.item_cap * 24;
-    p.lds_union_bytes = up(phys_bytes > item_bytes ? phys_bytes : item_bytes, 8);
-    int wb = (2 * A * 4 + 4 * A + 2 * A + A * kK + NPs + 3 * p.R) * 8 + p.lds_union_bytes;
-    wb += (A * kK * 2 + NPs + 2 * p.R + 4 * p.maxE) * 4;
+    const int slot_bytes = kMaxJ * kLanes * 2;
+    p.lds_union_bytes = up(phys_bytes > slot_bytes ? phys_bytes : slot_bytes, 8);
+    int wb = (2 * A * 4 + 4 * A + 2 * A + A * kK + NPs) * 8 + p.lds_union_bytes;
+    wb += (A * kK * 2 + NPs + 3 * p.maxE) * 4;
     wb += up(A * p.R, 4) * 2 + up(A * p.R, 16);
     p.lds_wave_bytes = up(wb, 16);
     s->lds_bytes = (size_t)p.lds_map_bytes + (size_t)kWaves * p.lds_wave_bytes;
@@ -1298,6 +1229,12 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
             snprintf(s->err, sizeof s->err, "cannot raise dynamic LDS limit to %zu", s->lds_bytes);
             return fail(CAT_ERR_HIP);
         }
+    }
+    {
+        Params *dp = nullptr;
+        rc = dev_alloc(s, &dp, 1, &p);
+        if (rc != CAT_OK) return fail(rc);
+        s->dev_p = dp;
     }
     *out = s;
     return CAT_OK;
@@ -1317,11 +1254,12 @@ static int launch_reset(cat_sim *s, const uint8_t *mask, const double *positions
 {
     if (!s) return CAT_ERR_BAD_ARG;
     HIP_TRY(s, hipSetDevice(s->device));
-    Params p = s->p;
-    if (out) p.out = *out;
-    p.mask = mask; p.positions = positions; p.use_done_mask = use_done;
+    LaunchArgs la;
+    memset(&la, 0, sizeof la);
+    if (out) la.out = *out;
+    la.mask = mask; la.positions = positions; la.use_done_mask = use_done;
     hipLaunchKernelGGL(reset_kernel, dim3(s->n_blocks), dim3(kWaves * kLanes), s->lds_bytes,
-                       static_cast<hipStream_t>(stream), p);
+                       static_cast<hipStream_t>(stream), s->dev_p, la);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -1340,11 +1278,12 @@ extern "C" int cat_step(cat_sim *s, const int32_t *actions, const cat_outputs *o
 {
     if (!s || !actions) { if (s) snprintf(s->err, sizeof s->err, "cat_step: actions is NULL"); return CAT_ERR_BAD_ARG; }
     HIP_TRY(s, hipSetDevice(s->device));
-    Params p = s->p;
-    if (out) p.out = *out;
-    p.actions = actions;
+    LaunchArgs la;
+    memset(&la, 0, sizeof la);
+    if (out) la.out = *out;
+    la.actions = actions;
     hipLaunchKernelGGL(tick_kernel, dim3(s->n_blocks), dim3(kWaves * kLanes), s->lds_bytes,
-                       static_cast<hipStream_t>(stream), p);
+                       static_cast<hipStream_t>(stream), s->dev_p, la);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -1355,7 +1294,7 @@ extern "C" int cat_random_actions(cat_sim *s, uint64_t tick, int32_t *actions, v
     HIP_TRY(s, hipSetDevice(s->device));
     const int n = s->p.N * s->p.A;
     hipLaunchKernelGGL(random_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       s->p, (unsigned long long)tick, actions);
+                       s->dev_p, (unsigned long long)tick, actions);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -1382,6 +1321,17 @@ static int copy_state(cat_sim *s, const cat_state *v, bool get, void *stream)
 
 extern "C" int cat_get_state(cat_sim *s, const cat_state *dst, void *stream) { return copy_state(s, dst, true, stream); }
 extern "C" int cat_set_state(cat_sim *s, const cat_state *src, void *stream) { return copy_state(s, src, false, stream); }
+
+#ifdef CAT_PHASE_TIMING
+extern "C" int cat_debug_phase_cycles(unsigned long long *out24, int reset)
+{
+    unsigned long long h[32];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_cycles), sizeof h) != hipSuccess) return CAT_ERR_HIP;
+    for (int i = 0; i < 24; i++) out24[i] = h[i];
+    if (reset) { memset(h, 0, sizeof h); if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), h, sizeof h) != hipSuccess) return CAT_ERR_HIP; }
+    return CAT_OK;
+}
+#endif
 
 extern "C" int cat_selftest_arith(int op, const double *a, const double *b, double *out, int n, int device, void *stream)
 {

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase shader-cycle shares of tick_kernel (build with -DCAT_PHASE_TIMING into
+libcat_sim_timing.so; never the shipped library).  Usage: python tools/phase_timing.py [map] [envs] [rays]"""
+import ctypes as C, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import torch
+from as_cops_and_thieves_amd import _native as nat
+nat.LIB_PATH = nat.PKG / "libcat_sim_timing.so"
+from as_cops_and_thieves_amd.config import SimConfig
+from as_cops_and_thieves_amd.maps import load_preset
+from as_cops_and_thieves_amd.sim import CatSim
+name = sys.argv[1] if len(sys.argv) > 1 else "labyrinth"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+cmap = load_preset(name).compile()
+sim = CatSim(SimConfig(n_envs=N, n_rays=R, seed=0), [cmap])
+sim.reset()
+for t in range(100):
+    sim.step(sim.random_actions(t)); sim.reset_done()
+torch.cuda.synchronize()
+L = nat.lib()
+buf = (C.c_ulonglong * 24)()
+L.cat_debug_phase_cycles(buf, 1)
+T = 50
+for t in range(100, 100 + T):
+    sim.step(sim.random_actions(t)); sim.reset_done()
+torch.cuda.synchronize()
+L.cat_debug_phase_cycles(buf, 1)
+names = {0: "stage_map", 1: "load_state", 2: "termination+actions", 3: "ray setup", 4: "candidates (cone)",
+         5: "ray list build", 6: "list walk (gate+query)", 7: "f16 + obs store", 8: "reward", 9: "shared obs", 10: "physics",
+         11: "store"}
+tot = sum(buf)
+for i in range(24):
+    if buf[i]:
+        print(f"{names.get(i, i):22s} {buf[i] / T / N:10.0f} cycles/wave  {100.0 * buf[i] / tot:5.1f}%")
+print(f"{'total':22s} {tot / T / N:10.0f} cycles/wave")
