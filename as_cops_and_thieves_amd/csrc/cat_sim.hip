@@ -282,8 +282,15 @@ __device__ __forceinline__ void poly_segment_query(const Lds &L, int sh, double 
         }
     }
     if (rsum > 0.0) {
+        // Conservative f32 pre-test: a bevel circle whose centre lies farther than rsum + 0.01 from
+        // the ray's line cannot be hit (the exact f64 discriminant is then negative by a margin
+        // ~1e3 that dwarfs its ~1e-4 rounding error), so the exact test is skipped for it.
+        const float dxf = (float)(bx - ax), dyf = (float)(by - ay);
+        const float thr = ((float)rsum + 0.01f) * sqrtf(dxf * dxf + dyf * dyf) * 1.00001f + 0.25f;
         for (int i = 0; i < count; i++) {
             const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + i) + 2);
+            const float ex = (float)(v.x - ax), ey = (float)(v.y - ay);
+            if (fabsf(dxf * ey - dyf * ex) > thr) continue;
             SegInfo ci = {0, 1.0, bx, by};
             circle_segment_query(v.x, v.y, r, ax, ay, bx, by, r2, ci);
             if (ci.alpha < info.alpha) info = ci;
@@ -423,6 +430,8 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         const bool is_cop = i < p.n_cops;
         const unsigned want = is_cop ? CAT_THIEF : CAT_COP;
         unsigned dmin = 0x10000u;
+        // the first 64 candidates stay in registers (lane = candidate) and are broadcast by readlane
+        const int my_cnt = lane < ncand ? L.ccnt[lane] : 0, my_k0 = lane < ncand ? L.ck0[lane] : 0;
         for (int kb = 0; kb < R; kb += kLanes) {
             const int k = kb + lane;
             const bool active = k < R;
@@ -438,7 +447,9 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                 // ---- this ray's candidates, in index order, until some lane's list is full
                 int nj = 0, c = cstart;
                 for (; c < ncand; c++) {
-                    const int cnt = L.ccnt[c], k0 = L.ck0[c];
+                    int cnt, k0;
+                    if (c < kLanes) { cnt = __builtin_amdgcn_readlane(my_cnt, c); k0 = __builtin_amdgcn_readlane(my_k0, c); }
+                    else { cnt = L.ccnt[c]; k0 = L.ck0[c]; }
                     int rel = k - k0; if (rel < 0) rel += R;
                     const bool inr = active && rel < cnt;
                     if (__ballot(inr && nj == kMaxJ) != 0ull) break;
