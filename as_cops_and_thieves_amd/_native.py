@@ -89,11 +89,12 @@ def lib() -> C.CDLL:
     L.cat_get_state.argtypes = [vp, vp, vp]
     L.cat_set_state.argtypes = [vp, vp, vp]
     L.cat_random_actions.argtypes = [vp, u64, vp, vp]
+    L.cat_set_seed.argtypes = [vp, u64, vp]
     L.cat_num_agents.argtypes = [vp]
     L.cat_num_shapes.argtypes = [vp, i32]
     L.cat_selftest_arith.argtypes = [i32, vp, vp, vp, i32, i32, vp]
     for name in ("cat_create", "cat_destroy", "cat_reset", "cat_reset_done", "cat_step", "cat_get_state",
-                 "cat_set_state", "cat_random_actions", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith"):
+                 "cat_set_state", "cat_random_actions", "cat_set_seed", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -101,4 +102,4 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = ("cat_abi_version", "cat_last_error", "cat_create", "cat_destroy", "cat_reset",
                     "cat_reset_done", "cat_step", "cat_get_state", "cat_set_state", "cat_random_actions",
-                    "cat_num_agents", "cat_num_shapes", "cat_selftest_arith")
+                    "cat_set_seed", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith")

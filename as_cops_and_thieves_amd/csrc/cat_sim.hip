@@ -1310,6 +1310,17 @@ extern "C" int cat_random_actions(cat_sim *s, uint64_t tick, int32_t *actions, v
     return CAT_OK;
 }
 
+extern "C" int cat_set_seed(cat_sim *s, uint64_t seed, void *stream)
+{
+    if (!s) return CAT_ERR_BAD_ARG;
+    HIP_TRY(s, hipSetDevice(s->device));
+    s->p.seed = seed;
+    // the 8-byte source lives in the handle, which outlives the async copy
+    HIP_TRY(s, hipMemcpyAsync(&s->dev_p->seed, &s->p.seed, sizeof(s->p.seed), hipMemcpyHostToDevice,
+                              static_cast<hipStream_t>(stream)));
+    return CAT_OK;
+}
+
 static int copy_state(cat_sim *s, const cat_state *v, bool get, void *stream)
 {
     if (!s || !v) return CAT_ERR_BAD_ARG;

@@ -5,7 +5,7 @@ Host-side mirror of reference ``src/maps/map.py`` (``Map._parse_block`` :35-61,
 into ``pymunk.Poly(space.static_body, ring, radius=1)``; Chipmunk2D then replaces the ring by
 its convex hull (``cpConvexHull`` with tolerance 0) and derives one splitting plane per hull
 edge.  That construction is restated here ([CHIPMUNK-RECALL]) and the
-result is serialised into a flat blob shared by the device library and the test oracle.
+result is serialised into a flat blob (the input format of the device library).
 
 Differences from the reference that are build-side options (never silently applied):
 

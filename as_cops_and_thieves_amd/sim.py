@@ -130,6 +130,10 @@ class CatSim:
         self._check(self._L.cat_random_actions(self._h, int(tick), out.data_ptr(), self._stream()), "cat_random_actions")
         return out
 
+    def set_seed(self, seed: int) -> None:
+        self.cfg.seed = int(seed) & (2**64 - 1)
+        self._check(self._L.cat_set_seed(self._h, self.cfg.seed, self._stream()), "cat_set_seed")
+
     def get_state(self) -> Dict[str, torch.Tensor]:
         st = {k: torch.zeros(shape, dtype=dt, device=self.device) for k, (shape, dt) in _state_spec(self.N, self.A).items()}
         view = nat.CatState(*[st[k].data_ptr() if st[k].numel() else None for k in nat.STATE_FIELDS])

@@ -79,6 +79,7 @@ def main() -> None:
     import torch
     from as_cops_and_thieves_amd.config import SimConfig
     from as_cops_and_thieves_amd.maps import load_preset
+    from as_cops_and_thieves_amd.sharding import max_over_ranks
     from as_cops_and_thieves_amd.sim import CatSim
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,10 +127,7 @@ def main() -> None:
         sim.reset_done()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed, device=dev)   # the slowest rank bounds the whole-job rate
     tick_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     episodes = int(sim.get_state()["reset_count"].sum().item())
 

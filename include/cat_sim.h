@@ -145,6 +145,10 @@ int cat_set_state(cat_sim *sim, const cat_state *src, void *stream);
    Philox(key = seed, counter = (env_global, tick, agent, 0xAC710)) & 3 -> DEVICE [N,A] int32. */
 int cat_random_actions(cat_sim *sim, uint64_t tick, int32_t *actions, void *stream);
 
+/* gymnasium-style reseeding (BaseEnv.reset(seed=...), base_env.py:307-311): replaces the Philox key
+   used by later spawn sampling / synthetic actions. */
+int cat_set_seed(cat_sim *sim, uint64_t seed, void *stream);
+
 /* Introspection */
 int cat_abi_version(void);
 int cat_num_agents(const cat_sim *sim);

@@ -1,0 +1,81 @@
+"""The C-ABI library loads and exports every symbol include/cat_sim.h declares (no compute calls:
+no GPU here); the product package never touches the oracle; compute entry points refuse to run
+without a device."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "cat_sim.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cat_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from as_cops_and_thieves_amd import _native
+    _native.build()
+    L = _native.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 13
+    for sym in declared:
+        assert hasattr(L, sym), f"libcat_sim.so does not export {sym}"
+    assert set(declared) == set(_native.EXPORTED_SYMBOLS)
+    assert L.cat_abi_version() == 1
+
+
+def test_struct_layouts_match_header_field_order():
+    from as_cops_and_thieves_amd import _native
+    text = (ROOT / "include" / "cat_sim.h").read_text()
+    for struct, cls in (("cat_config", _native.CatConfig), ("cat_outputs", _native.CatOutputs),
+                        ("cat_state", _native.CatState), ("cat_tables", _native.CatTables)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = re.findall(r"\*?\s*([a-z_0-9]+);", body)
+        assert names == [f[0] for f in cls._fields_], struct
+    assert C.sizeof(_native.CatConfig) == 8 * 4 + 8 + 8 + 11 * 8
+
+
+def test_no_device_is_a_loud_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from as_cops_and_thieves_amd import _native
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.maps import load_preset
+    from as_cops_and_thieves_amd.sim import CatSim, CatSimError
+    with pytest.raises(CatSimError):
+        CatSim(SimConfig(), [load_preset("squarinth").compile()])
+    # and straight through the C ABI: cat_create reports CAT_ERR_NO_DEVICE
+    L = _native.lib()
+    cfg = _native.CatConfig()
+    cfg.n_envs, cfg.n_cops, cfg.n_thieves, cfg.n_rays = 1, 2, 1, 8
+    blob = load_preset("squarinth").compile().to_blob()
+    import numpy as np
+    dx = np.zeros(8); lut = np.zeros(32768, np.float32)
+    tabs = _native.CatTables(dx.ctypes.data, dx.ctypes.data, lut.ctypes.data, lut.ctypes.data)
+    arr = (C.c_char_p * 1)(blob); sizes = (C.c_size_t * 1)(len(blob)); h = C.c_void_p()
+    rc = L.cat_create(C.byref(cfg), C.byref(tabs), arr, sizes, 1, None, 0, C.byref(h))
+    assert rc == -4 and b"no CPU path" in L.cat_last_error(None)
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    from as_cops_and_thieves_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_native.NativeLibraryMissing):
+        _native.lib()
+
+
+def test_product_package_never_references_the_oracle():
+    pkg = ROOT / "as_cops_and_thieves_amd"
+    offenders = []
+    for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list((ROOT / "include").glob("*.h")):
+        txt = f.read_text()
+        if re.search(r"\boracle\b|cat_oracle|cato_", txt):
+            offenders.append(str(f.relative_to(ROOT)))
+    assert offenders == [], offenders
