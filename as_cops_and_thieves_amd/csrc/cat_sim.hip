@@ -254,48 +254,57 @@ __device__ __forceinline__ void circle_segment_query(double cx, double cy, doubl
     }
 }
 
-// [CP cpPolyShapeSegmentQuery]; plane record = n.x n.y v0.x v0.y dot(v0,n) dtMin dtMax pad
+// [CP cpPolyShapeSegmentQuery]; plane record = n.x n.y v0.x v0.y dot(v0,n) dtMin dtMax pad.
+// Chipmunk runs all face planes first (a passing plane overwrites the result unconditionally) and
+// then the bevel circles (strictly smaller alpha replaces).  The two passes only interact through
+// "min, earlier wins ties", so one loop over the records that tracks the plane result and the best
+// bevel result separately and merges them afterwards gives the identical answer.
 __device__ __forceinline__ void poly_segment_query(const Lds &L, int sh, double r, double ax, double ay,
                                                    double bx, double by, double r2, SegInfo &info)
 {
     const int first = L.first[sh], count = L.count[sh];
     const double rsum = r + r2;
-    for (int i = 0; i < count; i++) {
-        const double *pl = L.planes + 8 * (first + i);
+    // Conservative f32 pre-test for the bevels: a circle whose centre lies farther than rsum + 0.01 from
+    // the ray's line cannot be hit (the exact f64 discriminant is then negative by a margin ~1e3 that
+    // dwarfs its ~1e-4 rounding error), so the exact test is skipped for it.
+    const float dxf = (float)(bx - ax), dyf = (float)(by - ay);
+    const float thr = ((float)rsum + 0.01f) * sqrtf(dxf * dxf + dyf * dyf) * 1.00001f + 0.25f;
+    const bool bevels = rsum > 0.0;
+    SegInfo ci = {0, 1.0, bx, by};  // best bevel hit so far
+    const double *pl = L.planes + 8 * first;
+    for (int i = 0; i < count; i++, pl += 8) {
         const double2 n = *reinterpret_cast<const double2 *>(pl);
+        const double2 v = *reinterpret_cast<const double2 *>(pl + 2);
         const double2 e0 = *reinterpret_cast<const double2 *>(pl + 4);  // vn, dtMin
         double an = ax * n.x + ay * n.y;
         double d = an - e0.x - rsum;
-        if (d < 0.0) continue;
-        double bn = bx * n.x + by * n.y;
-        double den = fmax2(an - bn, DBL_MIN);
-        if (d > den) continue;  // <=> fl(d/den) > 1: exact pre-reject before the division
-        double t = d / den;
-        if (t < 0.0 || 1.0 < t) continue;
-        double ptx = ax * (1.0 - t) + bx * t, pty = ay * (1.0 - t) + by * t;
-        double dtv = n.x * pty - n.y * ptx;
-        if (e0.y <= dtv && dtv <= pl[6]) {
-            info.hit = 1;
-            info.alpha = t;
-            info.px = ptx - n.x * r2;
-            info.py = pty - n.y * r2;
+        if (!(d < 0.0)) {
+            double bn = bx * n.x + by * n.y;
+            double den = fmax2(an - bn, DBL_MIN);
+            if (!(d > den)) {  // d > den <=> fl(d/den) > 1: exact pre-reject before the division
+                double t = d / den;
+                if (!(t < 0.0 || 1.0 < t)) {
+                    double ptx = ax * (1.0 - t) + bx * t, pty = ay * (1.0 - t) + by * t;
+                    double dtv = n.x * pty - n.y * ptx;
+                    if (e0.y <= dtv && dtv <= pl[6]) {
+                        info.hit = 1;
+                        info.alpha = t;
+                        info.px = ptx - n.x * r2;
+                        info.py = pty - n.y * r2;
+                    }
+                }
+            }
         }
-    }
-    if (rsum > 0.0) {
-        // Conservative f32 pre-test: a bevel circle whose centre lies farther than rsum + 0.01 from
-        // the ray's line cannot be hit (the exact f64 discriminant is then negative by a margin
-        // ~1e3 that dwarfs its ~1e-4 rounding error), so the exact test is skipped for it.
-        const float dxf = (float)(bx - ax), dyf = (float)(by - ay);
-        const float thr = ((float)rsum + 0.01f) * sqrtf(dxf * dxf + dyf * dyf) * 1.00001f + 0.25f;
-        for (int i = 0; i < count; i++) {
-            const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + i) + 2);
+        if (bevels) {
             const float ex = (float)(v.x - ax), ey = (float)(v.y - ay);
-            if (fabsf(dxf * ey - dyf * ex) > thr) continue;
-            SegInfo ci = {0, 1.0, bx, by};
-            circle_segment_query(v.x, v.y, r, ax, ay, bx, by, r2, ci);
-            if (ci.alpha < info.alpha) info = ci;
+            if (!(fabsf(dxf * ey - dyf * ex) > thr)) {
+                SegInfo c2 = {0, 1.0, bx, by};
+                circle_segment_query(v.x, v.y, r, ax, ay, bx, by, r2, c2);
+                if (c2.alpha < ci.alpha) ci = c2;
+            }
         }
     }
+    if (ci.alpha < info.alpha) info = ci;
 }
 
 // [CP cpPolyShapePointQuery] -> signed distance to the rounded surface
@@ -345,25 +354,36 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
 }
 
 // contiguous ray-index range [k0, k0+cnt) (mod R) whose directions can enter the box; any
-// superset is correct, the exact decision is the slab test of the item.
+// superset is correct, the exact decision is the slab test of the visit.  Seen from a point
+// outside an axis-aligned box the cone is bounded by two silhouette corners that depend only on
+// which side(s) of the box the point lies: start corner (counter-clockwise first) and end corner.
 __device__ __forceinline__ void ray_cone(const Params &p, double ax, double ay, double l, double b, double r,
                                          double t, int R, int &k0, int &cnt)
 {
-    if (!p.ang_ok || (ax >= l && ax <= r && ay >= b && ay <= t)) { k0 = 0; cnt = R; return; }
+    const int sx = ax < l ? 0 : (ax > r ? 2 : 1), sy = ay < b ? 0 : (ay > t ? 2 : 1);
+    if (!p.ang_ok || (sx == 1 && sy == 1)) { k0 = 0; cnt = R; return; }
     const float x0 = (float)(l - ax), x1 = (float)(r - ax), y0 = (float)(b - ay), y1 = (float)(t - ay);
-    const float thc = fast_atan2(0.5f * (y0 + y1), 0.5f * (x0 + x1));
-    const float kPi = 3.14159265358979f;
-    float lo = 0.0f, hi = 0.0f;
-    const float xs[4] = {x0, x1, x1, x0}, ys[4] = {y0, y0, y1, y1};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        float d = fast_atan2(ys[q], xs[q]) - thc;
-        if (d > kPi) d -= 2.0f * kPi;
-        if (d < -kPi) d += 2.0f * kPi;
-        lo = fminf(lo, d); hi = fmaxf(hi, d);
+    // angles grow from +x toward +y.  start = silhouette corner with the smallest angle, end = the
+    // one with the largest (x0 < x1, y0 < y1 are the box sides relative to the point):
+    //   box above (sy 0):  left-of-box (sx 0): (x1,y0)->(x0,y1)   inside: (x1,y0)->(x0,y0)   right: (x1,y1)->(x0,y0)
+    //   box level (sy 1):  sx 0: (x0,y0)->(x0,y1)                                              sx 2: (x1,y1)->(x1,y0) (wraps)
+    //   box below (sy 2):  sx 0: (x0,y0)->(x1,y1)               inside: (x0,y1)->(x1,y1)     sx 2: (x0,y1)->(x1,y0)
+    float sxx, syy, exx, eyy;
+    if (sy == 0) {
+        sxx = x1; syy = (sx == 2) ? y1 : y0;
+        exx = x0; eyy = (sx == 0) ? y1 : y0;
+    } else if (sy == 2) {
+        sxx = x0; syy = (sx == 0) ? y0 : y1;
+        exx = x1; eyy = (sx == 2) ? y0 : y1;
+    } else if (sx == 0) {
+        sxx = x0; syy = y0; exx = x0; eyy = y1;
+    } else {
+        sxx = x1; syy = y1; exx = x1; eyy = y0;
     }
+    float th0 = fast_atan2(syy, sxx), th1 = fast_atan2(eyy, exx);
+    if (th1 < th0) th1 += 6.28318548f;
     const float eps = 1.5e-3f;
-    const float a0 = (thc + lo - eps - p.ang0) * p.inv_step, a1 = (thc + hi + eps - p.ang0) * p.inv_step;
+    const float a0 = (th0 - eps - p.ang0) * p.inv_step, a1 = (th1 + eps - p.ang0) * p.inv_step;
     const int ka = (int)ceilf(a0), kb = (int)floorf(a1);
     int c = kb - ka + 1;
     if (c <= 0) { k0 = 0; cnt = 0; return; }
@@ -384,6 +404,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
     const double reach = p.ray_length + r2 + 1e-6;
     const double cone_m = p.gate ? 1e-6 : r2 + 1e-6;
     const int E = S + A;
+    unsigned my_dmin = 0x10000u;  // lane i keeps agent i's minimum wanted-class distance
     for (int i = 0; i < A; i++) {
         const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];  // fresh body.position (entity.py:186)
         // ---- candidates: walls in index order, then the other agents (entity.py:118-123: the ray
@@ -445,15 +466,28 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
             int cstart = 0;
             while (cstart < ncand) {
                 // ---- this ray's candidates, in index order, until some lane's list is full
-                int nj = 0, c = cstart;
+                // (a full list simply stops taking entries; `cfull` remembers the first candidate that did
+                // not fit anywhere so the next pass resumes there -- index order is preserved)
+                int nj = 0, c = cstart, cfull = ncand;
                 for (; c < ncand; c++) {
                     int cnt, k0;
                     if (c < kLanes) { cnt = __builtin_amdgcn_readlane(my_cnt, c); k0 = __builtin_amdgcn_readlane(my_k0, c); }
                     else { cnt = L.ccnt[c]; k0 = L.ck0[c]; }
                     int rel = k - k0; if (rel < 0) rel += R;
-                    const bool inr = active && rel < cnt;
-                    if (__ballot(inr && nj == kMaxJ) != 0ull) break;
-                    if (inr) { myslot[nj * kLanes] = (unsigned short)c; nj++; }
+                    const bool inr = active && rel < cnt && c < cfull;
+                    if (inr) {
+                        if (nj < kMaxJ) { myslot[nj * kLanes] = (unsigned short)c; nj++; }
+                        else cfull = c;
+                    }
+                }
+                {   // earliest overflow over the wave: later candidates are dropped from EVERY list of this pass
+                    int m = cfull;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { int o2 = __shfl_xor(m, off); m = o2 < m ? o2 : m; }
+                    if (m < ncand) {
+                        while (nj > 0 && (int)myslot[(nj - 1) * kLanes] >= m) nj--;
+                        c = m;
+                    }
                 }
                 PHASE(pc, 5);
                 // ---- walk the list: [CP cpSpaceSegmentQueryFirst] over this ray's candidates
@@ -496,21 +530,25 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
             }
             PHASE(pc, 7);
         }
-        if (rew_mode) {  // cop.py:49-75 / thief.py:48-69
+        if (rew_mode) {  // min over the wave; the LUT lookups of all agents are issued together below
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 unsigned o2 = (unsigned)__shfl_xor((int)dmin, off);
                 dmin = o2 < dmin ? o2 : dmin;
             }
-            float r;
-            if (captured) r = is_cop ? 1.0f : -1.0f;
-            else if (timeout) r = is_cop ? -1.0f : 1.0f;
-            else if (dmin < 0x10000u) r = (is_cop ? p.cop_lut : p.thief_lut)[dmin & 0x7FFFu];
-            else r = is_cop ? (float)(-0.02 - 0.02) : (float)0.15;
-            if (lane == 0 && la.out.reward) la.out.reward[(size_t)env * A + i] = r;
+            if (lane == i) my_dmin = dmin;
         }
         wave_sync();
         PHASE(pc, 8);
+    }
+    if (rew_mode && lane < A && la.out.reward) {  // cop.py:49-75 / thief.py:48-69, lane = agent
+        const bool is_cop = lane < p.n_cops;
+        float r;
+        if (captured) r = is_cop ? 1.0f : -1.0f;
+        else if (timeout) r = is_cop ? -1.0f : 1.0f;
+        else if (my_dmin < 0x10000u) r = (is_cop ? p.cop_lut : p.thief_lut)[my_dmin & 0x7FFFu];
+        else r = is_cop ? (float)(-0.02 - 0.02) : (float)0.15;
+        la.out.reward[(size_t)env * A + lane] = r;
     }
     // get_shared_observations (observation_spaces.py:98-129): first team member, roster order,
     // with a non-EMPTY ray supplies (type, distance); else EMPTY with the last member's distance
