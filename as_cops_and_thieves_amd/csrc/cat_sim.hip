@@ -103,6 +103,9 @@ struct LaunchArgs {
 };
 
 // ------------------------------------------------------------------ small helpers -----------
+// value known to be the same in every lane -> SGPR (lets the compiler keep loop control scalar)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ double fmax2(double a, double b) { return (a > b) ? a : b; }  // [CP cpfmax]
 __device__ __forceinline__ double fmin2(double a, double b) { return (a < b) ? a : b; }  // [CP cpfmin]
 
@@ -185,7 +188,7 @@ __device__ __forceinline__ double u53(unsigned a, unsigned b)
 struct Lds {
     const double *bb;      // [S][4]            workgroup-shared
     const double *planes;  // [P][8]
-    const int *first, *count;
+    const int *fc;         // [S] first plane | plane count << 16
     // per-wave scratch
     double *pos, *vel, *vb, *tc, *leaf;  // [A][2] x4, [A][4]
     double *wjn, *pjn;
@@ -194,7 +197,7 @@ struct Lds {
     int *coni;      // [maxc][4]
     const double *rayd;  // [R][2]  ray offsets (workgroup-shared)
     int *cid, *ck0, *ccnt;  // [S+A] candidates of the current agent
-    unsigned short *slot;   // [kMaxJ][64] per-ray candidate lists (overlay the contact arrays)
+    unsigned short *slot;   // [2][kMaxJ][64] per-ray candidate lists: index, then shape id | near << 15
     unsigned short *od;  // [A*R]
     unsigned char *ot;   // [A*R]
     double *spawn;  // [A][2]
@@ -262,7 +265,7 @@ __device__ __forceinline__ void circle_segment_query(double cx, double cy, doubl
 __device__ __forceinline__ void poly_segment_query(const Lds &L, int sh, double r, double ax, double ay,
                                                    double bx, double by, double r2, SegInfo &info)
 {
-    const int first = L.first[sh], count = L.count[sh];
+    const int fc = L.fc[sh], first = fc & 0xFFFF, count = fc >> 16;
     const double rsum = r + r2;
     // Conservative f32 pre-test for the bevels: a circle whose centre lies farther than rsum + 0.01 from
     // the ray's line cannot be hit (the exact f64 discriminant is then negative by a margin ~1e3 that
@@ -310,7 +313,7 @@ __device__ __forceinline__ void poly_segment_query(const Lds &L, int sh, double 
 // [CP cpPolyShapePointQuery] -> signed distance to the rounded surface
 __device__ __forceinline__ double poly_point_distance(const Lds &L, int sh, double r, double px, double py)
 {
-    const int first = L.first[sh], count = L.count[sh];
+    const int fc = L.fc[sh], first = fc & 0xFFFF, count = fc >> 16;
     const double *last = L.planes + 8 * (first + count - 1);
     double v0x = last[2], v0y = last[3];
     double minDist = INFINITY;
@@ -446,6 +449,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
             }
             ncand += __popcll(mask);
         }
+        ncand = uni(ncand);
         wave_sync();
         PHASE(pc, 4);
         const bool is_cop = i < p.n_cops;
@@ -453,13 +457,13 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         unsigned dmin = 0x10000u;
         // the first 64 candidates stay in registers (lane = candidate) and are broadcast by readlane
         const int my_cnt = lane < ncand ? L.ccnt[lane] : 0, my_k0 = lane < ncand ? L.ck0[lane] : 0;
+        const int my_id = lane < ncand ? L.cid[lane] : 0;
         for (int kb = 0; kb < R; kb += kLanes) {
             const int k = kb + lane;
             const bool active = k < R;
             const int kk = active ? k : 0;
             const double bx = ax + L.rayd[2 * kk], by = ay + L.rayd[2 * kk + 1];  // entity.py:191-193
-            const double dx = bx - ax, dy = by - ay;
-            const double idx = 1.0 / dx, idy = 1.0 / dy;
+            const double idx = 1.0 / (bx - ax), idy = 1.0 / (by - ay);
             int best = -1;
             double best_a = 1.0, bpx = bx, bpy = by;
             unsigned short *myslot = L.slot + lane;  // slot[j][lane]
@@ -470,20 +474,24 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                 // not fit anywhere so the next pass resumes there -- index order is preserved)
                 int nj = 0, c = cstart, cfull = ncand;
                 for (; c < ncand; c++) {
-                    int cnt, k0;
-                    if (c < kLanes) { cnt = __builtin_amdgcn_readlane(my_cnt, c); k0 = __builtin_amdgcn_readlane(my_k0, c); }
-                    else { cnt = L.ccnt[c]; k0 = L.ck0[c]; }
+                    int cnt, k0, ce;
+                    if (c < kLanes) { cnt = __builtin_amdgcn_readlane(my_cnt, c); k0 = __builtin_amdgcn_readlane(my_k0, c); ce = __builtin_amdgcn_readlane(my_id, c); }
+                    else { cnt = uni(L.ccnt[c]); k0 = uni(L.ck0[c]); ce = uni(L.cid[c]); }
                     int rel = k - k0; if (rel < 0) rel += R;
                     const bool inr = active && rel < cnt && c < cfull;
                     if (inr) {
-                        if (nj < kMaxJ) { myslot[nj * kLanes] = (unsigned short)c; nj++; }
-                        else cfull = c;
+                        if (nj < kMaxJ) {
+                            myslot[nj * kLanes] = (unsigned short)c;
+                            myslot[(kMaxJ + nj) * kLanes] = (unsigned short)((ce & 0x7FFF) | ((ce >> 16) << 15));
+                            nj++;
+                        } else cfull = c;
                     }
                 }
                 {   // earliest overflow over the wave: later candidates are dropped from EVERY list of this pass
                     int m = cfull;
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) { int o2 = __shfl_xor(m, off); m = o2 < m ? o2 : m; }
+                    m = uni(m);
                     if (m < ncand) {
                         while (nj > 0 && (int)myslot[(nj - 1) * kLanes] >= m) nj--;
                         c = m;
@@ -493,16 +501,16 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                 // ---- walk the list: [CP cpSpaceSegmentQueryFirst] over this ray's candidates
                 for (int j = 0; __ballot(j < nj) != 0ull; j++) {
                     if (j < nj) {
-                        const int e = L.cid[myslot[j * kLanes]];
-                        const int id = e & 0xFFFF;
+                        const int e = myslot[(kMaxJ + j) * kLanes];  // shape id | near << 15
+                        const int id = e & 0x7FFF;
                         bool visit = true;
                         if (p.gate) {
                             const double *bbp = (id < S) ? (L.bb + 4 * id) : (L.leaf + 4 * (id - S));
-                            visit = bb_segment_query(bbp, ax, ay, dx, dy, idx, idy) < best_a;  // t_exit == best alpha
+                            visit = bb_segment_query(bbp, ax, ay, bx - ax, by - ay, idx, idy) < best_a;  // t_exit == best alpha
                         }
                         if (visit) {
                             SegInfo info = {0, 1.0, bx, by};
-                            if (e >> 16) { info.hit = 1; info.alpha = 0.0; }
+                            if (e >> 15) { info.hit = 1; info.alpha = 0.0; }
                             else if (id < S) poly_segment_query(L, id, p.wall_r, ax, ay, bx, by, r2, info);
                             else circle_segment_query(L.tc[2 * (id - S)], L.tc[2 * (id - S) + 1], p.rc, ax, ay, bx, by, r2, info);
                             if (info.hit && info.alpha < best_a) { best_a = info.alpha; best = id; bpx = info.px; bpy = info.py; }
@@ -518,14 +526,11 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                 d16 = obs_distance_f16(bpx, bpy, ax, ay);
                 ty = (best < S) ? CAT_WALL : ((best - S) >= p.n_cops ? CAT_THIEF : CAT_COP);
             }
-            if (active) {
+            if (active) {  // observations go to LDS; one coalesced burst to HBM after the agent loop
                 const int q = i * R + k;
                 L.od[q] = (unsigned short)d16;
                 L.ot[q] = (unsigned char)ty;
-                const size_t g = (size_t)env * A * R + q;
-                if (la.out.obs_distance) la.out.obs_distance[g] = (unsigned short)d16;
-                if (la.out.obs_type) la.out.obs_type[g] = (unsigned char)ty;
-                if (la.out.hit_shape) la.out.hit_shape[g] = best;
+                if (la.out.hit_shape) la.out.hit_shape[(size_t)env * A * R + q] = best;  // parity/debug only
                 if (ty == want && d16 < dmin) dmin = d16;  // non-negative f16: bit order = value order
             }
             PHASE(pc, 7);
@@ -540,6 +545,11 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         }
         wave_sync();
         PHASE(pc, 8);
+    }
+    {   // Entity.get_observation outputs: [A*R] contiguous per env
+        const size_t g0 = (size_t)env * A * R;
+        if (la.out.obs_distance) for (int q = lane; q < A * R; q += kLanes) la.out.obs_distance[g0 + q] = L.od[q];
+        if (la.out.obs_type) for (int q = lane; q < A * R; q += kLanes) la.out.obs_type[g0 + q] = L.ot[q];
     }
     if (rew_mode && lane < A && la.out.reward) {  // cop.py:49-75 / thief.py:48-69, lane = agent
         const bool is_cop = lane < p.n_cops;
@@ -608,7 +618,7 @@ __device__ __forceinline__ int pair_index(int A, int i, int j) { return i * A - 
 __device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, double cy, double rc,
                                    double &nx, double &ny, double &p1x, double &p1y, double &p2x, double &p2y)
 {
-    const int first = L.first[sh], count = L.count[sh];
+    const int fc = uni(L.fc[sh]), first = fc & 0xFFFF, count = fc >> 16;
     int best = -1, sepi = 0;
     double bestd = INFINITY, bt = 0, bpx = 0, bpy = 0, maxsep = -INFINITY;
     bool inside = true;
@@ -704,21 +714,21 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
                 double nx, ny, p1x, p1y, p2x, p2y;
                 if (!circle_poly_contact(L, sh, p.wall_r, cx, cy, rc, nx, ny, p1x, p1y, p2x, p2y)) continue;
                 int slot = -1;
-                for (int k = 0; k < kK; k++) if (slot < 0 && L.wsh[i * kK + k] == sh) slot = k;
+                for (int k = 0; k < kK; k++) if (slot < 0 && uni(L.wsh[i * kK + k]) == sh) slot = k;
                 int first;
                 if (slot < 0) {
                     first = 1;
-                    for (int k = 0; k < kK; k++) if (slot < 0 && L.wsh[i * kK + k] < 0) slot = k;
+                    for (int k = 0; k < kK; k++) if (slot < 0 && uni(L.wsh[i * kK + k]) < 0) slot = k;
                     if (slot < 0) {
                         int oldest = -1;
                         for (int k = 0; k < kK; k++)
-                            if (!((seen_w >> (i * kK + k)) & 1ull) && (oldest < 0 || L.wag[i * kK + k] > L.wag[i * kK + oldest])) oldest = k;
+                            if (!((seen_w >> (i * kK + k)) & 1ull) && (oldest < 0 || uni(L.wag[i * kK + k]) > uni(L.wag[i * kK + oldest]))) oldest = k;
                         if (oldest < 0) continue;
                         slot = oldest;
                     }
                     L.wsh[i * kK + slot] = sh; L.wjn[i * kK + slot] = 0.0; L.wag[i * kK + slot] = 0;
                 } else {
-                    first = L.wag[i * kK + slot] > 0;
+                    first = uni(L.wag[i * kK + slot]) > 0;
                 }
                 seen_w |= 1ull << (i * kK + slot);
                 double *cf = L.conf + 12 * nc;
@@ -743,8 +753,9 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
             if (dist != 0.0) { double inv = 1.0 / dist; nx = dx * inv; ny = dy * inv; }
             const int pi = pair_index(A, i, j);
             int first;
-            if (L.pag[pi] < 0) { first = 1; L.pjn[pi] = 0.0; }
-            else first = L.pag[pi] > 0;
+            const int page = uni(L.pag[pi]);
+            if (page < 0) { first = 1; L.pjn[pi] = 0.0; }
+            else first = page > 0;
             L.pag[pi] = 0; seen_p |= 1u << pi;
             double *cf = L.conf + 12 * nc;
             int *ci = L.coni + 4 * nc;
@@ -760,17 +771,18 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
     }
     // [CP cpSpaceArbiterSetFilter]: age / expire
     for (int q = 0; q < A * kK; q++) {
-        if (L.wsh[q] < 0) continue;
+        if (uni(L.wsh[q]) < 0) continue;
         if ((seen_w >> q) & 1ull) L.wag[q] = 0;
         else {
-            int a = L.wag[q] + 1;
+            int a = uni(L.wag[q]) + 1;
             if (a >= p.persistence) { L.wsh[q] = -1; L.wag[q] = 0; L.wjn[q] = 0.0; }
             else L.wag[q] = a;
         }
     }
     for (int q = 0; q < p.NP; q++) {
-        if (L.pag[q] < 0 || ((seen_p >> q) & 1u)) continue;
-        int a = L.pag[q] + 1;
+        const int page = uni(L.pag[q]);
+        if (page < 0 || ((seen_p >> q) & 1u)) continue;
+        int a = page + 1;
         if (a >= p.persistence) { L.pag[q] = -1; L.pjn[q] = 0.0; }
         else L.pag[q] = a;
     }
@@ -779,7 +791,7 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
     for (int q = 0; q < nc; q++) {  // [CP cpArbiterPreStep]
         double *cf = L.conf + 12 * q;
         const int *ci = L.coni + 4 * q;
-        const int a = ci[0], b = ci[1];
+        const int a = uni(ci[0]), b = uni(ci[1]);
         double mib = (b < 0) ? 0.0 : m_inv;
         cf[6] = 1.0 / (m_inv + mib);
         double bpx = (b < 0) ? 0.0 : L.pos[2 * b], bpy = (b < 0) ? 0.0 : L.pos[2 * b + 1];
@@ -793,8 +805,8 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
     for (int q = 0; q < nc; q++) {  // [CP cpArbiterApplyCachedImpulse], dt_coef = 1
         const double *cf = L.conf + 12 * q;
         const int *ci = L.coni + 4 * q;
-        if (ci[2]) continue;
-        const int a = ci[0], b = ci[1];
+        if (uni(ci[2])) continue;
+        const int a = uni(ci[0]), b = uni(ci[1]);
         double jx = (cf[0] * cf[9] - cf[1] * 0.0) * 1.0, jy = (cf[0] * 0.0 + cf[1] * cf[9]) * 1.0;
         L.vel[2 * a] = L.vel[2 * a] + (-jx) * m_inv; L.vel[2 * a + 1] = L.vel[2 * a + 1] + (-jy) * m_inv;
         if (b >= 0) { L.vel[2 * b] = L.vel[2 * b] + jx * m_inv; L.vel[2 * b + 1] = L.vel[2 * b + 1] + jy * m_inv; }
@@ -803,7 +815,7 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
         for (int q = 0; q < nc; q++) {
             double *cf = L.conf + 12 * q;
             const int *ci = L.coni + 4 * q;
-            const int a = ci[0], b = ci[1];
+            const int a = uni(ci[0]), b = uni(ci[1]);
             const double nx = cf[0], ny = cf[1];
             double vbbx = (b < 0) ? 0.0 : L.vb[2 * b], vbby = (b < 0) ? 0.0 : L.vb[2 * b + 1];
             double vvbx = (b < 0) ? 0.0 : L.vel[2 * b], vvby = (b < 0) ? 0.0 : L.vel[2 * b + 1];
@@ -830,7 +842,7 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
         }
     }
     for (int q = 0; q < nc; q++) {
-        const int idx = L.coni[4 * q + 3];
+        const int idx = uni(L.coni[4 * q + 3]);
         if (idx & (1 << 20)) L.pjn[idx & 0xFFFFF] = L.conf[12 * q + 9];
         else L.wjn[idx] = L.conf[12 * q + 9];
     }
@@ -843,8 +855,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     const int S = md.S, P = md.P;
     L.bb = reinterpret_cast<const double *>(smem);
     L.planes = L.bb + 4 * S;
-    L.first = reinterpret_cast<const int *>(L.planes + 8 * P);
-    L.count = L.first + S;
+    L.fc = reinterpret_cast<const int *>(L.planes + 8 * P);
     L.rayd = reinterpret_cast<const double *>(smem + p.lds_map_bytes - 16 * p.R);
     char *w = smem + p.lds_map_bytes + wave * p.lds_wave_bytes;
     const int A = p.A, R = p.R, NPs = p.NP > 0 ? p.NP : 1;
@@ -870,10 +881,25 @@ __device__ __forceinline__ void stage_map(const Params &p, char *smem, const Map
     const int nf = 4 * md.S + 8 * md.P;
     double *dst = reinterpret_cast<double *>(smem);
     const double *src = p.geo_f64 + md.f64_off;
-    for (int i = threadIdx.x; i < nf; i += blockDim.x) dst[i] = src[i];
+    {   // 16-byte copies, four in flight per thread (every map base is 16-byte aligned, nf is even)
+        const double2 *s2 = reinterpret_cast<const double2 *>(src);
+        double2 *d2 = reinterpret_cast<double2 *>(dst);
+        const int n2 = nf / 2, T = blockDim.x;
+        for (int i = threadIdx.x; i < n2; i += 4 * T) {
+            double2 v0 = s2[i], v1, v2, v3;
+            const bool h1 = i + T < n2, h2 = i + 2 * T < n2, h3 = i + 3 * T < n2;
+            if (h1) v1 = s2[i + T];
+            if (h2) v2 = s2[i + 2 * T];
+            if (h3) v3 = s2[i + 3 * T];
+            d2[i] = v0;
+            if (h1) d2[i + T] = v1;
+            if (h2) d2[i + 2 * T] = v2;
+            if (h3) d2[i + 3 * T] = v3;
+        }
+    }
     int *di = reinterpret_cast<int *>(dst + nf);
     const int *si = p.geo_i32 + md.i32_off;
-    for (int i = threadIdx.x; i < 2 * md.S; i += blockDim.x) di[i] = si[i];
+    for (int i = threadIdx.x; i < md.S; i += blockDim.x) di[i] = si[i] | (si[md.S + i] << 16);
     double *rd = reinterpret_cast<double *>(smem + p.lds_map_bytes - 16 * p.R);
     for (int i = threadIdx.x; i < p.R; i += blockDim.x) { rd[2 * i] = p.ray_dx[i]; rd[2 * i + 1] = p.ray_dy[i]; }
     __syncthreads();
@@ -914,26 +940,26 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
 {
     const Params &p = *pp;
     extern __shared__ __align__(16) char smem[];
-    const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
+    const int wave = uni(threadIdx.x / kLanes), lane = threadIdx.x % kLanes;
     PhaseClock pc;
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
     stage_map(p, smem, md);
     PHASE(pc, 0);
-    const int env = p.work_env[blockIdx.x * kWaves + wave];
+    const int env = uni(p.work_env[blockIdx.x * kWaves + wave]);
     if (env < 0) return;
     const Lds L = carve(p, smem, md, wave);
     const int S = md.S, A = p.A;
     load_state(L, p, env, lane);
     PHASE(pc, 1);
 
-    const int step = p.step_count[env] + 1;                       // :372
+    const int step = uni(p.step_count[env]) + 1;                  // :372
     const int captured = termination_captured(L, p, S, lane);     // :378
     const int timeout = (!captured && step >= p.max_step) ? 1 : 0;
 
     // Entity._perform_action (entity.py:126-134), every lane computes all agents identically
     const double m_inv = 1.0 / p.mass;
     for (int i = 0; i < A; i++) {
-        const int act = la.actions[(size_t)env * A + i];
+        const int act = uni(la.actions[(size_t)env * A + i]);
         double jx = 0.0, jy = 0.0;
         if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
         else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
@@ -966,13 +992,17 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__r
 {
     const Params &p = *pp;
     extern __shared__ __align__(16) char smem[];
-    const int wave = threadIdx.x / kLanes, lane = threadIdx.x % kLanes;
+    const int wave = uni(threadIdx.x / kLanes), lane = threadIdx.x % kLanes;
+    const int env = uni(p.work_env[blockIdx.x * kWaves + wave]);
+    bool need = env >= 0;
+    if (need) {
+        if (la.use_done_mask) need = p.done[env] != 0;
+        else if (la.mask) need = la.mask[env] != 0;
+    }
+    if (!__syncthreads_or(need ? 1 : 0)) return;  // nothing to reset in this workgroup: skip the map staging
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
     stage_map(p, smem, md);
-    const int env = p.work_env[blockIdx.x * kWaves + wave];
-    if (env < 0) return;
-    if (la.use_done_mask) { if (!p.done[env]) return; }
-    else if (la.mask && !la.mask[env]) return;
+    if (!need) return;
     const Lds L = carve(p, smem, md, wave);
     const int S = md.S, A = p.A;
     load_state(L, p, env, lane);
@@ -1257,10 +1287,10 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     // ---- LDS carve sizes (must match carve())
     auto up = [](int x, int a) { return (x + a - 1) / a * a; };
     p.maxE = maxS + A;
-    p.lds_map_bytes = up((4 * maxS + 8 * maxP) * 8 + 2 * maxS * 4, 16) + 16 * p.R;
+    p.lds_map_bytes = up((4 * maxS + 8 * maxP) * 8 + maxS * 4, 16) + 16 * p.R;
     const int NPs = p.NP > 0 ? p.NP : 1;
     const int phys_bytes = 12 * p.maxc * 8 + 4 * p.maxc * 4;
-    const int slot_bytes = kMaxJ * kLanes * 2;
+    const int slot_bytes = 2 * kMaxJ * kLanes * 2;
     p.lds_union_bytes = up(phys_bytes > slot_bytes ? phys_bytes : slot_bytes, 8);
     int wb = (2 * A * 4 + 4 * A + 2 * A + A * kK + NPs) * 8 + p.lds_union_bytes;
     wb += (A * kK * 2 + NPs + 3 * p.maxE) * 4;

@@ -95,10 +95,18 @@ def main() -> None:
         local_rank = 0
     dev = torch.device("cuda", local_rank)
 
-    cmap = load_preset(args.map, args.cops, args.thieves).compile()
+    if args.map == "mixed":   # BASELINE configs[4]: all five maps interleaved across env slots
+        import numpy as np
+        names = ["agh-map", "grandbyrinth", "labyrinth", "lbirinth", "squarinth"]
+        cmaps = [load_preset(n, args.cops, args.thieves).compile() for n in names]
+        slot = (np.arange(args.envs) % len(cmaps)).astype(np.int32)
+        cmap = cmaps[2]
+    else:
+        cmaps, slot = [load_preset(args.map, args.cops, args.thieves).compile()], None
+        cmap = cmaps[0]
     cfg = SimConfig(n_envs=args.envs, n_cops=args.cops, n_thieves=args.thieves, n_rays=args.rays,
                     max_step_count=400, seed=0, env_id_offset=rank * args.envs)
-    sim = CatSim(cfg, [cmap], device=dev)
+    sim = CatSim(cfg, cmaps, slot, device=dev)
     sim.reset()
     acts = torch.empty((cfg.n_envs, cfg.n_agents), dtype=torch.int32, device=dev)
 
