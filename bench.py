@@ -143,6 +143,10 @@ def main() -> None:
         A, R = cfg.n_agents, cfg.n_rays
         bytes_launch = algorithmic_bytes_per_env_step(A, R) * cfg.n_envs
         achieved = bytes_launch / (tick_ms * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch from the committed PMC passes of this exact workload, if any
+        tfile = ROOT / "profiles" / "r01_traffic.json"
+        if tfile.exists() and (args.map, cfg.n_envs, R, args.cops, args.thieves) == ("labyrinth", 4096, 64, 2, 1):
+            traffic = json.loads(tfile.read_text())["hbm_bytes_per_launch"]
         line = {
             "metric": "env-steps/sec (whole node) at 4096 parallel envs, 2v1 agents, 64-ray sensors",
             "value": world * cfg.n_envs * args.steps / elapsed,
@@ -158,7 +162,7 @@ def main() -> None:
                        "parallelism": f"env-sharded x{world}, no data-path collective",
                        "episodes_reset_per_gpu": episodes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "tick_kernel", "kernel_ms": tick_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "path is FP64-VALU/LDS bound, not HBM bound (SURVEY 8d); fraction reported as contracted"},
