@@ -86,6 +86,7 @@ def lib() -> C.CDLL:
     L.cat_reset.argtypes = [vp, vp, vp, vp, vp]
     L.cat_reset_done.argtypes = [vp, vp, vp]
     L.cat_step.argtypes = [vp, vp, vp, vp]
+    L.cat_step_fused.argtypes = [vp, vp, u64, i32, vp, vp]
     L.cat_get_state.argtypes = [vp, vp, vp]
     L.cat_set_state.argtypes = [vp, vp, vp]
     L.cat_random_actions.argtypes = [vp, u64, vp, vp]
@@ -93,7 +94,7 @@ def lib() -> C.CDLL:
     L.cat_num_agents.argtypes = [vp]
     L.cat_num_shapes.argtypes = [vp, i32]
     L.cat_selftest_arith.argtypes = [i32, vp, vp, vp, i32, i32, vp]
-    for name in ("cat_create", "cat_destroy", "cat_reset", "cat_reset_done", "cat_step", "cat_get_state",
+    for name in ("cat_create", "cat_destroy", "cat_reset", "cat_reset_done", "cat_step", "cat_step_fused", "cat_get_state",
                  "cat_set_state", "cat_random_actions", "cat_set_seed", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith"):
         getattr(L, name).restype = i32
     _lib = L
@@ -101,5 +102,5 @@ def lib() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ("cat_abi_version", "cat_last_error", "cat_create", "cat_destroy", "cat_reset",
-                    "cat_reset_done", "cat_step", "cat_get_state", "cat_set_state", "cat_random_actions",
+                    "cat_reset_done", "cat_step", "cat_step_fused", "cat_get_state", "cat_set_state", "cat_random_actions",
                     "cat_set_seed", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith")

@@ -100,6 +100,7 @@ struct LaunchArgs {
     const unsigned char *mask;
     const double *positions;
     int use_done_mask;
+    unsigned long long synth_tick;  // tick_kernel with actions == NULL: Philox actions of this tick
 };
 
 // ------------------------------------------------------------------ small helpers -----------
@@ -959,7 +960,9 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
     // Entity._perform_action (entity.py:126-134), every lane computes all agents identically
     const double m_inv = 1.0 / p.mass;
     for (int i = 0; i < A; i++) {
-        const int act = uni(la.actions[(size_t)env * A + i]);
+        int act;
+        if (la.actions) act = uni(la.actions[(size_t)env * A + i]);
+        else { unsigned rnd[4]; philox_env(p, env, (unsigned)la.synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
         double jx = 0.0, jy = 0.0;
         if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
         else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
@@ -1365,6 +1368,23 @@ extern "C" int cat_step(cat_sim *s, const int32_t *actions, const cat_outputs *o
                        static_cast<hipStream_t>(stream), s->dev_p, la);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
+}
+
+extern "C" int cat_step_fused(cat_sim *s, const int32_t *actions, uint64_t synth_tick, int auto_reset,
+                              const cat_outputs *out, void *stream)
+{
+    if (!s) return CAT_ERR_BAD_ARG;
+    HIP_TRY(s, hipSetDevice(s->device));
+    LaunchArgs la;
+    memset(&la, 0, sizeof la);
+    if (out) la.out = *out;
+    la.actions = actions; la.synth_tick = synth_tick;
+    hipLaunchKernelGGL(tick_kernel, dim3(s->n_blocks), dim3(kWaves * kLanes), s->lds_bytes,
+                       static_cast<hipStream_t>(stream), s->dev_p, la);
+    HIP_TRY(s, hipGetLastError());
+    // the reset stays its own (early-exiting) launch: inlining it into tick_kernel costs 40+ spilled
+    // VGPRs on the common path, far more than the ~4 us launch it would save
+    return auto_reset ? launch_reset(s, nullptr, nullptr, out, 1, stream) : CAT_OK;
 }
 
 extern "C" int cat_random_actions(cat_sim *s, uint64_t tick, int32_t *actions, void *stream)

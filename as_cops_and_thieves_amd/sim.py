@@ -124,6 +124,19 @@ class CatSim:
         self._check(self._L.cat_step(self._h, actions.data_ptr(), C.byref(self._out_struct), self._stream()), "cat_step")
         return self.out
 
+    def step_fused(self, actions: Optional[torch.Tensor] = None, tick: int = 0, auto_reset: bool = True):
+        """One launch: (synthetic Philox actions when ``actions`` is None) + step + auto-reset."""
+        ptr = None
+        if actions is not None:
+            if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+                actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+            if actions.shape != (self.N, self.A):
+                raise ValueError(f"actions must have shape {(self.N, self.A)}, got {tuple(actions.shape)}")
+            ptr = actions.data_ptr()
+        self._check(self._L.cat_step_fused(self._h, ptr, int(tick), int(auto_reset), C.byref(self._out_struct),
+                                           self._stream()), "cat_step_fused")
+        return self.out
+
     def random_actions(self, tick: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty((self.N, self.A), dtype=torch.int32, device=self.device)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the batched Cops-and-Thieves env core on MI355X.
 
-One "step" = one tick of the whole env batch on every GPU: synthetic Philox actions -> cat_step
-(the full BaseEnv.step pipeline) -> cat_reset_done (auto-reset of finished episodes).  Workload =
+One "step" = one tick of the whole env batch on every GPU: cat_step_fused = synthetic Philox actions
+generated in the step kernel + the full BaseEnv.step pipeline, then cat_reset_done (auto-reset of
+finished episodes on the device-side done mask).  Workload =
 BASELINE.json configs[1]: 2 cops vs 1 thief, labyrinth map, 4096 envs per GPU, 64 rays/agent.
 Env slots shard across GPUs with no data-path collective (weak scaling); only the timing uses a
 barrier + MAX all-reduce.  Prints ONE JSON line on rank 0.
@@ -110,10 +111,8 @@ def main() -> None:
     sim.reset()
     acts = torch.empty((cfg.n_envs, cfg.n_agents), dtype=torch.int32, device=dev)
 
-    def one_step(t: int) -> None:
-        sim.random_actions(t, out=acts)
-        sim.step(acts)
-        sim.reset_done()
+    def one_step(t: int) -> None:   # synthetic Philox actions are generated inside the step kernel
+        sim.step_fused(None, tick=t, auto_reset=True)
 
     for t in range(args.warmup):
         one_step(t)
@@ -128,11 +127,10 @@ def main() -> None:
     t0 = time.perf_counter()
     for k in range(args.steps):
         t = args.warmup + k
-        sim.random_actions(t, out=acts)
         ev[k][0].record()           # HIP events on the stream the kernels are launched on
-        sim.step(acts)
+        sim.step_fused(None, tick=t, auto_reset=False)   # tick_kernel (actions: in-kernel Philox)
         ev[k][1].record()
-        sim.reset_done()
+        sim.reset_done()                                  # reset_kernel on the device-side done mask
     fence()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, device=dev)   # the slowest rank bounds the whole-job rate

@@ -137,6 +137,12 @@ int cat_reset_done(cat_sim *sim, const cat_outputs *out, void *stream);
    actions: DEVICE [N,A] int32 in {0,1,2,3}. */
 int cat_step(cat_sim *sim, const int32_t *actions, const cat_outputs *out, void *stream);
 
+/* One-call form of the rollout tick: cat_step followed by cat_reset_done (auto_reset != 0) and,
+   when actions == NULL, the synthetic Philox actions of cat_random_actions for tick `synth_tick`
+   generated inside the step kernel.  Results are identical to the three separate calls. */
+int cat_step_fused(cat_sim *sim, const int32_t *actions, uint64_t synth_tick, int auto_reset,
+                   const cat_outputs *out, void *stream);
+
 /* Env-state access (the reference cannot checkpoint env state). D2D copies. */
 int cat_get_state(cat_sim *sim, const cat_state *dst, void *stream);
 int cat_set_state(cat_sim *sim, const cat_state *src, void *stream);

@@ -150,3 +150,25 @@ def test_device_arithmetic_is_ieee_exact():
     torch.cuda.synchronize()
     want = np.array([O.cato_obs_distance_f16(float(u), float(v), 0.0, 0.0) for u, v in zip(px[:20000], py[:20000])])
     assert np.array_equal(out.cpu().numpy()[:20000].astype(np.uint16), want.astype(np.uint16))
+
+
+def test_fused_step_equals_three_separate_calls():
+    """cat_step_fused(actions=NULL, tick, auto_reset) == cat_random_actions + cat_step + cat_reset_done."""
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.sim import CatSim
+    m = compiled("lbirinth")
+    cfg = SimConfig(n_envs=96, n_rays=64, max_step_count=15, seed=13)
+    a, b = CatSim(cfg, [m], device="cuda:0"), CatSim(cfg, [m], device="cuda:0")
+    a.reset(); b.reset()
+    for t in range(40):
+        a.step(a.random_actions(t)); a.reset_done()
+        b.step_fused(None, tick=t, auto_reset=True)
+        torch.cuda.synchronize()
+        for k in a.out:
+            assert torch.equal(a.out[k], b.out[k]), (t, k)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert int(sa["reset_count"].min()) >= 2
+    a.close(); b.close()
