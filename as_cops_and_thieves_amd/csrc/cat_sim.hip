@@ -43,6 +43,20 @@ struct MapDesc {
     int pad0, pad1;
 };
 
+// Spatial-hash grids, built once per (map, ray table) on the host (build_grids):
+//   ray grid     : (origin cell, ray index) -> ascending wall ids whose bb the thin segment of that ray
+//                  can enter from ANY origin inside the cell (a conservative superset; the exact
+//                  [CP cpBBSegmentQuery] gate is still evaluated per visit)
+//   contact grid : cell -> ascending wall ids whose bb comes within the agent radius of the cell
+//                  (broadphase of [CP cpSpaceStep], the "origin within ray radius" rule, spawn queries)
+struct GridDesc {
+    double x0, y0, inv_cell;
+    int nx, ny;
+    int off_base, ent_base;     // into grid_off / grid_ent ; rows = nx*ny*R (+1); row_base == off_base - map index
+    int coff_base, cent_base;   // into cgrid_off / cgrid_ent ; rows = nx*ny (+1)
+    int row_base, pad1;         // into grid_rows
+};
+
 struct Params {
     int N, A, n_cops, R, max_step, iterations, persistence, gate, NP, maxc;
     long long env_id_offset;
@@ -53,6 +67,10 @@ struct Params {
     const MapDesc *maps;
     const double *geo_f64;
     const int *geo_i32;
+    const GridDesc *grids;  // [n_maps]
+    const unsigned long long *grid_rows;
+    const int *grid_off, *cgrid_off;
+    const unsigned char *grid_ent, *cgrid_ent;
     const int *work_env;    // [n_blocks*kWaves] env slot or -1
     const int *block_map;   // [n_blocks]
     double *pos, *vel, *vbias, *tc, *leaf, *wjn, *pjn;
@@ -113,9 +131,10 @@ __device__ __forceinline__ double fmin2(double a, double b) { return (a < b) ? a
 // wave-local ordering of LDS traffic between lanes (one wave owns its scratch; no s_barrier)
 __device__ __forceinline__ void wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // LDS-only ("local") fences: ordering global stores here would make every sync wait for HBM
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 // round-to-nearest-even f64 -> f16 bits: NumPy's cast for np.array(points, dtype=np.float16)
@@ -197,8 +216,13 @@ struct Lds {
     double *conf;   // [maxc][12]
     int *coni;      // [maxc][4]
     const double *rayd;  // [R][2]  ray offsets (workgroup-shared)
-    int *cid, *ck0, *ccnt;  // [S+A] candidates of the current agent
-    unsigned short *slot;   // [2][kMaxJ][64] per-ray candidate lists: index, then shape id | near << 15
+    int *acell, *anear;     // [A], [A][2]  grid cell and "origin inside" wall ids per agent
+    int *dk0, *dcnt;        // [A*A]  ray cone (start, count | near << 16) of agent j seen from agent i
+    // ray-fan scratch (overlays the contact arrays: disjoint phases)
+    double *rinv;           // [64][2]   1/(b-a) of the chunk's rays
+    double *itbb, *ialpha;  // [kItemCap] per item: BBTree gate value, hit alpha (2.0 = none)
+    unsigned short *itm;    // [kItemCap] in: ray lane | id << 6   out: id << 6 | feature
+    unsigned short *itemidx;  // [kPassJ][64] item index of (candidate position, ray lane)
     unsigned short *od;  // [A*R]
     unsigned char *ot;   // [A*R]
     double *spawn;  // [A][2]
@@ -338,12 +362,82 @@ __device__ __forceinline__ double poly_point_distance(const Lds &L, int sh, doub
 }
 
 // ------------------------------------------------------------------ ray fan -------------------
-// Per agent, lanes stride the shapes (walls, then the other agents' circles) once and keep those
-// the agent can reach, each with the contiguous range of ray indices whose direction falls inside
-// the cone its bb subtends (a superset of the rays whose thin segment can enter the bb).  Then
-// lanes = rays: every ray collects ITS OWN short list of candidates (index order) and walks it
-// with [CP cpSpaceSegmentQueryFirst]'s sequential rule "visit iff t_bb < best alpha so far, accept
-// iff alpha < best" -- the same result as visiting every shape one after the other.
+// Broadphase = spatial hash (GridDesc): (cell of the agent, ray index) -> ascending candidate wall ids,
+// looked up in a table built once per map; the other agents' circles are added per ray from the cone
+// their (leaf) bb subtends.  The (ray, candidate) pairs of a 64-ray chunk are packed j-major into a
+// dense item list (ballot + mbcnt, no scan), every lane evaluates one item -- the BBTree gate value
+// t_bb and the shape's own segment query (alpha + which face/vertex was hit) -- and each ray then walks
+// ITS items in index order with [CP cpSpaceSegmentQueryFirst]'s sequential rule "visit iff t_bb < best
+// alpha so far, accept iff alpha < best": identical to visiting every shape one after the other.
+constexpr int kFeatNear = 63;       // alpha = 0 hit ([CP cpShapeSegmentQuery] start-inside rule)
+constexpr int kItemCap = 160;       // items per pass
+constexpr int kPassJ = 8;           // candidate positions per ray per pass
+
+// [CP cpPolyShapeSegmentQuery] returning (alpha, feature): plane i -> i, bevel of vertex i -> count + i.
+// Planes overwrite unconditionally, bevels replace on strictly smaller alpha; tracking both separately
+// and merging afterwards is the same "min, earlier wins ties".
+__device__ __forceinline__ void poly_query_feat(const Lds &L, int sh, double r, double ax, double ay,
+                                                double bx, double by, double r2, double &alpha, int &feat)
+{
+    const int fc = L.fc[sh], first = fc & 0xFFFF, count = fc >> 16;
+    const double rsum = r + r2, rr = rsum * rsum;
+    // conservative f32 pre-test for the bevels (see poly_segment_query)
+    const float dxf = (float)(bx - ax), dyf = (float)(by - ay);
+    const float thr = ((float)rsum + 0.01f) * sqrtf(dxf * dxf + dyf * dyf) * 1.00001f + 0.25f;
+    const bool bevels = rsum > 0.0;
+    double pa = 1.0, va = 1.0;
+    int pf = -1, vf = -1;
+    const double *pl = L.planes + 8 * first;
+    for (int i = 0; i < count; i++, pl += 8) {
+        const double2 n = *reinterpret_cast<const double2 *>(pl);
+        const double2 v = *reinterpret_cast<const double2 *>(pl + 2);
+        const double2 e0 = *reinterpret_cast<const double2 *>(pl + 4);  // vn, dtMin
+        double an = ax * n.x + ay * n.y;
+        double d = an - e0.x - rsum;
+        if (!(d < 0.0)) {
+            double bn = bx * n.x + by * n.y;
+            double den = fmax2(an - bn, DBL_MIN);
+            if (!(d > den)) {  // d > den <=> fl(d/den) > 1: exact pre-reject before the division
+                double t = d / den;
+                if (!(t < 0.0 || 1.0 < t)) {
+                    double ptx = ax * (1.0 - t) + bx * t, pty = ay * (1.0 - t) + by * t;
+                    double dtv = n.x * pty - n.y * ptx;
+                    if (e0.y <= dtv && dtv <= pl[6]) { pa = t; pf = i; }
+                }
+            }
+        }
+        if (bevels) {
+            const float ex = (float)(v.x - ax), ey = (float)(v.y - ay);
+            if (!(fabsf(dxf * ey - dyf * ex) > thr)) {  // [CP CircleSegmentQuery]
+                double dax = ax - v.x, day = ay - v.y, dbx = bx - v.x, dby = by - v.y;
+                double dada = dax * dax + day * day, dadb = dax * dbx + day * dby, dbdb = dbx * dbx + dby * dby;
+                double qa = dada - 2.0 * dadb + dbdb;
+                double qb = dadb - dada;
+                double det = qb * qb - qa * (dada - rr);
+                if (det >= 0.0) {
+                    double t = (-qb - sqrt(det)) / qa;
+                    if (0.0 <= t && t <= 1.0 && t < va) { va = t; vf = count + i; }
+                }
+            }
+        }
+    }
+    alpha = 2.0; feat = -1;
+    if (pf >= 0) { alpha = pa; feat = pf; }
+    if (vf >= 0 && va < (pf >= 0 ? pa : 1.0)) { alpha = va; feat = vf; }
+}
+
+// hit point of [CP CircleSegmentQuery]: lerp(a,b,t) - normalize(lerp(da,db,t)) * r2
+__device__ __forceinline__ void circle_hit_point(double cx, double cy, double ax, double ay, double bx, double by,
+                                                 double t, double r2, double &px, double &py)
+{
+    double dax = ax - cx, day = ay - cy, dbx = bx - cx, dby = by - cy;
+    double lx = dax * (1.0 - t) + dbx * t, ly = day * (1.0 - t) + dby * t;
+    double inv = 1.0 / (sqrt(lx * lx + ly * ly) + DBL_MIN);
+    double nx = lx * inv, ny = ly * inv;
+    px = (ax * (1.0 - t) + bx * t) - nx * r2;
+    py = (ay * (1.0 - t) + by * t) - ny * r2;
+}
+
 // atan2 good to ~2e-4 rad (only used for a conservative cone, never for results)
 __device__ __forceinline__ float fast_atan2(float y, float x)
 {
@@ -399,132 +493,208 @@ __device__ __forceinline__ void ray_cone(const Params &p, double ax, double ay, 
 
 // Entity.get_observation for every agent of the env + rewards + team-shared channels.
 // rew_mode: 0 = no rewards (reset), 1 = step (captured/timeout known).
-__device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la, int env, int lane, int S,
-                            int rew_mode, int captured, int timeout, PhaseClock &pc)
+struct LateOut { float reward; unsigned tp16; };   // per-lane values stored at the very end of the kernel
+
+__device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, int env, int lane,
+                            int S, int rew_mode, int captured, int timeout, PhaseClock &pc, LateOut &late)
 {
     const int A = p.A, R = p.R;
     const double r2 = p.ray_radius;
     const unsigned d_empty = f64_to_f16(p.ray_length);  // np.full(R, ray_length, float16) entity.py:200
     const double reach = p.ray_length + r2 + 1e-6;
     const double cone_m = p.gate ? 1e-6 : r2 + 1e-6;
-    const int E = S + A;
-    unsigned my_dmin = 0x10000u;  // lane i keeps agent i's minimum wanted-class distance
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // ---- per-agent setup: grid cell, walls the origin is "inside" (alpha = 0 rule), cones of the other agents
     for (int i = 0; i < A; i++) {
-        const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];  // fresh body.position (entity.py:186)
-        // ---- candidates: walls in index order, then the other agents (entity.py:118-123: the ray
-        //      filter shares the agent's group, so only its own circle is rejected)
-        int ncand = 0;
-        for (int base = 0; base < E; base += kLanes) {
-            const int e = base + lane;
-            bool in = false;
-            int near = 0, k0 = 0, cnt = 0;
-            if (e < S) {
-                const double *bb = L.bb + 4 * e;
-                const double l = bb[0], b = bb[1], r = bb[2], t = bb[3];
-                in = (l <= ax + reach) && (ax - reach <= r) && (b <= ay + reach) && (ay - reach <= t);
-                if (in) {
+        const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];
+        const int cx = (int)floor((ax - gd.x0) * gd.inv_cell), cy = (int)floor((ay - gd.y0) * gd.inv_cell);
+        int cellid = -1, near0 = -1, near1 = -1;
+        if (cx >= 0 && cy >= 0 && cx < gd.nx && cy < gd.ny) {
+            cellid = cy * gd.nx + cx;
+            const int c0 = uni(p.cgrid_off[gd.coff_base + cellid]), c1 = uni(p.cgrid_off[gd.coff_base + cellid + 1]);
+            for (int base = c0; base < c1; base += kLanes) {   // lanes stride the cell's contact candidates
+                const int e = base + lane;
+                bool near = false;
+                int sh = 0;
+                if (e < c1) {
+                    sh = p.cgrid_ent[gd.cent_base + e];
+                    const double *bb = L.bb + 4 * sh;
                     const double m = r2 + 1e-6;
-                    if ((l - m <= ax) && (ax <= r + m) && (b - m <= ay) && (ay <= t + m))
-                        near = poly_point_distance(L, e, p.wall_r, ax, ay) <= r2;  // [CP cpShapeSegmentQuery] alpha = 0 rule
-                    ray_cone(p, ax, ay, l - cone_m, b - cone_m, r + cone_m, t + cone_m, R, k0, cnt);
-                    in = cnt > 0;
+                    if ((bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m))
+                        near = poly_point_distance(L, sh, p.wall_r, ax, ay) <= r2;  // [CP cpShapeSegmentQuery] alpha = 0 rule
                 }
-            } else if (e < E && e - S != i) {
-                const int j = e - S;
-                const double tcx = L.tc[2 * j], tcy = L.tc[2 * j + 1];
-                double l, b, r, t;
-                if (p.gate) { l = L.leaf[4 * j]; b = L.leaf[4 * j + 1]; r = L.leaf[4 * j + 2]; t = L.leaf[4 * j + 3]; }
-                else { l = tcx - p.rc; b = tcy - p.rc; r = tcx + p.rc; t = tcy + p.rc; }
-                in = (l <= ax + reach) && (ax - reach <= r) && (b <= ay + reach) && (ay - reach <= t);
-                if (in) {
-                    const double ex = ax - tcx, ey = ay - tcy;
-                    near = sqrt(ex * ex + ey * ey) - p.rc <= r2;  // [CP cpCircleShapePointQuery]
-                    ray_cone(p, ax, ay, l - cone_m, b - cone_m, r + cone_m, t + cone_m, R, k0, cnt);
-                    in = cnt > 0;
+                unsigned long long m = __ballot(near);
+                while (m) {  // ascending wall ids; more than two such walls cannot matter: the first visited wins at alpha 0
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int id = __builtin_amdgcn_readlane(sh, src);
+                    if (near0 < 0) near0 = id; else if (near1 < 0) near1 = id;
                 }
             }
-            const unsigned long long mask = __ballot(in);
-            if (in) {
-                const int pos = ncand + __popcll(mask & ((1ull << lane) - 1ull));
-                L.cid[pos] = e | (near << 16); L.ck0[pos] = k0; L.ccnt[pos] = cnt;
-            }
-            ncand += __popcll(mask);
         }
-        ncand = uni(ncand);
-        wave_sync();
-        PHASE(pc, 4);
+        if (lane == 0) { L.acell[i] = cellid; L.anear[2 * i] = near0; L.anear[2 * i + 1] = near1; }
+    }
+    if (lane < A * A) {   // lane = (i, j): cone of agent j's circle seen from agent i
+        const int i = lane / A, j = lane % A;
+        int k0 = 0, cnt = 0, near = 0;
+        if (i != j) {
+            const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];
+            const double tcx = L.tc[2 * j], tcy = L.tc[2 * j + 1];
+            double l, b, r, t;
+            if (p.gate) { l = L.leaf[4 * j]; b = L.leaf[4 * j + 1]; r = L.leaf[4 * j + 2]; t = L.leaf[4 * j + 3]; }
+            else { l = tcx - p.rc; b = tcy - p.rc; r = tcx + p.rc; t = tcy + p.rc; }
+            if ((l <= ax + reach) && (ax - reach <= r) && (b <= ay + reach) && (ay - reach <= t)) {
+                const double ex = ax - tcx, ey = ay - tcy;
+                near = sqrt(ex * ex + ey * ey) - p.rc <= r2;  // [CP cpCircleShapePointQuery]
+                ray_cone(p, ax, ay, l - cone_m, b - cone_m, r + cone_m, t + cone_m, R, k0, cnt);
+            }
+        }
+        L.dk0[lane] = k0; L.dcnt[lane] = cnt | (near << 16);
+    }
+    wave_sync();
+    PHASE(pc, 4);
+
+    unsigned my_dmin = 0x10000u;  // lane i keeps agent i's minimum wanted-class distance
+    const int cpa = (R + kLanes - 1) / kLanes, nchunks = A * cpa;   // chunks per agent / in total
+    // packed spatial-hash row of (agent cell, ray): one 8-byte load per ray, fetched one chunk ahead
+    auto fetch_row = [&](int c) -> unsigned long long {
+        if (c >= nchunks) return 0ull;
+        const int ci = c / cpa, ck = (c % cpa) * kLanes + lane;
+        const int cell = uni(L.acell[ci]);
+        if (cell < 0 || ck >= R) return 0ull;
+        return p.grid_rows[gd.row_base + (size_t)cell * R + ck];
+    };
+    unsigned long long row_next = fetch_row(0);
+    unsigned dmin = 0x10000u;
+    for (int c = 0; c < nchunks; c++) {
+        const int i = c / cpa, kb = (c % cpa) * kLanes;
+        const unsigned long long row = row_next;
+        row_next = fetch_row(c + 1);
+        const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];  // fresh body.position (entity.py:186)
+        const int cellid = uni(L.acell[i]), near0 = uni(L.anear[2 * i]), near1 = uni(L.anear[2 * i + 1]);
         const bool is_cop = i < p.n_cops;
         const unsigned want = is_cop ? CAT_THIEF : CAT_COP;
-        unsigned dmin = 0x10000u;
-        // the first 64 candidates stay in registers (lane = candidate) and are broadcast by readlane
-        const int my_cnt = lane < ncand ? L.ccnt[lane] : 0, my_k0 = lane < ncand ? L.ck0[lane] : 0;
-        const int my_id = lane < ncand ? L.cid[lane] : 0;
-        for (int kb = 0; kb < R; kb += kLanes) {
+        if (kb == 0) dmin = 0x10000u;
+        {
             const int k = kb + lane;
             const bool active = k < R;
             const int kk = active ? k : 0;
             const double bx = ax + L.rayd[2 * kk], by = ay + L.rayd[2 * kk + 1];  // entity.py:191-193
-            const double idx = 1.0 / (bx - ax), idy = 1.0 / (by - ay);
-            int best = -1;
-            double best_a = 1.0, bpx = bx, bpy = by;
-            unsigned short *myslot = L.slot + lane;  // slot[j][lane]
-            int cstart = 0;
-            while (cstart < ncand) {
-                // ---- this ray's candidates, in index order, until some lane's list is full
-                // (a full list simply stops taking entries; `cfull` remembers the first candidate that did
-                // not fit anywhere so the next pass resumes there -- index order is preserved)
-                int nj = 0, c = cstart, cfull = ncand;
-                for (; c < ncand; c++) {
-                    int cnt, k0, ce;
-                    if (c < kLanes) { cnt = __builtin_amdgcn_readlane(my_cnt, c); k0 = __builtin_amdgcn_readlane(my_k0, c); ce = __builtin_amdgcn_readlane(my_id, c); }
-                    else { cnt = uni(L.ccnt[c]); k0 = uni(L.ck0[c]); ce = uni(L.cid[c]); }
-                    int rel = k - k0; if (rel < 0) rel += R;
-                    const bool inr = active && rel < cnt && c < cfull;
-                    if (inr) {
-                        if (nj < kMaxJ) {
-                            myslot[nj * kLanes] = (unsigned short)c;
-                            myslot[(kMaxJ + nj) * kLanes] = (unsigned short)((ce & 0x7FFF) | ((ce >> 16) << 15));
-                            nj++;
-                        } else cfull = c;
-                    }
+            L.rinv[2 * lane] = 1.0 / (bx - ax); L.rinv[2 * lane + 1] = 1.0 / (by - ay);
+            // ---- candidates of this ray: walls from the spatial hash (ascending ids), then the other agents
+            const int cnt_w = active ? (int)(row & 0xFF) : 0;
+            unsigned dynmask = 0;
+            if (active)
+                for (int j = 0; j < A; j++) {
+                    if (j == i) continue;
+                    const int dc = uni(L.dcnt[i * A + j]) & 0xFFFF, dk = uni(L.dk0[i * A + j]);
+                    int rel = k - dk; if (rel < 0) rel += R;
+                    if (rel < dc) dynmask |= 1u << j;
                 }
-                {   // earliest overflow over the wave: later candidates are dropped from EVERY list of this pass
-                    int m = cfull;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) { int o2 = __shfl_xor(m, off); m = o2 < m ? o2 : m; }
-                    m = uni(m);
-                    if (m < ncand) {
-                        while (nj > 0 && (int)myslot[(nj - 1) * kLanes] >= m) nj--;
-                        c = m;
+            const int cnt = cnt_w + __popc(dynmask);
+            double best_a = 1.0;
+            int best_fi = -1;   // id << 6 | feature of the accepted item
+            int jj0 = 0;
+            while (__ballot(cnt > jj0) != 0ull) {
+                // ---- pack the items (ray, jj) for jj in [jj0, jj1) j-major
+                int n_items = 0, jj = jj0;
+                for (; jj < jj0 + kPassJ; jj++) {
+                    const bool has = cnt > jj;
+                    const unsigned long long m = __ballot(has);
+                    const int c = __popcll(m);
+                    if (c == 0 || n_items + c > kItemCap) break;
+                    if (has) {
+                        int id;
+                        if (jj < cnt_w) {
+                            if (jj < 7) id = (int)((row >> (8 * (jj + 1))) & 0xFF);
+                            else {   // long rows (dense maps): the full list
+                                const size_t r0 = (size_t)cellid * R + k;
+                                id = p.grid_ent[gd.ent_base + p.grid_off[gd.off_base + r0] + jj];
+                            }
+                        } else {
+                            unsigned dj = dynmask;
+                            for (int q = jj - cnt_w; q > 0; q--) dj &= dj - 1;
+                            id = S + __builtin_ctz(dj);
+                        }
+                        const int t = n_items + __popcll(m & lt_mask);
+                        L.itm[t] = (unsigned short)(lane | (id << 6));
+                        L.itemidx[(jj - jj0) * kLanes + lane] = (unsigned short)t;
                     }
+                    n_items += c;
                 }
+                const int jj1 = jj;
+                wave_sync();
                 PHASE(pc, 5);
-                // ---- walk the list: [CP cpSpaceSegmentQueryFirst] over this ray's candidates
-                for (int j = 0; __ballot(j < nj) != 0ull; j++) {
-                    if (j < nj) {
-                        const int e = myslot[(kMaxJ + j) * kLanes];  // shape id | near << 15
-                        const int id = e & 0x7FFF;
-                        bool visit = true;
+                // ---- one item per lane
+                for (int t0 = 0; t0 < n_items; t0 += kLanes) {
+                    const int t = t0 + lane;
+                    if (t < n_items) {
+                        const int d = L.itm[t];
+                        const int il = d & 63, id = d >> 6;
+                        const int k2 = kb + il;
+                        const double cbx = ax + L.rayd[2 * k2], cby = ay + L.rayd[2 * k2 + 1];
+                        double tbb = 0.0, alpha = 2.0;   // 2.0 = no hit (never below a best alpha <= 1)
+                        int feat = 0;
                         if (p.gate) {
                             const double *bbp = (id < S) ? (L.bb + 4 * id) : (L.leaf + 4 * (id - S));
-                            visit = bb_segment_query(bbp, ax, ay, bx - ax, by - ay, idx, idy) < best_a;  // t_exit == best alpha
+                            tbb = bb_segment_query(bbp, ax, ay, cbx - ax, cby - ay, L.rinv[2 * il], L.rinv[2 * il + 1]);
                         }
-                        if (visit) {
-                            SegInfo info = {0, 1.0, bx, by};
-                            if (e >> 15) { info.hit = 1; info.alpha = 0.0; }
-                            else if (id < S) poly_segment_query(L, id, p.wall_r, ax, ay, bx, by, r2, info);
-                            else circle_segment_query(L.tc[2 * (id - S)], L.tc[2 * (id - S) + 1], p.rc, ax, ay, bx, by, r2, info);
-                            if (info.hit && info.alpha < best_a) { best_a = info.alpha; best = id; bpx = info.px; bpy = info.py; }
+                        if (tbb < 1.0) {
+                            if (id < S) {
+                                if (id == near0 || id == near1) { alpha = 0.0; feat = kFeatNear; }
+                                else { int f; poly_query_feat(L, id, p.wall_r, ax, ay, cbx, cby, r2, alpha, f); feat = f < 0 ? 0 : f; }
+                            } else {
+                                const int j = id - S;
+                                if ((L.dcnt[i * A + j] >> 16) & 1) { alpha = 0.0; feat = kFeatNear; }
+                                else {
+                                    SegInfo ci = {0, 1.0, cbx, cby};
+                                    circle_segment_query(L.tc[2 * j], L.tc[2 * j + 1], p.rc, ax, ay, cbx, cby, r2, ci);
+                                    if (ci.hit) alpha = ci.alpha;
+                                }
+                            }
                         }
+                        L.itbb[t] = tbb; L.ialpha[t] = alpha; L.itm[t] = (unsigned short)((id << 6) | feat);
                     }
                 }
+                wave_sync();
                 PHASE(pc, 6);
-                cstart = c;
+                // ---- each ray walks its own items in index order
+                for (int q = jj0; q < jj1; q++) {
+                    if (cnt > q) {
+                        const int t = L.itemidx[(q - jj0) * kLanes + lane];
+                        const double al = L.ialpha[t];
+                        if (al < best_a && L.itbb[t] < best_a) { best_a = al; best_fi = L.itm[t]; }   // t_exit == best alpha
+                    }
+                }
+                wave_sync();
+                PHASE(pc, 7);
+                jj0 = jj1;
             }
             // ---- hit point -> f16 distance and class (entity.py:200-215, :222-241)
             unsigned d16 = d_empty, ty = CAT_EMPTY;
-            if (best >= 0) {
-                d16 = obs_distance_f16(bpx, bpy, ax, ay);
+            int best = -1;
+            if (best_fi >= 0) {
+                best = best_fi >> 6;
+                const int f = best_fi & 63;
+                const double t = best_a;
+                double px = bx, py = by;  // alpha = 0 hits keep the segment end as their point
+                if (f != kFeatNear) {
+                    if (best < S) {
+                        const int fc = L.fc[best], first = fc & 0xFFFF, count = fc >> 16;
+                        if (f < count) {
+                            const double2 n = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f));
+                            px = (ax * (1.0 - t) + bx * t) - n.x * r2;
+                            py = (ay * (1.0 - t) + by * t) - n.y * r2;
+                        } else {
+                            const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f - count) + 2);
+                            circle_hit_point(v.x, v.y, ax, ay, bx, by, t, r2, px, py);
+                        }
+                    } else {
+                        circle_hit_point(L.tc[2 * (best - S)], L.tc[2 * (best - S) + 1], ax, ay, bx, by, t, r2, px, py);
+                    }
+                }
+                d16 = obs_distance_f16(px, py, ax, ay);
                 ty = (best < S) ? CAT_WALL : ((best - S) >= p.n_cops ? CAT_THIEF : CAT_COP);
             }
             if (active) {  // observations go to LDS; one coalesced burst to HBM after the agent loop
@@ -534,9 +704,9 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                 if (la.out.hit_shape) la.out.hit_shape[(size_t)env * A * R + q] = best;  // parity/debug only
                 if (ty == want && d16 < dmin) dmin = d16;  // non-negative f16: bit order = value order
             }
-            PHASE(pc, 7);
+            PHASE(pc, 8);
         }
-        if (rew_mode) {  // min over the wave; the LUT lookups of all agents are issued together below
+        if (rew_mode && kb + kLanes >= R) {  // last chunk of agent i: min over the wave; LUT lookups are issued together below
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 unsigned o2 = (unsigned)__shfl_xor((int)dmin, off);
@@ -544,14 +714,9 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
             }
             if (lane == i) my_dmin = dmin;
         }
-        wave_sync();
-        PHASE(pc, 8);
     }
-    {   // Entity.get_observation outputs: [A*R] contiguous per env
-        const size_t g0 = (size_t)env * A * R;
-        if (la.out.obs_distance) for (int q = lane; q < A * R; q += kLanes) la.out.obs_distance[g0 + q] = L.od[q];
-        if (la.out.obs_type) for (int q = lane; q < A * R; q += kLanes) la.out.obs_type[g0 + q] = L.ot[q];
-    }
+    wave_sync();
+    late.reward = 0.0f; late.tp16 = 0;
     if (rew_mode && lane < A && la.out.reward) {  // cop.py:49-75 / thief.py:48-69, lane = agent
         const bool is_cop = lane < p.n_cops;
         float r;
@@ -559,8 +724,22 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         else if (timeout) r = is_cop ? -1.0f : 1.0f;
         else if (my_dmin < 0x10000u) r = (is_cop ? p.cop_lut : p.thief_lut)[my_dmin & 0x7FFFu];
         else r = is_cop ? (float)(-0.02 - 0.02) : (float)0.15;
-        la.out.reward[(size_t)env * A + lane] = r;
+        late.reward = r;
     }
+    if (lane < 2 * A) late.tp16 = f64_to_f16(L.pos[lane]);  // observation_spaces.py:92-95 (positions BEFORE Space.step)
+}
+
+// All output stores, issued at the very end of the kernel: the compiler's s_waitcnt vmcnt(0) (in-order
+// with stores, and forced by every flat access) would otherwise stall mid-kernel on HBM write latency.
+__device__ __forceinline__ void emit_observations(const Lds &L, const Params &p, const LaunchArgs &la, int env, int lane,
+                                                  int rew_mode, const LateOut &late)
+{
+    const int A = p.A, R = p.R;
+    if (rew_mode && lane < A && la.out.reward) la.out.reward[(size_t)env * A + lane] = late.reward;
+    if (lane < 2 * A && la.out.team_positions) la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)late.tp16;
+    const size_t g0 = (size_t)env * A * R;   // Entity.get_observation outputs: [A*R] contiguous per env
+    if (la.out.obs_distance) for (int q = lane; q < A * R; q += kLanes) la.out.obs_distance[g0 + q] = L.od[q];
+    if (la.out.obs_type) for (int q = lane; q < A * R; q += kLanes) la.out.obs_type[g0 + q] = L.ot[q];
     // get_shared_observations (observation_spaces.py:98-129): first team member, roster order,
     // with a non-EMPTY ray supplies (type, distance); else EMPTY with the last member's distance
     for (int k = lane; k < R; k += kLanes) {
@@ -574,8 +753,6 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
             if (la.out.shared_distance) la.out.shared_distance[g] = (unsigned short)d;
         }
     }
-    if (lane < 2 * A && la.out.team_positions)  // observation_spaces.py:92-95
-        la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)f64_to_f16(L.pos[lane]);
 }
 
 // ------------------------------------------------------------------ termination ---------------
@@ -615,27 +792,43 @@ __device__ int termination_captured(const Lds &L, const Params &p, int S, int la
 // ------------------------------------------------------------------ physics -------------------
 __device__ __forceinline__ int pair_index(int A, int i, int j) { return i * A - i * (i + 1) / 2 + (j - i - 1); }
 
-// closest hull feature + [CP ClosestPointsNew] -> contact of [CP CircleToPoly]
-__device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, double cy, double rc,
+// closest hull feature + [CP ClosestPointsNew] -> contact of [CP CircleToPoly].
+// Called wave-uniformly; lane i evaluates hull edge i (ClosestT / LerpT of its Minkowski edge), the
+// closest edge is then found by a scalar scan over the per-lane results (lowest index wins ties, as
+// in the sequential loop), and every lane finishes the winning edge identically.
+__device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, double cy, double rc, int lane,
                                    double &nx, double &ny, double &p1x, double &p1y, double &p2x, double &p2y)
 {
     const int fc = uni(L.fc[sh]), first = fc & 0xFFFF, count = fc >> 16;
-    int best = -1, sepi = 0;
-    double bestd = INFINITY, bt = 0, bpx = 0, bpy = 0, maxsep = -INFINITY;
-    bool inside = true;
-    for (int i = 0; i < count; i++) {
+    double sep = -INFINITY, dd = INFINITY, tt = 0.0, ppx = 0.0, ppy = 0.0;
+    if (lane < count) {
+        const int i = lane;
         const double *pl = L.planes + 8 * (first + i);
         const double *pv = L.planes + 8 * (first + (i - 1 + count) % count);
-        double sep = pl[0] * (cx - pl[2]) + pl[1] * (cy - pl[3]);
-        if (sep > 0.0) inside = false;
-        if (sep > maxsep) { maxsep = sep; sepi = i; }
+        sep = pl[0] * (cx - pl[2]) + pl[1] * (cy - pl[3]);
+        // Minkowski points (poly vertex - circle centre); GJK's final ordering for a CCW hull: v0 = vert[i], v1 = vert[i-1]
         double ax_ = pl[2] - cx, ay_ = pl[3] - cy, bx_ = pv[2] - cx, by_ = pv[3] - cy;
         double dx = bx_ - ax_, dy = by_ - ay_;
         double t = -fmin2(fmax2((dx * (ax_ + bx_) + dy * (ay_ + by_)) / (dx * dx + dy * dy), -1.0), 1.0);  // [CP ClosestT]
         double ht = 0.5 * t;                                                                                  // [CP LerpT]
-        double px = ax_ * (0.5 - ht) + bx_ * (0.5 + ht), py = ay_ * (0.5 - ht) + by_ * (0.5 + ht);
-        double dd = px * px + py * py;
-        if (dd < bestd) { bestd = dd; best = i; bt = t; bpx = px; bpy = py; }
+        ppx = ax_ * (0.5 - ht) + bx_ * (0.5 + ht); ppy = ay_ * (0.5 - ht) + by_ * (0.5 + ht);
+        dd = ppx * ppx + ppy * ppy;
+        tt = t;
+    }
+    // a plane farther than rc + rp from the centre separates: no contact (hull lies behind every plane)
+    if (__ballot(sep > rc + rp + 1e-9) != 0ull) return 0;
+    const bool inside = __ballot(sep > 0.0) == 0ull;
+    int best = 0, sepi = 0;
+    double bestd = INFINITY, maxsep = -INFINITY;
+    for (int i = 0; i < count; i++) {   // scalar scan, index order
+        const double di = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(dd) >> 32), i) << 32) |
+                                               (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(dd), i));
+        if (di < bestd) { bestd = di; best = i; }
+        if (inside) {
+            const double si = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(sep) >> 32), i) << 32) |
+                                                   (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(sep), i));
+            if (si > maxsep) { maxsep = si; sepi = i; }
+        }
     }
     if (inside) {  // centre inside the hull: least-penetration plane (deviation D4)
         const double *pl = L.planes + 8 * (first + sepi);
@@ -647,6 +840,11 @@ __device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, d
         p2x = qx + nx * (-rp); p2y = qy + ny * (-rp);
         return 1;
     }
+    auto bcast = [&](double v) -> double {
+        return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), best) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(v), best));
+    };
+    const double bt = bcast(tt), bpx = bcast(ppx), bpy = bcast(ppy);
     const double *pl = L.planes + 8 * (first + best);
     const double *pv = L.planes + 8 * (first + (best - 1 + count) % count);
     double ax_ = pl[2] - cx, ay_ = pl[3] - cy, bx_ = pv[2] - cx, by_ = pv[3] - cy;
@@ -675,11 +873,12 @@ __device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, d
 //                        coni[q*4 + ..] = a b first cache_index (wall: i*K+slot, pair: 1<<20 | pi)
 // [CP cpSpaceStep] for one env.  Executed wave-uniformly (every lane computes the same values and
 // stores them to the same LDS words) except the bb-overlap test, where lanes stride the walls.
-__device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
+__device__ void physics_env(const Lds &L, const Params &p, int S, int lane, PhaseClock &pc)
 {
     const int A = p.A;
     const double dt = p.dt, rc = p.rc;
-    for (int i = 0; i < A; i++) {
+    if (lane < A) {   // lane = agent
+        const int i = lane;
         // [CP cpBodyUpdatePosition]
         double px = L.pos[2 * i] + (L.vel[2 * i] + L.vb[2 * i]) * dt;
         double py = L.pos[2 * i + 1] + (L.vel[2 * i + 1] + L.vb[2 * i + 1]) * dt;
@@ -695,9 +894,13 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
             lf[2] = br + fmax2(x, vx); lf[3] = bt + fmax2(y, vy);
         }
     }
+    wave_sync();
+    PHASE(pc, 12);
     int nc = 0;
     unsigned long long seen_w = 0ull;  // bit i*K+slot (A*K <= 64)
     unsigned seen_p = 0u;
+    // arbiter cache snapshot: lane q = (agent, slot)
+    const int my_wsh = lane < A * kK ? L.wsh[lane] : -1;
     for (int i = 0; i < A; i++) {
         const double cx = L.tc[2 * i], cy = L.tc[2 * i + 1];
         const double bl = cx - rc, bb_ = cy - rc, br = cx + rc, bt = cy + rc;
@@ -713,23 +916,26 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
                 const int sh = base + __builtin_ctzll(m);
                 m &= m - 1;
                 double nx, ny, p1x, p1y, p2x, p2y;
-                if (!circle_poly_contact(L, sh, p.wall_r, cx, cy, rc, nx, ny, p1x, p1y, p2x, p2y)) continue;
-                int slot = -1;
-                for (int k = 0; k < kK; k++) if (slot < 0 && uni(L.wsh[i * kK + k]) == sh) slot = k;
-                int first;
-                if (slot < 0) {
+                if (!circle_poly_contact(L, sh, p.wall_r, cx, cy, rc, lane, nx, ny, p1x, p1y, p2x, p2y)) continue;
+                // arbiter cache lookup [CP cpSpaceCollideShapes / cpArbiterUpdate]: lanes = the agent's slots
+                const bool mine = lane >= i * kK && lane < (i + 1) * kK;
+                const int cur = mine ? L.wsh[lane] : -2;
+                unsigned long long hit = __ballot(cur == sh), freem = __ballot(cur == -1);
+                int slot, first;
+                if (hit) { slot = __builtin_ctzll(hit) - i * kK; first = uni(L.wag[i * kK + slot]) > 0; }
+                else {
                     first = 1;
-                    for (int k = 0; k < kK; k++) if (slot < 0 && uni(L.wsh[i * kK + k]) < 0) slot = k;
-                    if (slot < 0) {
-                        int oldest = -1;
-                        for (int k = 0; k < kK; k++)
-                            if (!((seen_w >> (i * kK + k)) & 1ull) && (oldest < 0 || uni(L.wag[i * kK + k]) > uni(L.wag[i * kK + oldest]))) oldest = k;
+                    if (freem) slot = __builtin_ctzll(freem) - i * kK;
+                    else {   // evict the oldest entry not seen this step (table full of live contacts: drop)
+                        int oldest = -1, oldage = -1;
+                        for (int k = 0; k < kK; k++) {
+                            const int ag = uni(L.wag[i * kK + k]);
+                            if (!((seen_w >> (i * kK + k)) & 1ull) && ag > oldage) { oldest = k; oldage = ag; }
+                        }
                         if (oldest < 0) continue;
                         slot = oldest;
                     }
                     L.wsh[i * kK + slot] = sh; L.wjn[i * kK + slot] = 0.0; L.wag[i * kK + slot] = 0;
-                } else {
-                    first = uni(L.wag[i * kK + slot]) > 0;
                 }
                 seen_w |= 1ull << (i * kK + slot);
                 double *cf = L.conf + 12 * nc;
@@ -743,8 +949,24 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
             }
         }
     }
-    for (int i = 0; i < A; i++) {
-        for (int j = i + 1; j < A; j++) {  // [CP CircleToCircle]
+    PHASE(pc, 13);
+    {   // [CP CircleToCircle] candidates: lane = pair index, then the (rare) overlapping pairs in order
+        bool touch = false;
+        if (lane < p.NP) {
+            int i = 0, rem = lane;
+            while (rem >= A - 1 - i) { rem -= A - 1 - i; i++; }
+            const int j = i + 1 + rem;
+            const double dx = L.tc[2 * j] - L.tc[2 * i], dy = L.tc[2 * j + 1] - L.tc[2 * i + 1];
+            const double mindist = rc + rc;
+            touch = dx * dx + dy * dy < mindist * mindist;
+        }
+        unsigned long long pm = __ballot(touch);
+        while (pm) {
+            const int pi = __builtin_ctzll(pm);
+            pm &= pm - 1;
+            int i = 0, rem = pi;
+            while (rem >= A - 1 - i) { rem -= A - 1 - i; i++; }
+            const int j = i + 1 + rem;
             double mindist = rc + rc;
             double dx = L.tc[2 * j] - L.tc[2 * i], dy = L.tc[2 * j + 1] - L.tc[2 * i + 1];
             double distsq = dx * dx + dy * dy;
@@ -752,7 +974,6 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
             double dist = sqrt(distsq);
             double nx = 1.0, ny = 0.0;
             if (dist != 0.0) { double inv = 1.0 / dist; nx = dx * inv; ny = dy * inv; }
-            const int pi = pair_index(A, i, j);
             int first;
             const int page = uni(L.pag[pi]);
             if (page < 0) { first = 1; L.pjn[pi] = 0.0; }
@@ -770,83 +991,92 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane)
             nc++;
         }
     }
-    // [CP cpSpaceArbiterSetFilter]: age / expire
-    for (int q = 0; q < A * kK; q++) {
-        if (uni(L.wsh[q]) < 0) continue;
-        if ((seen_w >> q) & 1ull) L.wag[q] = 0;
+    (void)my_wsh;
+    wave_sync();
+    PHASE(pc, 14);
+    // [CP cpSpaceArbiterSetFilter]: age / expire, lane = cache entry
+    if (lane < A * kK && L.wsh[lane] >= 0) {
+        if ((seen_w >> lane) & 1ull) L.wag[lane] = 0;
         else {
-            int a = uni(L.wag[q]) + 1;
-            if (a >= p.persistence) { L.wsh[q] = -1; L.wag[q] = 0; L.wjn[q] = 0.0; }
-            else L.wag[q] = a;
+            const int a = L.wag[lane] + 1;
+            if (a >= p.persistence) { L.wsh[lane] = -1; L.wag[lane] = 0; L.wjn[lane] = 0.0; }
+            else L.wag[lane] = a;
         }
     }
-    for (int q = 0; q < p.NP; q++) {
-        const int page = uni(L.pag[q]);
-        if (page < 0 || ((seen_p >> q) & 1u)) continue;
-        int a = page + 1;
-        if (a >= p.persistence) { L.pag[q] = -1; L.pjn[q] = 0.0; }
-        else L.pag[q] = a;
+    if (lane < p.NP) {
+        const int page = L.pag[lane];
+        if (page >= 0 && !((seen_p >> lane) & 1u)) {
+            const int a = page + 1;
+            if (a >= p.persistence) { L.pag[lane] = -1; L.pjn[lane] = 0.0; }
+            else L.pag[lane] = a;
+        }
     }
+    wave_sync();
+    PHASE(pc, 15);
     if (nc == 0) return;
+    wave_sync();   // contact records were written by every lane identically; make them visible per lane
+    // Solver: lane q owns contact q and keeps its constants and accumulators in registers; the bodies stay
+    // in LDS.  Arbiters are processed strictly in list order (only lane q is active in step q), which is
+    // what makes the result equal to the sequential Gauss-Seidel of Chipmunk bit for bit.
     const double m_inv = 1.0 / p.mass;
-    for (int q = 0; q < nc; q++) {  // [CP cpArbiterPreStep]
-        double *cf = L.conf + 12 * q;
-        const int *ci = L.coni + 4 * q;
-        const int a = uni(ci[0]), b = uni(ci[1]);
-        double mib = (b < 0) ? 0.0 : m_inv;
-        cf[6] = 1.0 / (m_inv + mib);
-        double bpx = (b < 0) ? 0.0 : L.pos[2 * b], bpy = (b < 0) ? 0.0 : L.pos[2 * b + 1];
-        double bdx = bpx - L.pos[2 * a], bdy = bpy - L.pos[2 * a + 1];
-        double dist = ((cf[4] - cf[2]) + bdx) * cf[0] + ((cf[5] - cf[3]) + bdy) * cf[1];
-        cf[7] = -p.bias_coef * fmin2(0.0, dist + p.slop) / dt;
-        cf[8] = 0.0;
-        double vbx = (b < 0) ? 0.0 : L.vel[2 * b], vby = (b < 0) ? 0.0 : L.vel[2 * b + 1];
-        cf[10] = ((vbx - L.vel[2 * a]) * cf[0] + (vby - L.vel[2 * a + 1]) * cf[1]) * 0.0;
-    }
-    for (int q = 0; q < nc; q++) {  // [CP cpArbiterApplyCachedImpulse], dt_coef = 1
+    const int q = lane;
+    const bool own = q < nc;
+    int ca = 0, cb = -1, cfirst = 1, cidx = 0;
+    double nx = 0, ny = 0, nMass = 0, bias = 0, jBiasAcc = 0.0, jnAcc = 0, bounce = 0;
+    if (own) {   // [CP cpArbiterPreStep]
         const double *cf = L.conf + 12 * q;
         const int *ci = L.coni + 4 * q;
-        if (uni(ci[2])) continue;
-        const int a = uni(ci[0]), b = uni(ci[1]);
-        double jx = (cf[0] * cf[9] - cf[1] * 0.0) * 1.0, jy = (cf[0] * 0.0 + cf[1] * cf[9]) * 1.0;
-        L.vel[2 * a] = L.vel[2 * a] + (-jx) * m_inv; L.vel[2 * a + 1] = L.vel[2 * a + 1] + (-jy) * m_inv;
-        if (b >= 0) { L.vel[2 * b] = L.vel[2 * b] + jx * m_inv; L.vel[2 * b + 1] = L.vel[2 * b + 1] + jy * m_inv; }
+        ca = ci[0]; cb = ci[1]; cfirst = ci[2]; cidx = ci[3];
+        nx = cf[0]; ny = cf[1]; jnAcc = cf[9];
+        const double mib = (cb < 0) ? 0.0 : m_inv;
+        nMass = 1.0 / (m_inv + mib);
+        const double bpx = (cb < 0) ? 0.0 : L.pos[2 * cb], bpy = (cb < 0) ? 0.0 : L.pos[2 * cb + 1];
+        const double bdx = bpx - L.pos[2 * ca], bdy = bpy - L.pos[2 * ca + 1];
+        const double dist = ((cf[4] - cf[2]) + bdx) * nx + ((cf[5] - cf[3]) + bdy) * ny;
+        bias = -p.bias_coef * fmin2(0.0, dist + p.slop) / dt;
+        const double vbx = (cb < 0) ? 0.0 : L.vel[2 * cb], vby = (cb < 0) ? 0.0 : L.vel[2 * cb + 1];
+        bounce = ((vbx - L.vel[2 * ca]) * nx + (vby - L.vel[2 * ca + 1]) * ny) * 0.0;   // e = 0
+    }
+    wave_sync();
+    for (int step = 0; step < nc; step++) {  // [CP cpArbiterApplyCachedImpulse], dt_coef = 1
+        if (q == step && !cfirst) {
+            const double jx = (nx * jnAcc - ny * 0.0) * 1.0, jy = (nx * 0.0 + ny * jnAcc) * 1.0;
+            L.vel[2 * ca] = L.vel[2 * ca] + (-jx) * m_inv; L.vel[2 * ca + 1] = L.vel[2 * ca + 1] + (-jy) * m_inv;
+            if (cb >= 0) { L.vel[2 * cb] = L.vel[2 * cb] + jx * m_inv; L.vel[2 * cb + 1] = L.vel[2 * cb + 1] + jy * m_inv; }
+        }
     }
     for (int it = 0; it < p.iterations; it++) {  // [CP cpArbiterApplyImpulse]
-        for (int q = 0; q < nc; q++) {
-            double *cf = L.conf + 12 * q;
-            const int *ci = L.coni + 4 * q;
-            const int a = uni(ci[0]), b = uni(ci[1]);
-            const double nx = cf[0], ny = cf[1];
-            double vbbx = (b < 0) ? 0.0 : L.vb[2 * b], vbby = (b < 0) ? 0.0 : L.vb[2 * b + 1];
-            double vvbx = (b < 0) ? 0.0 : L.vel[2 * b], vvby = (b < 0) ? 0.0 : L.vel[2 * b + 1];
-            double vbax = L.vb[2 * a], vbay = L.vb[2 * a + 1], vax = L.vel[2 * a], vay = L.vel[2 * a + 1];
-            double vbn = (vbbx - vbax) * nx + (vbby - vbay) * ny;
-            double vrn = (vvbx - vax) * nx + (vvby - vay) * ny;
-            double jbn = (cf[7] - vbn) * cf[6];
-            double jbnOld = cf[8];
-            double jBias = fmax2(jbnOld + jbn, 0.0);
-            cf[8] = jBias;
-            double jn = -(cf[10] + vrn) * cf[6];
-            double jnOld = cf[9];
-            double jnAcc = fmax2(jnOld + jn, 0.0);
-            cf[9] = jnAcc;
-            double jbx = nx * (jBias - jbnOld), jby = ny * (jBias - jbnOld);
-            double dj = jnAcc - jnOld;
-            double jx = nx * dj - ny * 0.0, jy = nx * 0.0 + ny * dj;
-            L.vb[2 * a] = vbax + (-jbx) * m_inv; L.vb[2 * a + 1] = vbay + (-jby) * m_inv;
-            L.vel[2 * a] = vax + (-jx) * m_inv; L.vel[2 * a + 1] = vay + (-jy) * m_inv;
-            if (b >= 0) {
-                L.vb[2 * b] = vbbx + jbx * m_inv; L.vb[2 * b + 1] = vbby + jby * m_inv;
-                L.vel[2 * b] = vvbx + jx * m_inv; L.vel[2 * b + 1] = vvby + jy * m_inv;
+        for (int step = 0; step < nc; step++) {
+            if (q == step) {
+                const double2 va = *reinterpret_cast<const double2 *>(L.vel + 2 * ca);
+                const double2 vba = *reinterpret_cast<const double2 *>(L.vb + 2 * ca);
+                double2 vb2 = {0.0, 0.0}, vbb2 = {0.0, 0.0};
+                if (cb >= 0) { vb2 = *reinterpret_cast<const double2 *>(L.vel + 2 * cb); vbb2 = *reinterpret_cast<const double2 *>(L.vb + 2 * cb); }
+                const double vbn = (vbb2.x - vba.x) * nx + (vbb2.y - vba.y) * ny;
+                const double vrn = (vb2.x - va.x) * nx + (vb2.y - va.y) * ny;
+                const double jbn = (bias - vbn) * nMass;
+                const double jbnOld = jBiasAcc;
+                jBiasAcc = fmax2(jbnOld + jbn, 0.0);
+                const double jn = -(bounce + vrn) * nMass;
+                const double jnOld = jnAcc;
+                jnAcc = fmax2(jnOld + jn, 0.0);
+                const double jbx = nx * (jBiasAcc - jbnOld), jby = ny * (jBiasAcc - jbnOld);
+                const double dj = jnAcc - jnOld;
+                const double jx = nx * dj - ny * 0.0, jy = nx * 0.0 + ny * dj;   // cpvrotate, jt = 0
+                L.vb[2 * ca] = vba.x + (-jbx) * m_inv; L.vb[2 * ca + 1] = vba.y + (-jby) * m_inv;
+                L.vel[2 * ca] = va.x + (-jx) * m_inv; L.vel[2 * ca + 1] = va.y + (-jy) * m_inv;
+                if (cb >= 0) {
+                    L.vb[2 * cb] = vbb2.x + jbx * m_inv; L.vb[2 * cb + 1] = vbb2.y + jby * m_inv;
+                    L.vel[2 * cb] = vb2.x + jx * m_inv; L.vel[2 * cb + 1] = vb2.y + jy * m_inv;
+                }
             }
         }
     }
-    for (int q = 0; q < nc; q++) {
-        const int idx = uni(L.coni[4 * q + 3]);
-        if (idx & (1 << 20)) L.pjn[idx & 0xFFFFF] = L.conf[12 * q + 9];
-        else L.wjn[idx] = L.conf[12 * q + 9];
+    if (own) {
+        if (cidx & (1 << 20)) L.pjn[cidx & 0xFFFFF] = jnAcc;
+        else L.wjn[cidx] = jnAcc;
     }
+    wave_sync();
 }
 
 // ------------------------------------------------------------------ kernel plumbing -----------
@@ -864,14 +1094,18 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.pos = d; d += 2 * A; L.vel = d; d += 2 * A; L.vb = d; d += 2 * A; L.tc = d; d += 2 * A;
     L.leaf = d; d += 4 * A; L.spawn = d; d += 2 * A;
     L.wjn = d; d += A * kK; L.pjn = d; d += NPs;
-    // union: contact arrays (physics) / per-ray candidate lists (ray fan)
+    // union: contact arrays (physics) / ray-fan scratch
     char *u = reinterpret_cast<char *>(d);
     L.conf = reinterpret_cast<double *>(u);
     L.coni = reinterpret_cast<int *>(L.conf + 12 * p.maxc);
-    L.slot = reinterpret_cast<unsigned short *>(u);
+    L.rinv = reinterpret_cast<double *>(u);
+    L.itbb = L.rinv + 2 * kLanes;
+    L.ialpha = L.itbb + kItemCap;
+    L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
+    L.itemidx = L.itm + kItemCap;
     int *iv = reinterpret_cast<int *>(u + p.lds_union_bytes);
     L.wsh = iv; iv += A * kK; L.wag = iv; iv += A * kK; L.pag = iv; iv += NPs;
-    L.cid = iv; iv += p.maxE; L.ck0 = iv; iv += p.maxE; L.ccnt = iv; iv += p.maxE;
+    L.acell = iv; iv += A; L.anear = iv; iv += 2 * A; L.dk0 = iv; iv += A * A; L.dcnt = iv; iv += A * A;
     L.od = reinterpret_cast<unsigned short *>(iv);
     L.ot = reinterpret_cast<unsigned char *>(L.od + align_up(A * R, 4));
     return L;
@@ -944,6 +1178,7 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
     const int wave = uni(threadIdx.x / kLanes), lane = threadIdx.x % kLanes;
     PhaseClock pc;
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
+    const GridDesc gd = p.grids[p.block_map[blockIdx.x]];
     stage_map(p, smem, md);
     PHASE(pc, 0);
     const int env = uni(p.work_env[blockIdx.x * kWaves + wave]);
@@ -973,11 +1208,13 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
     }
 
     PHASE(pc, 2);
-    observe_env(L, p, la, env, lane, S, 1, captured, timeout, pc);    // entity.py:143-144, :388-390
+    LateOut late;
+    observe_env(L, p, la, gd, env, lane, S, 1, captured, timeout, pc, late);    // entity.py:143-144, :388-390
     PHASE(pc, 9);
-    physics_env(L, p, S, lane);                                   // :392
+    physics_env(L, p, S, lane, pc);                               // :392
     PHASE(pc, 10);
     store_state(L, p, env, lane, true);
+    emit_observations(L, p, la, env, lane, 1, late);
     if (lane == 0) {
         p.step_count[env] = step;
         const unsigned char term = (unsigned char)(captured || timeout);
@@ -1004,6 +1241,7 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__r
     }
     if (!__syncthreads_or(need ? 1 : 0)) return;  // nothing to reset in this workgroup: skip the map staging
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
+    const GridDesc gd = p.grids[p.block_map[blockIdx.x]];
     stage_map(p, smem, md);
     if (!need) return;
     const Lds L = carve(p, smem, md, wave);
@@ -1061,8 +1299,10 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__r
         L.vel[2 * i] = 0.0; L.vel[2 * i + 1] = 0.0;
     }
     PhaseClock pc;
-    observe_env(L, p, la, env, lane, S, 0, 0, 0, pc);   // :334-344
+    LateOut late;
+    observe_env(L, p, la, gd, env, lane, S, 0, 0, 0, pc, late);   // :334-344
     store_state(L, p, env, lane, false);
+    emit_observations(L, p, la, env, lane, 0, late);
     if (lane == 0) { p.step_count[env] = 0; p.reset_count[env] = (int)rc; p.done[env] = 0; }  // :350
 }
 
@@ -1094,7 +1334,82 @@ thread_local char g_create_err[256] = "";
 }  // namespace
 
 // ====================================================================== host side ============
+// ---------------------------------------------------------------------- spatial-hash grids ----
+struct GridHost {
+    std::vector<GridDesc> desc;
+    std::vector<unsigned long long> rows;   // per (cell, ray): count | first 7 ids << 8.. (one 8-byte load)
+    std::vector<int> off, coff;
+    std::vector<unsigned char> ent, cent;
+};
+
+// One map.  bb: [S][4] wall bbs (already inflated by the wall radius).  A wall is a ray-grid candidate
+// of (cell, ray k) iff its bb, grown by `m_ray`, intersects the region swept by the thin segment
+// origin -> origin + d_k over all origins in the cell: conv(cell, cell + d_k), a hexagon whose edge
+// normals are x, y and perp(d_k) -- so a separating-axis test on those three axes is exact.
+static void build_grids(const double *bb, int S, int R, const double *rdx, const double *rdy, double reach,
+                        double m_ray, double m_contact, double cell, GridHost &g)
+{
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    for (int s = 0; s < S; s++) {
+        lo[0] = std::fmin(lo[0], bb[4 * s]); lo[1] = std::fmin(lo[1], bb[4 * s + 1]);
+        hi[0] = std::fmax(hi[0], bb[4 * s + 2]); hi[1] = std::fmax(hi[1], bb[4 * s + 3]);
+    }
+    GridDesc d{};
+    d.x0 = std::floor(lo[0] - reach - cell); d.y0 = std::floor(lo[1] - reach - cell);
+    d.nx = (int)std::ceil((hi[0] + reach + cell - d.x0) / cell); d.ny = (int)std::ceil((hi[1] + reach + cell - d.y0) / cell);
+    d.inv_cell = 1.0 / cell;
+    d.off_base = (int)g.off.size(); d.ent_base = (int)g.ent.size();
+    d.coff_base = (int)g.coff.size(); d.cent_base = (int)g.cent.size();
+    d.row_base = (int)g.rows.size();
+    const double eps = 1e-6;   // cell membership is decided in floating point on the device
+    std::vector<int> near;     // walls within reach of the cell (prefilter)
+    for (int cy = 0; cy < d.ny; cy++) {
+        for (int cx = 0; cx < d.nx; cx++) {
+            const double X0 = d.x0 + cx * cell - eps, X1 = d.x0 + (cx + 1) * cell + eps;
+            const double Y0 = d.y0 + cy * cell - eps, Y1 = d.y0 + (cy + 1) * cell + eps;
+            near.clear();
+            g.coff.push_back((int)g.cent.size() - d.cent_base);
+            for (int s = 0; s < S; s++) {
+                const double l = bb[4 * s], b = bb[4 * s + 1], r = bb[4 * s + 2], t = bb[4 * s + 3];
+                if (l - m_contact <= X1 && X0 <= r + m_contact && b - m_contact <= Y1 && Y0 <= t + m_contact)
+                    g.cent.push_back((unsigned char)s);
+                if (l - reach <= X1 && X0 <= r + reach && b - reach <= Y1 && Y0 <= t + reach) near.push_back(s);
+            }
+            for (int k = 0; k < R; k++) {
+                g.off.push_back((int)g.ent.size() - d.ent_base);
+                const double dx = rdx[k], dy = rdy[k];
+                const double hx0 = X0 + std::fmin(0.0, dx) - eps, hx1 = X1 + std::fmax(0.0, dx) + eps;
+                const double hy0 = Y0 + std::fmin(0.0, dy) - eps, hy1 = Y1 + std::fmax(0.0, dy) + eps;
+                // projections of the cell on n = (-dy, dx)
+                const double c0 = -dy * X0 + dx * Y0, c1 = -dy * X1 + dx * Y0, c2 = -dy * X0 + dx * Y1, c3 = -dy * X1 + dx * Y1;
+                const double nscale = std::fabs(dx) + std::fabs(dy);
+                const double pmin = std::fmin(std::fmin(c0, c1), std::fmin(c2, c3)) - eps * nscale;
+                const double pmax = std::fmax(std::fmax(c0, c1), std::fmax(c2, c3)) + eps * nscale;
+                for (int s : near) {
+                    const double l = bb[4 * s] - m_ray, b = bb[4 * s + 1] - m_ray, r = bb[4 * s + 2] + m_ray, t = bb[4 * s + 3] + m_ray;
+                    if (!(l <= hx1 && hx0 <= r && b <= hy1 && hy0 <= t)) continue;
+                    const double q0 = -dy * l + dx * b, q1 = -dy * r + dx * b, q2 = -dy * l + dx * t, q3 = -dy * r + dx * t;
+                    const double qmin = std::fmin(std::fmin(q0, q1), std::fmin(q2, q3)), qmax = std::fmax(std::fmax(q0, q1), std::fmax(q2, q3));
+                    if (qmin <= pmax && pmin <= qmax) g.ent.push_back((unsigned char)s);
+                }
+                {   // packed row: byte 0 = count (saturating at 255), bytes 1..7 = the first seven ids
+                    const int o0 = g.off.back() + d.ent_base, n = (int)g.ent.size() - o0;
+                    unsigned long long row = (unsigned long long)(n > 255 ? 255 : n);
+                    for (int q = 0; q < n && q < 7; q++) row |= (unsigned long long)g.ent[o0 + q] << (8 * (q + 1));
+                    g.rows.push_back(row);
+                }
+            }
+        }
+    }
+    g.off.push_back((int)g.ent.size() - d.ent_base);
+    g.coff.push_back((int)g.cent.size() - d.cent_base);
+    while (g.ent.size() & 3) g.ent.push_back(0);
+    while (g.cent.size() & 3) g.cent.push_back(0);
+    g.desc.push_back(d);
+}
+
 struct cat_sim {
+    GridHost grid;
     Params p;
     Params *dev_p;
     int device;
@@ -1256,6 +1571,21 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     TRY_ALLOC(dev_alloc(s, const_cast<MapDesc **>(&p.maps), descs.size(), descs.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<double **>(&p.geo_f64), geo_f.size(), geo_f.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.geo_i32), geo_i.size(), geo_i.data()));
+    {   // spatial-hash grids per map (cell size: CAT_GRID_CELL px, default 32)
+        double cell = 32.0;
+        if (const char *e = getenv("CAT_GRID_CELL")) { double v = atof(e); if (v >= 4.0 && v <= 512.0) cell = v; }
+        const double reach = cfg->ray_length + cfg->ray_radius + 1e-3;
+        const double m_ray = cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6;
+        for (int m = 0; m < n_maps; m++)
+            build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, p.R, tab->ray_dx, tab->ray_dy, reach, m_ray,
+                        cfg->agent_radius + 1e-6, cell, s->grid);
+        TRY_ALLOC(dev_alloc(s, const_cast<GridDesc **>(&p.grids), s->grid.desc.size(), s->grid.desc.data()));
+        TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.grid_rows), s->grid.rows.size(), s->grid.rows.data()));
+        TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.grid_off), s->grid.off.size(), s->grid.off.data()));
+        TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.grid_ent), s->grid.ent.size(), s->grid.ent.data()));
+        TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.cgrid_off), s->grid.coff.size(), s->grid.coff.data()));
+        TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.cgrid_ent), s->grid.cent.size(), s->grid.cent.data()));
+    }
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.work_env), work.size(), work.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.block_map), block_map.size(), block_map.data()));
     TRY_ALLOC(dev_alloc(s, &p.pos, NA * 2, pos0.data()));
@@ -1293,10 +1623,10 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     p.lds_map_bytes = up((4 * maxS + 8 * maxP) * 8 + maxS * 4, 16) + 16 * p.R;
     const int NPs = p.NP > 0 ? p.NP : 1;
     const int phys_bytes = 12 * p.maxc * 8 + 4 * p.maxc * 4;
-    const int slot_bytes = 2 * kMaxJ * kLanes * 2;
-    p.lds_union_bytes = up(phys_bytes > slot_bytes ? phys_bytes : slot_bytes, 8);
+    const int fan_bytes = 2 * kLanes * 8 + 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;
+    p.lds_union_bytes = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 8);
     int wb = (2 * A * 4 + 4 * A + 2 * A + A * kK + NPs) * 8 + p.lds_union_bytes;
-    wb += (A * kK * 2 + NPs + 3 * p.maxE) * 4;
+    wb += (A * kK * 2 + NPs + 3 * A + 2 * A * A) * 4;
     wb += up(A * p.R, 4) * 2 + up(A * p.R, 16);
     p.lds_wave_bytes = up(wb, 16);
     s->lds_bytes = (size_t)p.lds_map_bytes + (size_t)kWaves * p.lds_wave_bytes;
@@ -1442,6 +1772,71 @@ extern "C" int cat_debug_phase_cycles(unsigned long long *out24, int reset)
     return CAT_OK;
 }
 #endif
+
+static int grid_lookup(const GridHost &g, int map_index, int R, double x, double y, int k, int *out, int max_out)
+{
+    const GridDesc &d = g.desc[map_index];
+    const int cx = (int)std::floor((x - d.x0) * d.inv_cell), cy = (int)std::floor((y - d.y0) * d.inv_cell);
+    if (cx < 0 || cy < 0 || cx >= d.nx || cy >= d.ny) return 0;
+    const int cellid = cy * d.nx + cx;
+    int o0, o1;
+    const unsigned char *ent;
+    if (k >= 0) {
+        const int row = cellid * R + k;
+        o0 = g.off[d.off_base + row]; o1 = g.off[d.off_base + row + 1];
+        ent = g.ent.data() + d.ent_base;
+    } else {
+        o0 = g.coff[d.coff_base + cellid]; o1 = g.coff[d.coff_base + cellid + 1];
+        ent = g.cent.data() + d.cent_base;
+    }
+    int n = 0;
+    for (int i = o0; i < o1 && n < max_out; i++) out[n++] = ent[i];
+    return o1 - o0;
+}
+
+// Host-only construction of the tables of ONE map (no device needed): used by the CPU tests that
+// check the tables are supersets of the exact gate.
+struct cat_grid_host { GridHost g; int R; };
+
+extern "C" int cat_grid_build_host(const cat_config *cfg, const cat_tables *tab, const void *blob, size_t size,
+                                   double cell, cat_grid_host **out)
+{
+    if (!cfg || !tab || !blob || !out || size < 64) return CAT_ERR_BAD_ARG;
+    int32_t h[16];
+    memcpy(h, blob, 64);
+    const int S = h[2], P = h[3], A = h[4], Rg = h[7];
+    const size_t nf = 2 + 4 * (size_t)S + 8 * (size_t)P + 2 * (size_t)A + 4 * (size_t)Rg;
+    if ((unsigned)h[0] != kBlobMagic || size < 64 + nf * 8 || S < 1 || S > CAT_MAX_SHAPES) return CAT_ERR_BAD_MAP;
+    std::vector<double> f(nf);
+    memcpy(f.data(), static_cast<const unsigned char *>(blob) + 64, nf * 8);
+    cat_grid_host *gh = new cat_grid_host();
+    gh->R = cfg->n_rays;
+    build_grids(f.data() + 2, S, cfg->n_rays, tab->ray_dx, tab->ray_dy, cfg->ray_length + cfg->ray_radius + 1e-3,
+                cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6, cfg->agent_radius + 1e-6, cell > 0 ? cell : 32.0, gh->g);
+    *out = gh;
+    return CAT_OK;
+}
+
+extern "C" int cat_grid_lookup_host(const cat_grid_host *gh, double x, double y, int k, int *out, int max_out)
+{
+    if (!gh || k >= gh->R) return CAT_ERR_BAD_ARG;
+    return grid_lookup(gh->g, 0, gh->R, x, y, k, out, max_out);
+}
+
+extern "C" long long cat_grid_bytes_host(const cat_grid_host *gh)
+{
+    return gh ? (long long)(gh->g.rows.size() * 8 + gh->g.off.size() * 4 + gh->g.ent.size() + gh->g.coff.size() * 4 + gh->g.cent.size()) : 0;
+}
+
+extern "C" void cat_grid_free_host(cat_grid_host *gh) { delete gh; }
+
+// Host copy of the spatial-hash tables, for tests: candidate walls of ray k (k >= 0) or contact
+// candidates (k < 0) for an origin at (x, y) on map `map_index`.  Returns the count (ids in out).
+extern "C" int cat_debug_grid_lookup(const cat_sim *s, int map_index, double x, double y, int k, int *out, int max_out)
+{
+    if (!s || map_index < 0 || map_index >= (int)s->grid.desc.size() || k >= s->p.R) return CAT_ERR_BAD_ARG;
+    return grid_lookup(s->grid, map_index, s->p.R, x, y, k, out, max_out);
+}
 
 extern "C" int cat_selftest_arith(int op, const double *a, const double *b, double *out, int n, int device, void *stream)
 {

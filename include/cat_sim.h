@@ -163,6 +163,20 @@ int cat_num_shapes(const cat_sim *sim, int map_index);
    the caller with HIP events on `stream`; this returns the stream the handle would use for
    NULL (always the device's default stream). */
 
+/* Test hook: the host copy of the spatial-hash broadphase tables built at cat_create.  k >= 0:
+   candidate wall ids of ray k for an origin at (x, y); k < 0: contact candidates of that cell.
+   Returns the list length and writes up to max_out ids. */
+int cat_debug_grid_lookup(const cat_sim *sim, int map_index, double x, double y, int k, int *out, int max_out);
+
+/* Host-only construction/lookup of one map's tables (no device): lets the CPU test-suite verify that
+   the tables are supersets of the exact bb gate.  cell <= 0 selects the default cell size. */
+typedef struct cat_grid_host cat_grid_host;
+int cat_grid_build_host(const cat_config *cfg, const cat_tables *tables, const void *map_blob, size_t blob_size,
+                        double cell, cat_grid_host **out);
+int cat_grid_lookup_host(const cat_grid_host *grid, double x, double y, int k, int *out, int max_out);
+long long cat_grid_bytes_host(const cat_grid_host *grid);
+void cat_grid_free_host(cat_grid_host *grid);
+
 /* Device arithmetic self-test used by tests: out[i] = op(in_a[i], in_b[i]) evaluated on the GPU
    with the same primitives the kernels use (op 0 sqrt(a), 1 a/b, 2 f64->f16 bits of a,
    3 obs-distance f16 bits of (a,b) relative to the origin (0,0)).  DEVICE pointers. */
