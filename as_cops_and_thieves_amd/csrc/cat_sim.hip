@@ -73,9 +73,11 @@ struct Params {
     const unsigned char *grid_ent, *cgrid_ent;
     const int *work_env;    // [n_blocks*kWaves] env slot or -1
     const int *block_map;   // [n_blocks]
-    double *pos, *vel, *vbias, *tc, *leaf, *wjn, *pjn;
-    int *wsh, *wag, *pag, *step_count, *reset_count;
-    unsigned char *done;
+    // Env state: one contiguous record per env slot (so a wave moves it with 16-byte lanes):
+    //   f64  pos[2A] vel[2A] vbias[2A] tc[2A] leaf[4A] wall_jn[8A] pair_jn[NPs]
+    //   i32  wall_shape[8A] wall_age[8A] pair_age[NPs] step_count reset_count done pad
+    char *state;
+    int rec_bytes, rec_doubles;
     int maxE, ang_ok;
     float ang0, inv_step;
     // LDS carve (bytes)
@@ -122,6 +124,14 @@ struct LaunchArgs {
 };
 
 // ------------------------------------------------------------------ small helpers -----------
+// Pointers read out of the Params block are generic to the compiler, which then emits FLAT accesses:
+// those count on vmcnt AND lgkmcnt, so every LDS wait also drains them (no prefetch survives).  An
+// explicit cast to the global address space turns them into global_load/global_store.
+#define GAS __attribute__((address_space(1)))
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // 16-byte moves that work across address spaces
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ GAS T *G(T *p) { return (GAS T *)p; }
+
 // value known to be the same in every lane -> SGPR (lets the compiler keep loop control scalar)
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -213,6 +223,10 @@ struct Lds {
     double *pos, *vel, *vb, *tc, *leaf;  // [A][2] x4, [A][4]
     double *wjn, *pjn;
     int *wsh, *wag, *pag;
+    int *cnt;       // step_count, reset_count, done, pad (tail of the state record)
+    char *rec;      // the env's state record (same layout as in HBM)
+    unsigned short *sd;  // [2R] team-shared distance (staged for wide stores)
+    unsigned char *st;   // [2R] team-shared type
     double *conf;   // [maxc][12]
     int *coni;      // [maxc][4]
     const double *rayd;  // [R][2]  ray offsets (workgroup-shared)
@@ -512,13 +526,13 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         int cellid = -1, near0 = -1, near1 = -1;
         if (cx >= 0 && cy >= 0 && cx < gd.nx && cy < gd.ny) {
             cellid = cy * gd.nx + cx;
-            const int c0 = uni(p.cgrid_off[gd.coff_base + cellid]), c1 = uni(p.cgrid_off[gd.coff_base + cellid + 1]);
+            const int c0 = uni(G(p.cgrid_off)[gd.coff_base + cellid]), c1 = uni(G(p.cgrid_off)[gd.coff_base + cellid + 1]);
             for (int base = c0; base < c1; base += kLanes) {   // lanes stride the cell's contact candidates
                 const int e = base + lane;
                 bool near = false;
                 int sh = 0;
                 if (e < c1) {
-                    sh = p.cgrid_ent[gd.cent_base + e];
+                    sh = G(p.cgrid_ent)[gd.cent_base + e];
                     const double *bb = L.bb + 4 * sh;
                     const double m = r2 + 1e-6;
                     if ((bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m))
@@ -563,7 +577,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         const int ci = c / cpa, ck = (c % cpa) * kLanes + lane;
         const int cell = uni(L.acell[ci]);
         if (cell < 0 || ck >= R) return 0ull;
-        return p.grid_rows[gd.row_base + (size_t)cell * R + ck];
+        return G(p.grid_rows)[gd.row_base + (size_t)cell * R + ck];
     };
     unsigned long long row_next = fetch_row(0);
     unsigned dmin = 0x10000u;
@@ -610,7 +624,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                             if (jj < 7) id = (int)((row >> (8 * (jj + 1))) & 0xFF);
                             else {   // long rows (dense maps): the full list
                                 const size_t r0 = (size_t)cellid * R + k;
-                                id = p.grid_ent[gd.ent_base + p.grid_off[gd.off_base + r0] + jj];
+                                id = G(p.grid_ent)[gd.ent_base + G(p.grid_off)[gd.off_base + r0] + jj];
                             }
                         } else {
                             unsigned dj = dynmask;
@@ -722,11 +736,26 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         float r;
         if (captured) r = is_cop ? 1.0f : -1.0f;
         else if (timeout) r = is_cop ? -1.0f : 1.0f;
-        else if (my_dmin < 0x10000u) r = (is_cop ? p.cop_lut : p.thief_lut)[my_dmin & 0x7FFFu];
+        else if (my_dmin < 0x10000u) r = G(is_cop ? p.cop_lut : p.thief_lut)[my_dmin & 0x7FFFu];
         else r = is_cop ? (float)(-0.02 - 0.02) : (float)0.15;
         late.reward = r;
     }
     if (lane < 2 * A) late.tp16 = f64_to_f16(L.pos[lane]);  // observation_spaces.py:92-95 (positions BEFORE Space.step)
+}
+
+// LDS -> HBM copy of n bytes with the widest store both sides allow (LDS side is 16-byte aligned)
+__device__ __forceinline__ void wide_store(void *gdst, const void *lsrc, int n, int lane)
+{
+    const unsigned long long ga = (unsigned long long)gdst;
+    if (((ga | (unsigned)n) & 15u) == 0) {
+        for (int o = lane; o < n / 16; o += kLanes) ((GAS u32x4 *)gdst)[o] = reinterpret_cast<const u32x4 *>(lsrc)[o];
+    } else if (((ga | (unsigned)n) & 3u) == 0) {
+        for (int o = lane; o < n / 4; o += kLanes) ((GAS unsigned *)gdst)[o] = reinterpret_cast<const unsigned *>(lsrc)[o];
+    } else if (((ga | (unsigned)n) & 1u) == 0) {
+        for (int o = lane; o < n / 2; o += kLanes) ((GAS unsigned short *)gdst)[o] = reinterpret_cast<const unsigned short *>(lsrc)[o];
+    } else {
+        for (int o = lane; o < n; o += kLanes) ((GAS unsigned char *)gdst)[o] = reinterpret_cast<const unsigned char *>(lsrc)[o];
+    }
 }
 
 // All output stores, issued at the very end of the kernel: the compiler's s_waitcnt vmcnt(0) (in-order
@@ -737,9 +766,6 @@ __device__ __forceinline__ void emit_observations(const Lds &L, const Params &p,
     const int A = p.A, R = p.R;
     if (rew_mode && lane < A && la.out.reward) la.out.reward[(size_t)env * A + lane] = late.reward;
     if (lane < 2 * A && la.out.team_positions) la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)late.tp16;
-    const size_t g0 = (size_t)env * A * R;   // Entity.get_observation outputs: [A*R] contiguous per env
-    if (la.out.obs_distance) for (int q = lane; q < A * R; q += kLanes) la.out.obs_distance[g0 + q] = L.od[q];
-    if (la.out.obs_type) for (int q = lane; q < A * R; q += kLanes) la.out.obs_type[g0 + q] = L.ot[q];
     // get_shared_observations (observation_spaces.py:98-129): first team member, roster order,
     // with a non-EMPTY ray supplies (type, distance); else EMPTY with the last member's distance
     for (int k = lane; k < R; k += kLanes) {
@@ -748,11 +774,16 @@ __device__ __forceinline__ void emit_observations(const Lds &L, const Params &p,
             unsigned ty = CAT_EMPTY, d = 0;
             for (int i = lo; i < hi; i++)
                 if (ty == CAT_EMPTY) { ty = L.ot[i * R + k]; d = L.od[i * R + k]; }
-            const size_t g = (size_t)env * 2 * R + team * R + k;
-            if (la.out.shared_type) la.out.shared_type[g] = (unsigned char)ty;
-            if (la.out.shared_distance) la.out.shared_distance[g] = (unsigned short)d;
+            L.st[team * R + k] = (unsigned char)ty;
+            L.sd[team * R + k] = (unsigned short)d;
         }
     }
+    wave_sync();
+    const size_t g0 = (size_t)env * A * R;   // Entity.get_observation outputs: [A*R] contiguous per env
+    if (la.out.obs_distance) wide_store(la.out.obs_distance + g0, L.od, A * R * 2, lane);
+    if (la.out.obs_type) wide_store(la.out.obs_type + g0, L.ot, A * R, lane);
+    if (la.out.shared_distance) wide_store(la.out.shared_distance + (size_t)env * 2 * R, L.sd, 2 * R * 2, lane);
+    if (la.out.shared_type) wide_store(la.out.shared_type + (size_t)env * 2 * R, L.st, 2 * R, lane);
 }
 
 // ------------------------------------------------------------------ termination ---------------
@@ -1090,10 +1121,16 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.rayd = reinterpret_cast<const double *>(smem + p.lds_map_bytes - 16 * p.R);
     char *w = smem + p.lds_map_bytes + wave * p.lds_wave_bytes;
     const int A = p.A, R = p.R, NPs = p.NP > 0 ? p.NP : 1;
+    L.rec = w;
     double *d = reinterpret_cast<double *>(w);
     L.pos = d; d += 2 * A; L.vel = d; d += 2 * A; L.vb = d; d += 2 * A; L.tc = d; d += 2 * A;
-    L.leaf = d; d += 4 * A; L.spawn = d; d += 2 * A;
-    L.wjn = d; d += A * kK; L.pjn = d; d += NPs;
+    L.leaf = d; d += 4 * A; L.wjn = d; d += A * kK; L.pjn = d; d += NPs;
+    {
+        int *ri = reinterpret_cast<int *>(d);
+        L.wsh = ri; ri += A * kK; L.wag = ri; ri += A * kK; L.pag = ri; ri += NPs; L.cnt = ri;
+    }
+    d = reinterpret_cast<double *>(w + p.rec_bytes);
+    L.spawn = d; d += 2 * A;
     // union: contact arrays (physics) / ray-fan scratch
     char *u = reinterpret_cast<char *>(d);
     L.conf = reinterpret_cast<double *>(u);
@@ -1104,10 +1141,15 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
     L.itemidx = L.itm + kItemCap;
     int *iv = reinterpret_cast<int *>(u + p.lds_union_bytes);
-    L.wsh = iv; iv += A * kK; L.wag = iv; iv += A * kK; L.pag = iv; iv += NPs;
     L.acell = iv; iv += A; L.anear = iv; iv += 2 * A; L.dk0 = iv; iv += A * A; L.dcnt = iv; iv += A * A;
-    L.od = reinterpret_cast<unsigned short *>(iv);
-    L.ot = reinterpret_cast<unsigned char *>(L.od + align_up(A * R, 4));
+    {   // output staging, every array 16-byte aligned
+        char *o = reinterpret_cast<char *>(iv);
+        o = w + align_up((int)(o - w), 16);
+        L.od = reinterpret_cast<unsigned short *>(o); o += align_up(A * R * 2, 16);
+        L.ot = reinterpret_cast<unsigned char *>(o); o += align_up(A * R, 16);
+        L.sd = reinterpret_cast<unsigned short *>(o); o += align_up(2 * R * 2, 16);
+        L.st = reinterpret_cast<unsigned char *>(o);
+    }
     return L;
 }
 
@@ -1115,13 +1157,13 @@ __device__ __forceinline__ void stage_map(const Params &p, char *smem, const Map
 {
     const int nf = 4 * md.S + 8 * md.P;
     double *dst = reinterpret_cast<double *>(smem);
-    const double *src = p.geo_f64 + md.f64_off;
+    GAS const double *src = G(p.geo_f64) + md.f64_off;
     {   // 16-byte copies, four in flight per thread (every map base is 16-byte aligned, nf is even)
-        const double2 *s2 = reinterpret_cast<const double2 *>(src);
-        double2 *d2 = reinterpret_cast<double2 *>(dst);
+        GAS const f64x2 *s2 = (GAS const f64x2 *)src;
+        f64x2 *d2 = reinterpret_cast<f64x2 *>(dst);
         const int n2 = nf / 2, T = blockDim.x;
         for (int i = threadIdx.x; i < n2; i += 4 * T) {
-            double2 v0 = s2[i], v1, v2, v3;
+            f64x2 v0 = s2[i], v1, v2, v3;
             const bool h1 = i + T < n2, h2 = i + 2 * T < n2, h3 = i + 3 * T < n2;
             if (h1) v1 = s2[i + T];
             if (h2) v2 = s2[i + 2 * T];
@@ -1133,41 +1175,27 @@ __device__ __forceinline__ void stage_map(const Params &p, char *smem, const Map
         }
     }
     int *di = reinterpret_cast<int *>(dst + nf);
-    const int *si = p.geo_i32 + md.i32_off;
+    GAS const int *si = G(p.geo_i32) + md.i32_off;
     for (int i = threadIdx.x; i < md.S; i += blockDim.x) di[i] = si[i] | (si[md.S + i] << 16);
     double *rd = reinterpret_cast<double *>(smem + p.lds_map_bytes - 16 * p.R);
-    for (int i = threadIdx.x; i < p.R; i += blockDim.x) { rd[2 * i] = p.ray_dx[i]; rd[2 * i + 1] = p.ray_dy[i]; }
+    for (int i = threadIdx.x; i < p.R; i += blockDim.x) { rd[2 * i] = G(p.ray_dx)[i]; rd[2 * i + 1] = G(p.ray_dy)[i]; }
     __syncthreads();
 }
 
 __device__ __forceinline__ void load_state(const Lds &L, const Params &p, int env, int lane)
 {
-    const int A = p.A;
-    const size_t b2 = (size_t)env * A * 2, b4 = (size_t)env * A * 4, bk = (size_t)env * A * kK;
-    if (lane < 2 * A) {
-        L.pos[lane] = p.pos[b2 + lane]; L.vel[lane] = p.vel[b2 + lane];
-        L.vb[lane] = p.vbias[b2 + lane]; L.tc[lane] = p.tc[b2 + lane];
-    }
-    if (lane < 4 * A) L.leaf[lane] = p.leaf[b4 + lane];
-    if (lane < A * kK) { L.wsh[lane] = p.wsh[bk + lane]; L.wag[lane] = p.wag[bk + lane]; L.wjn[lane] = p.wjn[bk + lane]; }
-    if (lane < p.NP) { L.pag[lane] = p.pag[(size_t)env * p.NP + lane]; L.pjn[lane] = p.pjn[(size_t)env * p.NP + lane]; }
+    GAS const u32x4 *src = (GAS const u32x4 *)(G(p.state) + (size_t)env * p.rec_bytes);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(L.rec);
+    for (int o = lane; o < p.rec_bytes / 16; o += kLanes) dst[o] = src[o];
     wave_sync();
 }
 
-__device__ __forceinline__ void store_state(const Lds &L, const Params &p, int env, int lane, bool physics)
+__device__ __forceinline__ void store_state(const Lds &L, const Params &p, int env, int lane)
 {
-    const int A = p.A;
-    const size_t b2 = (size_t)env * A * 2, b4 = (size_t)env * A * 4, bk = (size_t)env * A * kK;
     wave_sync();
-    if (lane < 2 * A) {
-        p.pos[b2 + lane] = L.pos[lane]; p.vel[b2 + lane] = L.vel[lane];
-        if (physics) { p.vbias[b2 + lane] = L.vb[lane]; p.tc[b2 + lane] = L.tc[lane]; }
-    }
-    if (physics) {
-        if (lane < 4 * A) p.leaf[b4 + lane] = L.leaf[lane];
-        if (lane < A * kK) { p.wsh[bk + lane] = L.wsh[lane]; p.wag[bk + lane] = L.wag[lane]; p.wjn[bk + lane] = L.wjn[lane]; }
-        if (lane < p.NP) { p.pag[(size_t)env * p.NP + lane] = L.pag[lane]; p.pjn[(size_t)env * p.NP + lane] = L.pjn[lane]; }
-    }
+    GAS u32x4 *dst = (GAS u32x4 *)(G(p.state) + (size_t)env * p.rec_bytes);
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(L.rec);
+    for (int o = lane; o < p.rec_bytes / 16; o += kLanes) dst[o] = src[o];
 }
 
 // BaseEnv.step (base_env.py:354-413), one wave per env
@@ -1188,7 +1216,7 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
     load_state(L, p, env, lane);
     PHASE(pc, 1);
 
-    const int step = uni(p.step_count[env]) + 1;                  // :372
+    const int step = uni(L.cnt[0]) + 1;                           // :372
     const int captured = termination_captured(L, p, S, lane);     // :378
     const int timeout = (!captured && step >= p.max_step) ? 1 : 0;
 
@@ -1213,12 +1241,11 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
     PHASE(pc, 9);
     physics_env(L, p, S, lane, pc);                               // :392
     PHASE(pc, 10);
-    store_state(L, p, env, lane, true);
+    const unsigned char term = (unsigned char)(captured || timeout);
+    if (lane == 0) { L.cnt[0] = step; L.cnt[2] = term; }
+    store_state(L, p, env, lane);
     emit_observations(L, p, la, env, lane, 1, late);
     if (lane == 0) {
-        p.step_count[env] = step;
-        const unsigned char term = (unsigned char)(captured || timeout);
-        p.done[env] = term;
         if (la.out.terminated) la.out.terminated[env] = term;       // entity.py:146
         if (la.out.truncated) la.out.truncated[env] = (unsigned char)timeout;  // :397
         if (la.out.winner) la.out.winner[env] = (signed char)(captured ? 0 : (timeout ? 1 : -1));  // :399-406
@@ -1236,7 +1263,8 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__r
     const int env = uni(p.work_env[blockIdx.x * kWaves + wave]);
     bool need = env >= 0;
     if (need) {
-        if (la.use_done_mask) need = p.done[env] != 0;
+        if (la.use_done_mask)
+            need = ((GAS const int *)(G(p.state) + (size_t)env * p.rec_bytes + 8 * p.rec_doubles))[2 * p.A * kK + (p.NP > 0 ? p.NP : 1) + 2] != 0;
         else if (la.mask) need = la.mask[env] != 0;
     }
     if (!__syncthreads_or(need ? 1 : 0)) return;  // nothing to reset in this workgroup: skip the map staging
@@ -1247,10 +1275,10 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__r
     const Lds L = carve(p, smem, md, wave);
     const int S = md.S, A = p.A;
     load_state(L, p, env, lane);
-    const unsigned rc = (unsigned)(p.reset_count[env] + 1);
-    const double *start = p.geo_f64 + md.f64_off + 4 * md.S + 8 * md.P;
-    const double *regions = start + 2 * md.A;
-    const int *region_off = p.geo_i32 + md.i32_off + 2 * md.S;
+    const unsigned rc = (unsigned)(uni(L.cnt[1]) + 1);
+    GAS const double *start = G(p.geo_f64) + md.f64_off + 4 * md.S + 8 * md.P;
+    GAS const double *regions = start + 2 * md.A;
+    GAS const int *region_off = G(p.geo_i32) + md.i32_off + 2 * md.S;
 
     for (int i = 0; i < A; i++) {
         double sx, sy;
@@ -1262,7 +1290,7 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__r
             else {
                 unsigned rnd[4];
                 philox_env(p, env, rc, (unsigned)i, 0x100u, rnd);
-                const double *rg = regions + 4 * (r0 + (int)(rnd[0] % (unsigned)nr));  // :144-145
+                GAS const double *rg = regions + 4 * (r0 + (int)(rnd[0] % (unsigned)nr));  // :144-145
                 const double rgx = rg[0], rgy = rg[1], rgw = rg[2], rgh = rg[3];
                 bool ok = false;
                 sx = rgx + rgw / 2; sy = rgy + rgh / 2;                     // :163-166 fallback
@@ -1301,9 +1329,9 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__r
     PhaseClock pc;
     LateOut late;
     observe_env(L, p, la, gd, env, lane, S, 0, 0, 0, pc, late);   // :334-344
-    store_state(L, p, env, lane, false);
+    if (lane == 0) { L.cnt[0] = 0; L.cnt[1] = (int)rc; L.cnt[2] = 0; }  // :350
+    store_state(L, p, env, lane);
     emit_observations(L, p, la, env, lane, 0, late);
-    if (lane == 0) { p.step_count[env] = 0; p.reset_count[env] = (int)rc; p.done[env] = 0; }  // :350
 }
 
 __global__ void random_actions_kernel(const Params *__restrict__ pp, unsigned long long tick, int *actions)
@@ -1546,22 +1574,32 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
 
     int rc = CAT_OK;
     auto fail = [&](int code) { strncpy(g_create_err, s->err, sizeof g_create_err - 1); cat_destroy(s); return code; };
-    const size_t NA = (size_t)N * A;
-    std::vector<double> pos0(NA * 2), leaf0(NA * 4);
-    std::vector<int> wsh0(NA * kK, -1), pag0((size_t)N * (p.NP ? p.NP : 1), -1);
+    // ---- env state records (layout documented at Params::state)
+    const int NPs_rec = p.NP > 0 ? p.NP : 1;
+    p.rec_doubles = 12 * A + A * kK + NPs_rec;
+    {
+        const int ni = 2 * A * kK + NPs_rec + 4;
+        p.rec_bytes = (p.rec_doubles * 8 + ni * 4 + 15) / 16 * 16;
+    }
+    std::vector<char> rec0((size_t)N * p.rec_bytes, 0);
     for (int e = 0; e < N; e++) {
         const MapDesc &d = descs[slot[e]];
         const double *start = geo_f.data() + d.f64_off + 4 * d.S + 8 * d.P;
+        double *rd = reinterpret_cast<double *>(rec0.data() + (size_t)e * p.rec_bytes);
+        int *ri = reinterpret_cast<int *>(rd + p.rec_doubles);
         for (int i = 0; i < A; i++) {
             // Entity.__init__ + space.add: caches and BBTree leaf at the start position, v = 0
-            const size_t q = (size_t)e * A + i;
             const double x = start[2 * i], y = start[2 * i + 1], r = cfg->agent_radius;
-            pos0[2 * q] = x; pos0[2 * q + 1] = y;
+            rd[2 * i] = x; rd[2 * i + 1] = y;                       // pos
+            rd[6 * A + 2 * i] = x; rd[6 * A + 2 * i + 1] = y;       // tc
             const double l = x - r, b = y - r, rr = x + r, t = y + r;
             const double mx = (rr - l) * 0.1, my = (t - b) * 0.1;
-            leaf0[4 * q] = l + (-mx < 0.0 ? -mx : 0.0); leaf0[4 * q + 1] = b + (-my < 0.0 ? -my : 0.0);
-            leaf0[4 * q + 2] = rr + (mx > 0.0 ? mx : 0.0); leaf0[4 * q + 3] = t + (my > 0.0 ? my : 0.0);
+            double *lf = rd + 8 * A + 4 * i;
+            lf[0] = l + (-mx < 0.0 ? -mx : 0.0); lf[1] = b + (-my < 0.0 ? -my : 0.0);
+            lf[2] = rr + (mx > 0.0 ? mx : 0.0); lf[3] = t + (my > 0.0 ? my : 0.0);
         }
+        for (int q = 0; q < A * kK; q++) ri[q] = -1;                // wall_shape: free slots
+        for (int q = 0; q < NPs_rec; q++) ri[2 * A * kK + q] = -1;  // pair_age: none
     }
 #define TRY_ALLOC(call) do { rc = (call); if (rc != CAT_OK) return fail(rc); } while (0)
     TRY_ALLOC(dev_alloc(s, const_cast<double **>(&p.ray_dx), (size_t)p.R, tab->ray_dx));
@@ -1571,8 +1609,8 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     TRY_ALLOC(dev_alloc(s, const_cast<MapDesc **>(&p.maps), descs.size(), descs.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<double **>(&p.geo_f64), geo_f.size(), geo_f.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.geo_i32), geo_i.size(), geo_i.data()));
-    {   // spatial-hash grids per map (cell size: CAT_GRID_CELL px, default 32)
-        double cell = 32.0;
+    {   // spatial-hash grids per map (cell size: CAT_GRID_CELL px, default 16)
+        double cell = 16.0;
         if (const char *e = getenv("CAT_GRID_CELL")) { double v = atof(e); if (v >= 4.0 && v <= 512.0) cell = v; }
         const double reach = cfg->ray_length + cfg->ray_radius + 1e-3;
         const double m_ray = cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6;
@@ -1588,19 +1626,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     }
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.work_env), work.size(), work.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.block_map), block_map.size(), block_map.data()));
-    TRY_ALLOC(dev_alloc(s, &p.pos, NA * 2, pos0.data()));
-    TRY_ALLOC(dev_alloc(s, &p.tc, NA * 2, pos0.data()));
-    TRY_ALLOC(dev_alloc(s, &p.vel, NA * 2, nullptr));
-    TRY_ALLOC(dev_alloc(s, &p.vbias, NA * 2, nullptr));
-    TRY_ALLOC(dev_alloc(s, &p.leaf, NA * 4, leaf0.data()));
-    TRY_ALLOC(dev_alloc(s, &p.wsh, NA * kK, wsh0.data()));
-    TRY_ALLOC(dev_alloc(s, &p.wag, NA * kK, nullptr));
-    TRY_ALLOC(dev_alloc(s, &p.wjn, NA * kK, nullptr));
-    TRY_ALLOC(dev_alloc(s, &p.pag, pag0.size(), pag0.data()));
-    TRY_ALLOC(dev_alloc(s, &p.pjn, pag0.size(), nullptr));
-    TRY_ALLOC(dev_alloc(s, &p.step_count, (size_t)N, nullptr));
-    TRY_ALLOC(dev_alloc(s, &p.reset_count, (size_t)N, nullptr));
-    TRY_ALLOC(dev_alloc(s, &p.done, (size_t)N, nullptr));
+    TRY_ALLOC(dev_alloc(s, &p.state, rec0.size(), rec0.data()));
 #undef TRY_ALLOC
     // ---- ray-direction cone parameters: valid when the table is a uniform full circle
     {
@@ -1625,9 +1651,9 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     const int phys_bytes = 12 * p.maxc * 8 + 4 * p.maxc * 4;
     const int fan_bytes = 2 * kLanes * 8 + 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;
     p.lds_union_bytes = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 8);
-    int wb = (2 * A * 4 + 4 * A + 2 * A + A * kK + NPs) * 8 + p.lds_union_bytes;
-    wb += (A * kK * 2 + NPs + 3 * A + 2 * A * A) * 4;
-    wb += up(A * p.R, 4) * 2 + up(A * p.R, 16);
+    int wb = p.rec_bytes + 2 * A * 8 + p.lds_union_bytes;          // record, spawn, union
+    wb += (3 * A + 2 * A * A) * 4;                                 // acell, anear, dk0, dcnt
+    wb = up(wb, 16) + up(A * p.R * 2, 16) + up(A * p.R, 16) + up(2 * p.R * 2, 16) + up(2 * p.R, 16);   // output staging
     p.lds_wave_bytes = up(wb, 16);
     s->lds_bytes = (size_t)p.lds_map_bytes + (size_t)kWaves * p.lds_wave_bytes;
     if (s->lds_bytes > 160 * 1024) {
@@ -1744,18 +1770,28 @@ static int copy_state(cat_sim *s, const cat_state *v, bool get, void *stream)
     if (!s || !v) return CAT_ERR_BAD_ARG;
     HIP_TRY(s, hipSetDevice(s->device));
     const Params &p = s->p;
-    const size_t NA = (size_t)p.N * p.A;
+    const int A = p.A, NPs = p.NP > 0 ? p.NP : 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define CP(field, internal, bytes)                                                                        \
-    if (v->field) HIP_TRY(s, hipMemcpyAsync(get ? (void *)v->field : (void *)internal,                    \
-                                            get ? (const void *)internal : (const void *)v->field, bytes, \
-                                            hipMemcpyDeviceToDevice, st))
-    CP(pos, p.pos, NA * 16); CP(vel, p.vel, NA * 16); CP(vbias, p.vbias, NA * 16); CP(tc, p.tc, NA * 16);
-    CP(leaf_bb, p.leaf, NA * 32); CP(wall_shape, p.wsh, NA * kK * 4); CP(wall_age, p.wag, NA * kK * 4);
-    CP(wall_jn, p.wjn, NA * kK * 8);
-    if (p.NP > 0) { CP(pair_age, p.pag, (size_t)p.N * p.NP * 4); CP(pair_jn, p.pjn, (size_t)p.N * p.NP * 8); }
-    CP(step_count, p.step_count, (size_t)p.N * 4); CP(reset_count, p.reset_count, (size_t)p.N * 4);
-#undef CP
+    // field <-> strided slice of the per-env records
+    auto cp = [&](void *user, size_t rec_off, size_t width) -> hipError_t {
+        if (!user || width == 0) return hipSuccess;
+        char *recp = p.state + rec_off;
+        return get ? hipMemcpy2DAsync(user, width, recp, (size_t)p.rec_bytes, width, (size_t)p.N, hipMemcpyDeviceToDevice, st)
+                   : hipMemcpy2DAsync(recp, (size_t)p.rec_bytes, user, width, width, (size_t)p.N, hipMemcpyDeviceToDevice, st);
+    };
+    const size_t D = 8, I = 4, ib = (size_t)p.rec_doubles * 8;
+    HIP_TRY(s, cp(v->pos, 0, 2 * A * D));
+    HIP_TRY(s, cp(v->vel, 2 * A * D, 2 * A * D));
+    HIP_TRY(s, cp(v->vbias, 4 * A * D, 2 * A * D));
+    HIP_TRY(s, cp(v->tc, 6 * A * D, 2 * A * D));
+    HIP_TRY(s, cp(v->leaf_bb, 8 * A * D, 4 * A * D));
+    HIP_TRY(s, cp(v->wall_jn, 12 * A * D, (size_t)A * kK * D));
+    if (p.NP > 0) HIP_TRY(s, cp(v->pair_jn, (12 * A + (size_t)A * kK) * D, (size_t)p.NP * D));
+    HIP_TRY(s, cp(v->wall_shape, ib, (size_t)A * kK * I));
+    HIP_TRY(s, cp(v->wall_age, ib + (size_t)A * kK * I, (size_t)A * kK * I));
+    if (p.NP > 0) HIP_TRY(s, cp(v->pair_age, ib + 2 * (size_t)A * kK * I, (size_t)p.NP * I));
+    HIP_TRY(s, cp(v->step_count, ib + (2 * (size_t)A * kK + NPs) * I, I));
+    HIP_TRY(s, cp(v->reset_count, ib + (2 * (size_t)A * kK + NPs + 1) * I, I));
     return CAT_OK;
 }
 
@@ -1812,7 +1848,7 @@ extern "C" int cat_grid_build_host(const cat_config *cfg, const cat_tables *tab,
     cat_grid_host *gh = new cat_grid_host();
     gh->R = cfg->n_rays;
     build_grids(f.data() + 2, S, cfg->n_rays, tab->ray_dx, tab->ray_dy, cfg->ray_length + cfg->ray_radius + 1e-3,
-                cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6, cfg->agent_radius + 1e-6, cell > 0 ? cell : 32.0, gh->g);
+                cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6, cfg->agent_radius + 1e-6, cell > 0 ? cell : 16.0, gh->g);
     *out = gh;
     return CAT_OK;
 }
