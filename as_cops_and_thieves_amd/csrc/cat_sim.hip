@@ -519,7 +519,9 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
     const double cone_m = p.gate ? 1e-6 : r2 + 1e-6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    // ---- per-agent setup: grid cell, walls the origin is "inside" (alpha = 0 rule), cones of the other agents
+    // ---- per-agent setup: grid cell, walls the origin is "inside" (alpha = 0 rule), cones of the other agents.
+    //      Results stay in registers (lane i / lane i*A+j) and are broadcast with readlane: no LDS round trips.
+    int my_cell = -1, my_near0 = -1, my_near1 = -1, my_dk0 = 0, my_dcnt = 0;
     for (int i = 0; i < A; i++) {
         const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];
         const int cx = (int)floor((ax - gd.x0) * gd.inv_cell), cy = (int)floor((ay - gd.y0) * gd.inv_cell);
@@ -547,7 +549,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                 }
             }
         }
-        if (lane == 0) { L.acell[i] = cellid; L.anear[2 * i] = near0; L.anear[2 * i + 1] = near1; }
+        if (lane == i) { my_cell = cellid; my_near0 = near0; my_near1 = near1; }
     }
     if (lane < A * A) {   // lane = (i, j): cone of agent j's circle seen from agent i
         const int i = lane / A, j = lane % A;
@@ -564,9 +566,8 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                 ray_cone(p, ax, ay, l - cone_m, b - cone_m, r + cone_m, t + cone_m, R, k0, cnt);
             }
         }
-        L.dk0[lane] = k0; L.dcnt[lane] = cnt | (near << 16);
+        my_dk0 = k0; my_dcnt = cnt | (near << 16);
     }
-    wave_sync();
     PHASE(pc, 4);
 
     unsigned my_dmin = 0x10000u;  // lane i keeps agent i's minimum wanted-class distance
@@ -575,7 +576,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
     auto fetch_row = [&](int c) -> unsigned long long {
         if (c >= nchunks) return 0ull;
         const int ci = c / cpa, ck = (c % cpa) * kLanes + lane;
-        const int cell = uni(L.acell[ci]);
+        const int cell = __builtin_amdgcn_readlane(my_cell, ci);
         if (cell < 0 || ck >= R) return 0ull;
         return G(p.grid_rows)[gd.row_base + (size_t)cell * R + ck];
     };
@@ -586,7 +587,10 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         const unsigned long long row = row_next;
         row_next = fetch_row(c + 1);
         const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];  // fresh body.position (entity.py:186)
-        const int cellid = uni(L.acell[i]), near0 = uni(L.anear[2 * i]), near1 = uni(L.anear[2 * i + 1]);
+        const int cellid = __builtin_amdgcn_readlane(my_cell, i), near0 = __builtin_amdgcn_readlane(my_near0, i),
+                  near1 = __builtin_amdgcn_readlane(my_near1, i);
+        unsigned dnear_mask = 0;   // other agents whose circle the origin is "inside" (alpha = 0 rule)
+        for (int j = 0; j < A; j++) dnear_mask |= (unsigned)((__builtin_amdgcn_readlane(my_dcnt, i * A + j) >> 16) & 1) << j;
         const bool is_cop = i < p.n_cops;
         const unsigned want = is_cop ? CAT_THIEF : CAT_COP;
         if (kb == 0) dmin = 0x10000u;
@@ -602,7 +606,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
             if (active)
                 for (int j = 0; j < A; j++) {
                     if (j == i) continue;
-                    const int dc = uni(L.dcnt[i * A + j]) & 0xFFFF, dk = uni(L.dk0[i * A + j]);
+                    const int dc = __builtin_amdgcn_readlane(my_dcnt, i * A + j) & 0xFFFF, dk = __builtin_amdgcn_readlane(my_dk0, i * A + j);
                     int rel = k - dk; if (rel < 0) rel += R;
                     if (rel < dc) dynmask |= 1u << j;
                 }
@@ -660,7 +664,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                                 else { int f; poly_query_feat(L, id, p.wall_r, ax, ay, cbx, cby, r2, alpha, f); feat = f < 0 ? 0 : f; }
                             } else {
                                 const int j = id - S;
-                                if ((L.dcnt[i * A + j] >> 16) & 1) { alpha = 0.0; feat = kFeatNear; }
+                                if ((dnear_mask >> j) & 1u) { alpha = 0.0; feat = kFeatNear; }
                                 else {
                                     SegInfo ci = {0, 1.0, cbx, cby};
                                     circle_segment_query(L.tc[2 * j], L.tc[2 * j + 1], p.rc, ax, ay, cbx, cby, r2, ci);
