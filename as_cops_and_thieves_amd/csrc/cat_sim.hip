@@ -858,12 +858,12 @@ __device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, d
     for (int i = 0; i < count; i++) {   // scalar scan, index order
         const double di = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(dd) >> 32), i) << 32) |
                                                (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(dd), i));
-        if (di < bestd) { bestd = di; best = i; }
-        if (inside) {
-            const double si = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(sep) >> 32), i) << 32) |
-                                                   (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(sep), i));
-            if (si > maxsep) { maxsep = si; sepi = i; }
-        }
+        const double si = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(sep) >> 32), i) << 32) |
+                                               (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(sep), i));
+        // GJK only terminates on an edge the origin lies in front of: at a vertex shared with an edge the
+        // centre is behind, the tie goes to the other edge (whose normal gives d > 0: vertex/vertex branch)
+        if (si > 0.0 && di < bestd) { bestd = di; best = i; }
+        if (si > maxsep) { maxsep = si; sepi = i; }
     }
     if (inside) {  // centre inside the hull: least-penetration plane (deviation D4)
         const double *pl = L.planes + 8 * (first + sepi);

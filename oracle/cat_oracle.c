@@ -484,7 +484,10 @@ static int circle_poly_contact(const cato_map *m, int sh, double rp, double cx, 
         double ht = 0.5 * t; /* [CP LerpT] */
         double px = ax_ * (0.5 - ht) + bx_ * (0.5 + ht), py = ay_ * (0.5 - ht) + by_ * (0.5 + ht);
         double dd = px * px + py * py;
-        if (dd < bestd) { bestd = dd; best = i; bt = t; bpx = px; bpy = py; }
+        /* GJK only terminates on an edge the origin lies in front of ([CP GJKRecurse] flips / leaves an
+           edge with the origin behind it): at a vertex shared with such an edge the tie goes to the
+           other one, whose normal gives d > 0 and hence the vertex/vertex branch below. */
+        if (sep > 0.0 && dd < bestd) { bestd = dd; best = i; bt = t; bpx = px; bpy = py; }
     }
     if (inside) { /* D4 */
         const double *pl = m->planes + 8 * (size_t)(first + sepi);

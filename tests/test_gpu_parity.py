@@ -172,3 +172,44 @@ def test_fused_step_equals_three_separate_calls():
         assert torch.equal(sa[k], sb[k]), k
     assert int(sa["reset_count"].min()) >= 2
     a.close(); b.close()
+
+
+def _arena_map(tmp_path, n_cops, n_thieves):
+    import json
+    from as_cops_and_thieves_amd.maps import Map
+    blocks = [{"type": "rect", "x": 100, "y": 100, "w": 5, "h": 400}, {"type": "rect", "x": 100, "y": 500, "w": 400, "h": 5},
+              {"type": "rect", "x": 500, "y": 100, "w": 5, "h": 405}, {"type": "rect", "x": 100, "y": 100, "w": 400, "h": 5},
+              {"type": "poly", "vs": [{"x": 250, "y": 250}, {"x": 330, "y": 270}, {"x": 350, "y": 330}, {"x": 300, "y": 370},
+                                      {"x": 240, "y": 340}, {"x": 230, "y": 290}]},
+              {"type": "poly", "vs": [{"x": 400, "y": 150}, {"x": 450, "y": 160}, {"x": 430, "y": 220}]}]
+    region = {"x": 115, "y": 115, "w": 370, "h": 370}
+    agents = [{"type": "cop", "x": 130 + 25 * i, "y": 130, "spawn_region": region} for i in range(n_cops)] + \
+             [{"type": "thief", "x": 130 + 25 * i, "y": 470, "spawn_region": region} for i in range(n_thieves)]
+    f = tmp_path / "arena.json"
+    f.write_text(json.dumps({"window": {"w_px": 640, "h_px": 640}, "canvas": {"w": 640, "h": 640},
+                             "objects": {"blocks": blocks}, "agents": agents}))
+    return Map(f).compile()
+
+
+def test_maximum_roster_eight_agents(tmp_path):
+    """A = 8 (CAT_MAX_AGENTS): 64 pair cones, 64 wall-cache slots, 28 agent pairs; crowded arena -> many contacts."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    m = _arena_map(tmp_path, 5, 3)
+    cfg = SimConfig(n_envs=24, n_cops=5, n_thieves=3, n_rays=32, max_step_count=40, seed=31)
+    stats = _run(cfg, [m], np.zeros(24, np.int32), ticks=90, rng=np.random.default_rng(0), auto_reset=True)
+    assert stats["contacts"] > 0 and stats["done"] >= 24
+
+
+def test_many_rays_not_a_multiple_of_the_wave(tmp_path):
+    """R = 200: four ray chunks per agent with a ragged tail, more items than one pass holds."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    m = _arena_map(tmp_path, 2, 1)
+    cfg = SimConfig(n_envs=8, n_cops=2, n_thieves=1, n_rays=200, max_step_count=30, seed=17)
+    _run(cfg, [m], np.zeros(8, np.int32), ticks=50, rng=np.random.default_rng(1), auto_reset=True)
+
+
+def test_gate_off_on_dense_map():
+    from as_cops_and_thieves_amd.config import SimConfig
+    m = compiled("agh-map")
+    cfg = SimConfig(n_envs=8, n_rays=90, max_step_count=40, seed=4, bbtree_gate=0)
+    _run(cfg, [m], None, ticks=30, rng=np.random.default_rng(2), spread=60.0)

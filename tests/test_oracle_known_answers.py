@@ -238,3 +238,27 @@ def test_batch_independence_and_determinism(tmp_path):
         ob = batch.step(batch.random_actions(t)); os_ = single.step(single.random_actions(t))
         assert np.array_equal(ob["obs_distance"][3], os_["obs_distance"][0]) and ob["reward"][3].tolist() == os_["reward"][0].tolist()
         batch.reset(mask=ob["terminated"].copy()); single.reset(mask=os_["terminated"].copy())
+
+
+def test_vertex_region_behind_an_adjacent_edge_is_not_a_contact(tmp_path):
+    """Regression: near a hull vertex the centre can be in front of one adjacent edge and BEHIND the
+    other; GJK never terminates on the latter, so the closest feature is the vertex itself.  (A naive
+    lowest-index tie-break once produced a phantom 13 px deep contact here.)"""
+    blocks = [{"type": "poly", "vs": [{"x": 400, "y": 150}, {"x": 450, "y": 160}, {"x": 430, "y": 220}]}]
+    cmap = make_map(tmp_path, blocks, [{"type": "cop", "x": 100, "y": 100}, {"type": "thief", "x": 100, "y": 300}])
+    s = sim_for(cmap)
+    s.reset()
+    # 12.3 px from the vertex (430, 220): far outside the 6 px contact range
+    s.set_state(pos=np.array([[[440.79346967, 226.18129671], [100.0, 300.0]]]), vel=np.array([[[10.0, -30.0], [0.0, 0.0]]]))
+    s.step(np.array([[3, 0]], np.int32))
+    st = s.get_state()
+    assert (st["wall_shape"][0] == -1).all() and st["vbias"][0, 0].tolist() == [0.0, 0.0]
+    assert st["vel"][0, 0].tolist() == [10.0, -40.0]
+    # 5.5 px from the same vertex, same side: a vertex contact whose normal points from the centre to the vertex
+    c = np.array([430.0, 220.0]) + 5.5 * np.array([0.8, 0.6])
+    s.set_state(pos=np.array([[c, [100.0, 300.0]]]), vel=np.zeros((1, 2, 2)), vbias=np.zeros((1, 2, 2)))
+    s.step(np.array([[0, 0]], np.int32))
+    st = s.get_state()
+    assert (st["wall_shape"][0, 0] == 0).sum() == 1
+    vb = st["vbias"][0, 0]                                        # pushed away from the vertex, along (0.8, 0.6)
+    assert vb[0] > 0 and vb[1] > 0 and abs(vb[1] / vb[0] - 0.75) < 0.05
