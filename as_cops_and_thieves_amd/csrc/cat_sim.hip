@@ -233,7 +233,6 @@ struct Lds {
     int *acell, *anear;     // [A], [A][2]  grid cell and "origin inside" wall ids per agent
     int *dk0, *dcnt;        // [A*A]  ray cone (start, count | near << 16) of agent j seen from agent i
     // ray-fan scratch (overlays the contact arrays: disjoint phases)
-    double *rinv;           // [64][2]   1/(b-a) of the chunk's rays
     double *itbb, *ialpha;  // [kItemCap] per item: BBTree gate value, hit alpha (2.0 = none)
     unsigned short *itm;    // [kItemCap] in: ray lane | id << 6   out: id << 6 | feature
     unsigned short *itemidx;  // [kPassJ][64] item index of (candidate position, ray lane)
@@ -378,13 +377,15 @@ __device__ __forceinline__ double poly_point_distance(const Lds &L, int sh, doub
 // ------------------------------------------------------------------ ray fan -------------------
 // Broadphase = spatial hash (GridDesc): (cell of the agent, ray index) -> ascending candidate wall ids,
 // looked up in a table built once per map; the other agents' circles are added per ray from the cone
-// their (leaf) bb subtends.  The (ray, candidate) pairs of a 64-ray chunk are packed j-major into a
-// dense item list (ballot + mbcnt, no scan), every lane evaluates one item -- the BBTree gate value
-// t_bb and the shape's own segment query (alpha + which face/vertex was hit) -- and each ray then walks
-// ITS items in index order with [CP cpSpaceSegmentQueryFirst]'s sequential rule "visit iff t_bb < best
-// alpha so far, accept iff alpha < best": identical to visiting every shape one after the other.
+// their (leaf) bb subtends.  Per pass over <= kPassJ candidate positions: the ray's own lane computes the
+// BBTree gate value t_bb of its candidate and drops it when t_bb >= the ray's best alpha so far (best only
+// decreases, so that candidate could never be visited); the surviving (ray, candidate) pairs are packed
+// j-major into a dense item list (ballot + mbcnt, no scan), every lane evaluates one item -- the shape's
+// own segment query (alpha + which face/vertex was hit) -- and each ray then walks ITS items in index
+// order with [CP cpSpaceSegmentQueryFirst]'s sequential rule "visit iff t_bb < best alpha so far, accept
+// iff alpha < best": identical to visiting every shape one after the other.
 constexpr int kFeatNear = 63;       // alpha = 0 hit ([CP cpShapeSegmentQuery] start-inside rule)
-constexpr int kItemCap = 160;       // items per pass
+constexpr int kItemCap = 160;       // live items per pass (a sweep over 160..224 x 8..12 positions was flat)
 constexpr int kPassJ = 8;           // candidate positions per ray per pass
 
 // [CP cpPolyShapeSegmentQuery] returning (alpha, feature): plane i -> i, bevel of vertex i -> count + i.
@@ -599,7 +600,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
             const bool active = k < R;
             const int kk = active ? k : 0;
             const double bx = ax + L.rayd[2 * kk], by = ay + L.rayd[2 * kk + 1];  // entity.py:191-193
-            L.rinv[2 * lane] = 1.0 / (bx - ax); L.rinv[2 * lane + 1] = 1.0 / (by - ay);
+            const double rdx = bx - ax, rdy = by - ay, rix = 1.0 / rdx, riy = 1.0 / rdy;
             // ---- candidates of this ray: walls from the spatial hash (ascending ids), then the other agents
             const int cnt_w = active ? (int)(row & 0xFF) : 0;
             unsigned dynmask = 0;
@@ -619,11 +620,10 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                 int n_items = 0, jj = jj0;
                 for (; jj < jj0 + kPassJ; jj++) {
                     const bool has = cnt > jj;
-                    const unsigned long long m = __ballot(has);
-                    const int c = __popcll(m);
-                    if (c == 0 || n_items + c > kItemCap) break;
+                    if (__ballot(has) == 0ull) break;
+                    int id = 0;
+                    double tbb = 0.0;
                     if (has) {
-                        int id;
                         if (jj < cnt_w) {
                             if (jj < 7) id = (int)((row >> (8 * (jj + 1))) & 0xFF);
                             else {   // long rows (dense maps): the full list
@@ -635,10 +635,21 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                             for (int q = jj - cnt_w; q > 0; q--) dj &= dj - 1;
                             id = S + __builtin_ctz(dj);
                         }
-                        const int t = n_items + __popcll(m & lt_mask);
-                        L.itm[t] = (unsigned short)(lane | (id << 6));
-                        L.itemidx[(jj - jj0) * kLanes + lane] = (unsigned short)t;
+                        // the BBTree gate value, by the ray's own lane.  A candidate whose t_bb is not below the
+                        // ray's best alpha NOW can never be visited (best only decreases): it gets no item.
+                        if (p.gate) tbb = bb_segment_query((id < S) ? (L.bb + 4 * id) : (L.leaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy);
                     }
+                    const bool live = has && tbb < best_a;
+                    const unsigned long long m = __ballot(live);
+                    const int c = __popcll(m);
+                    if (n_items + c > kItemCap) break;
+                    int t = 0xFFFF;
+                    if (live) {
+                        t = n_items + __popcll(m & lt_mask);
+                        L.itm[t] = (unsigned short)(lane | (id << 6));
+                        L.itbb[t] = tbb;
+                    }
+                    L.itemidx[(jj - jj0) * kLanes + lane] = (unsigned short)t;
                     n_items += c;
                 }
                 const int jj1 = jj;
@@ -652,13 +663,9 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                         const int il = d & 63, id = d >> 6;
                         const int k2 = kb + il;
                         const double cbx = ax + L.rayd[2 * k2], cby = ay + L.rayd[2 * k2 + 1];
-                        double tbb = 0.0, alpha = 2.0;   // 2.0 = no hit (never below a best alpha <= 1)
+                        double alpha = 2.0;   // 2.0 = no hit (never below a best alpha <= 1)
                         int feat = 0;
-                        if (p.gate) {
-                            const double *bbp = (id < S) ? (L.bb + 4 * id) : (L.leaf + 4 * (id - S));
-                            tbb = bb_segment_query(bbp, ax, ay, cbx - ax, cby - ay, L.rinv[2 * il], L.rinv[2 * il + 1]);
-                        }
-                        if (tbb < 1.0) {
+                        {
                             if (id < S) {
                                 if (id == near0 || id == near1) { alpha = 0.0; feat = kFeatNear; }
                                 else { int f; poly_query_feat(L, id, p.wall_r, ax, ay, cbx, cby, r2, alpha, f); feat = f < 0 ? 0 : f; }
@@ -672,15 +679,15 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                                 }
                             }
                         }
-                        L.itbb[t] = tbb; L.ialpha[t] = alpha; L.itm[t] = (unsigned short)((id << 6) | feat);
+                        L.ialpha[t] = alpha; L.itm[t] = (unsigned short)((id << 6) | feat);
                     }
                 }
                 wave_sync();
                 PHASE(pc, 6);
                 // ---- each ray walks its own items in index order
                 for (int q = jj0; q < jj1; q++) {
-                    if (cnt > q) {
-                        const int t = L.itemidx[(q - jj0) * kLanes + lane];
+                    const int t = cnt > q ? (int)L.itemidx[(q - jj0) * kLanes + lane] : 0xFFFF;
+                    if (t != 0xFFFF) {
                         const double al = L.ialpha[t];
                         if (al < best_a && L.itbb[t] < best_a) { best_a = al; best_fi = L.itm[t]; }   // t_exit == best alpha
                     }
@@ -1139,8 +1146,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     char *u = reinterpret_cast<char *>(d);
     L.conf = reinterpret_cast<double *>(u);
     L.coni = reinterpret_cast<int *>(L.conf + 12 * p.maxc);
-    L.rinv = reinterpret_cast<double *>(u);
-    L.itbb = L.rinv + 2 * kLanes;
+    L.itbb = reinterpret_cast<double *>(u);
     L.ialpha = L.itbb + kItemCap;
     L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
     L.itemidx = L.itm + kItemCap;
@@ -1653,7 +1659,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     p.lds_map_bytes = up((4 * maxS + 8 * maxP) * 8 + maxS * 4, 16) + 16 * p.R;
     const int NPs = p.NP > 0 ? p.NP : 1;
     const int phys_bytes = 12 * p.maxc * 8 + 4 * p.maxc * 4;
-    const int fan_bytes = 2 * kLanes * 8 + 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;
+    const int fan_bytes = 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;
     p.lds_union_bytes = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 8);
     int wb = p.rec_bytes + 2 * A * 8 + p.lds_union_bytes;          // record, spawn, union
     wb += (3 * A + 2 * A * A) * 4;                                 // acell, anear, dk0, dcnt
