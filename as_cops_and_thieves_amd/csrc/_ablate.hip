@@ -54,7 +54,7 @@ struct GridDesc {
     int nx, ny;
     int off_base, ent_base;     // into grid_off / grid_ent ; rows = nx*ny*R (+1); row_base == off_base - map index
     int coff_base, cent_base;   // into cgrid_off / cgrid_ent ; rows = nx*ny (+1)
-    int row_base, pad1;         // into grid_rows, in rows of Params::row_words words
+    int row_base, pad1;         // into grid_rows
 };
 
 struct Params {
@@ -78,7 +78,7 @@ struct Params {
     //   i32  wall_shape[8A] wall_age[8A] pair_age[NPs] step_count reset_count done pad
     char *state;
     int rec_bytes, rec_doubles;
-    int maxE, ang_ok, row_words;
+    int maxE, ang_ok;
     float ang0, inv_step;
     // LDS carve (bytes)
     int lds_map_bytes, lds_wave_bytes, lds_union_bytes;
@@ -243,10 +243,6 @@ struct Lds {
 
 __device__ __forceinline__ int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
-// Pin a wave-uniform value in scalar registers: a kernel parameter read through the Params pointer is
-// otherwise re-loaded (s_load + wait) at every use inside the hot loops instead of being kept.
-template <class T> __device__ __forceinline__ T launder(T v) { asm volatile("" : "+s"(v)); return v; }
-
 // ------------------------------------------------------------------ geometry ------------------
 // [CP cpBBSegmentQuery]; slab test multiplies by 1/delta (DESIGN.md deviation D3)
 __device__ __forceinline__ double bb_segment_query(const double *bb, double ax, double ay, double dx,
@@ -395,10 +391,6 @@ constexpr int kPassJ = 8;           // candidate positions per ray per pass
 // [CP cpPolyShapeSegmentQuery] returning (alpha, feature): plane i -> i, bevel of vertex i -> count + i.
 // Planes overwrite unconditionally, bevels replace on strictly smaller alpha; tracking both separately
 // and merging afterwards is the same "min, earlier wins ties".
-// Shaped for a wave whose lanes hold unrelated (ray, wall) pairs: a branch-free sweep over the hull
-// classifies every edge (can the segment cross its face line / can it touch its corner circle), then
-// the exact face test and the exact corner test each run once per surviving candidate (ascending edge
-// order, so "a later face overwrites" is kept) instead of being entered from inside every edge iteration.
 __device__ __forceinline__ void poly_query_feat(const Lds &L, int sh, double r, double ax, double ay,
                                                 double bx, double by, double r2, double &alpha, int &feat)
 {
@@ -408,54 +400,40 @@ __device__ __forceinline__ void poly_query_feat(const Lds &L, int sh, double r, 
     const float dxf = (float)(bx - ax), dyf = (float)(by - ay);
     const float thr = ((float)rsum + 0.01f) * sqrtf(dxf * dxf + dyf * dyf) * 1.00001f + 0.25f;
     const bool bevels = rsum > 0.0;
-    unsigned pm = 0u, vm = 0u;
-    const double *pl0 = L.planes + 8 * first;
-    {
-        const double *pl = pl0;
-        for (int i = 0; i < count; i++, pl += 8) {
-            const double2 n = *reinterpret_cast<const double2 *>(pl);
-            const double2 v = *reinterpret_cast<const double2 *>(pl + 2);
-            const double an = ax * n.x + ay * n.y;
-            const double d = an - pl[4] - rsum;
-            const double bn = bx * n.x + by * n.y;
-            const double den = fmax2(an - bn, DBL_MIN);
-            // !(d < 0) and !(d > den): the segment reaches the face line (d > den <=> fl(d/den) > 1)
-            pm |= (unsigned)(!(d < 0.0) && !(d > den)) << i;
-            const float ex = (float)(v.x - ax), ey = (float)(v.y - ay);
-            vm |= (unsigned)(bevels && !(fabsf(dxf * ey - dyf * ex) > thr)) << i;
-        }
-    }
     double pa = 1.0, va = 1.0;
     int pf = -1, vf = -1;
-    while (pm) {   // exact face test
-        const int i = __builtin_ctz(pm);
-        pm &= pm - 1;
-        const double *pl = pl0 + 8 * i;
+    const double *pl = L.planes + 8 * first;
+    for (int i = 0; i < count; i++, pl += 8) {
         const double2 n = *reinterpret_cast<const double2 *>(pl);
+        const double2 v = *reinterpret_cast<const double2 *>(pl + 2);
         const double2 e0 = *reinterpret_cast<const double2 *>(pl + 4);  // vn, dtMin
-        const double an = ax * n.x + ay * n.y;
-        const double d = an - e0.x - rsum;
-        const double bn = bx * n.x + by * n.y;
-        const double den = fmax2(an - bn, DBL_MIN);
-        const double t = d / den;
-        if (!(t < 0.0 || 1.0 < t)) {
-            const double ptx = ax * (1.0 - t) + bx * t, pty = ay * (1.0 - t) + by * t;
-            const double dtv = n.x * pty - n.y * ptx;
-            if (e0.y <= dtv && dtv <= pl[6]) { pa = t; pf = i; }
+        double an = ax * n.x + ay * n.y;
+        double d = an - e0.x - rsum;
+        if (!(d < 0.0)) {
+            double bn = bx * n.x + by * n.y;
+            double den = fmax2(an - bn, DBL_MIN);
+            if (!(d > den)) {  // d > den <=> fl(d/den) > 1: exact pre-reject before the division
+                double t = d / den;
+                if (!(t < 0.0 || 1.0 < t)) {
+                    double ptx = ax * (1.0 - t) + bx * t, pty = ay * (1.0 - t) + by * t;
+                    double dtv = n.x * pty - n.y * ptx;
+                    if (e0.y <= dtv && dtv <= pl[6]) { pa = t; pf = i; }
+                }
+            }
         }
-    }
-    while (vm) {   // [CP CircleSegmentQuery] on the corner circle
-        const int i = __builtin_ctz(vm);
-        vm &= vm - 1;
-        const double2 v = *reinterpret_cast<const double2 *>(pl0 + 8 * i + 2);
-        const double dax = ax - v.x, day = ay - v.y, dbx = bx - v.x, dby = by - v.y;
-        const double dada = dax * dax + day * day, dadb = dax * dbx + day * dby, dbdb = dbx * dbx + dby * dby;
-        const double qa = dada - 2.0 * dadb + dbdb;
-        const double qb = dadb - dada;
-        const double det = qb * qb - qa * (dada - rr);
-        if (det >= 0.0) {
-            const double t = (-qb - sqrt(det)) / qa;
-            if (0.0 <= t && t <= 1.0 && t < va) { va = t; vf = count + i; }
+        if (bevels) {
+            const float ex = (float)(v.x - ax), ey = (float)(v.y - ay);
+            if (!(fabsf(dxf * ey - dyf * ex) > thr)) {  // [CP CircleSegmentQuery]
+                double dax = ax - v.x, day = ay - v.y, dbx = bx - v.x, dby = by - v.y;
+                double dada = dax * dax + day * day, dadb = dax * dbx + day * dby, dbdb = dbx * dbx + dby * dby;
+                double qa = dada - 2.0 * dadb + dbdb;
+                double qb = dadb - dada;
+                double det = qb * qb - qa * (dada - rr);
+                if (det >= 0.0) {
+                    double t = (-qb - sqrt(det)) / qa;
+                    if (0.0 <= t && t <= 1.0 && t < va) { va = t; vf = count + i; }
+                }
+            }
         }
     }
     alpha = 2.0; feat = -1;
@@ -595,44 +573,26 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
 
     unsigned my_dmin = 0x10000u;  // lane i keeps agent i's minimum wanted-class distance
     const int cpa = (R + kLanes - 1) / kLanes, nchunks = A * cpa;   // chunks per agent / in total
-    // Packed spatial-hash row of (agent cell, ray), fetched one chunk ahead.  The loads are relaxed
-    // single-thread atomics so that they are issued HERE: the compiler sinks an ordinary load to its first
-    // use (the top of the next chunk), which exposes the whole memory latency once per chunk.  Every lane loads a valid address
-    // (clamped); validity is applied when the row is consumed.
-    const int rw = uni(p.row_words), row_cap = 8 * rw - 1;
-    const int gate = launder(uni(p.gate)), n_cops = launder(uni(p.n_cops));
-    const double wall_r = launder(p.wall_r), rc = launder(p.rc);
-    unsigned long long n0 = 0ull, n1 = 0ull, n2 = 0ull, n3 = 0ull;
-    auto prefetch_row = [&](int c) {
-        if (c >= nchunks) return;
+    // packed spatial-hash row of (agent cell, ray): one 8-byte load per ray, fetched one chunk ahead
+    auto fetch_row = [&](int c) -> unsigned long long {
+        if (c >= nchunks) return 0ull;
         const int ci = c / cpa, ck = (c % cpa) * kLanes + lane;
         const int cell = __builtin_amdgcn_readlane(my_cell, ci);
-        const size_t r = (cell < 0 || ck >= R) ? 0 : (size_t)cell * R + ck;
-        GAS unsigned long long *ptr = (GAS unsigned long long *)(G(p.grid_rows) + (gd.row_base + r) * rw);
-        n0 = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD);
-        if (rw > 1) n1 = __hip_atomic_load(ptr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD);
-        if (rw > 2) {
-            n2 = __hip_atomic_load(ptr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD);
-            n3 = __hip_atomic_load(ptr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD);
-        }
+        if (cell < 0 || ck >= R) return 0ull;
+        return G(p.grid_rows)[gd.row_base + (size_t)cell * R + ck];
     };
-    prefetch_row(0);
+    unsigned long long row_next = fetch_row(0);
     unsigned dmin = 0x10000u;
-    for (int c = 0; c < nchunks; c++) {
+    for (int c = 0; c < ((CAT_ABLATE & 32) ? 0 : nchunks); c++) {
         const int i = c / cpa, kb = (c % cpa) * kLanes;
-        const unsigned long long w0 = n0, w1 = n1, w2 = n2, w3 = n3;
-        prefetch_row(c + 1);
-        auto row_byte = [&](int b) -> int {   // b is wave-uniform
-            unsigned long long w = w0;
-            if (b >= 8) w = b < 16 ? w1 : (b < 24 ? w2 : w3);
-            return (int)((w >> (8 * (b & 7))) & 0xFF);
-        };
+        const unsigned long long row = row_next;
+        row_next = fetch_row(c + 1);
         const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];  // fresh body.position (entity.py:186)
         const int cellid = __builtin_amdgcn_readlane(my_cell, i), near0 = __builtin_amdgcn_readlane(my_near0, i),
                   near1 = __builtin_amdgcn_readlane(my_near1, i);
         unsigned dnear_mask = 0;   // other agents whose circle the origin is "inside" (alpha = 0 rule)
         for (int j = 0; j < A; j++) dnear_mask |= (unsigned)((__builtin_amdgcn_readlane(my_dcnt, i * A + j) >> 16) & 1) << j;
-        const bool is_cop = i < n_cops;
+        const bool is_cop = i < p.n_cops;
         const unsigned want = is_cop ? CAT_THIEF : CAT_COP;
         if (kb == 0) dmin = 0x10000u;
         {
@@ -642,14 +602,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
             const double bx = ax + L.rayd[2 * kk], by = ay + L.rayd[2 * kk + 1];  // entity.py:191-193
             const double rdx = bx - ax, rdy = by - ay, rix = 1.0 / rdx, riy = 1.0 / rdy;
             // ---- candidates of this ray: walls from the spatial hash (ascending ids), then the other agents
-            int cnt_w = (active && cellid >= 0) ? (int)(w0 & 0xFF) : 0;
-            if (__ballot(cnt_w == 255) != 0ull) {   // saturated count byte (a map with >= 255 walls along one ray)
-                if (cnt_w == 255) {
-                    const size_t r0 = (size_t)cellid * R + k;
-                    cnt_w = G(p.grid_off)[gd.off_base + r0 + 1] - G(p.grid_off)[gd.off_base + r0];
-                    asm volatile("" : "+v"(cnt_w));   // consume the loads inside this branch
-                }
-            }
+            const int cnt_w = active ? (int)(row & 0xFF) : 0;
             unsigned dynmask = 0;
             if (active)
                 for (int j = 0; j < A; j++) {
@@ -672,11 +625,10 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                     double tbb = 0.0;
                     if (has) {
                         if (jj < cnt_w) {
-                            if (jj < row_cap) id = row_byte(jj + 1);
-                            else {   // more than 31 candidate walls on one ray: the rest of the list, from the CSR arrays
+                            if (jj < 7) id = (int)((row >> (8 * (jj + 1))) & 0xFF);
+                            else {   // long rows (dense maps): the full list
                                 const size_t r0 = (size_t)cellid * R + k;
                                 id = G(p.grid_ent)[gd.ent_base + G(p.grid_off)[gd.off_base + r0] + jj];
-                                asm volatile("" : "+v"(id));   // consume the load inside this branch
                             }
                         } else {
                             unsigned dj = dynmask;
@@ -685,7 +637,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                         }
                         // the BBTree gate value, by the ray's own lane.  A candidate whose t_bb is not below the
                         // ray's best alpha NOW can never be visited (best only decreases): it gets no item.
-                        if (gate) tbb = bb_segment_query((id < S) ? (L.bb + 4 * id) : (L.leaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy);
+                        if (p.gate) tbb = bb_segment_query((id < S) ? (L.bb + 4 * id) : (L.leaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy);
                     }
                     const bool live = has && tbb < best_a;
                     const unsigned long long m = __ballot(live);
@@ -704,7 +656,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                 wave_sync();
                 PHASE(pc, 5);
                 // ---- one item per lane
-                for (int t0 = 0; t0 < n_items; t0 += kLanes) {
+                for (int t0 = 0; t0 < ((CAT_ABLATE & 64) ? 0 : n_items); t0 += kLanes) {
                     const int t = t0 + lane;
                     if (t < n_items) {
                         const int d = L.itm[t];
@@ -716,13 +668,13 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                         {
                             if (id < S) {
                                 if (id == near0 || id == near1) { alpha = 0.0; feat = kFeatNear; }
-                                else { int f; poly_query_feat(L, id, wall_r, ax, ay, cbx, cby, r2, alpha, f); feat = f < 0 ? 0 : f; }
+                                else { int f; poly_query_feat(L, id, p.wall_r, ax, ay, cbx, cby, r2, alpha, f); feat = f < 0 ? 0 : f; }
                             } else {
                                 const int j = id - S;
                                 if ((dnear_mask >> j) & 1u) { alpha = 0.0; feat = kFeatNear; }
                                 else {
                                     SegInfo ci = {0, 1.0, cbx, cby};
-                                    circle_segment_query(L.tc[2 * j], L.tc[2 * j + 1], rc, ax, ay, cbx, cby, r2, ci);
+                                    circle_segment_query(L.tc[2 * j], L.tc[2 * j + 1], p.rc, ax, ay, cbx, cby, r2, ci);
                                     if (ci.hit) alpha = ci.alpha;
                                 }
                             }
@@ -747,7 +699,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
             // ---- hit point -> f16 distance and class (entity.py:200-215, :222-241)
             unsigned d16 = d_empty, ty = CAT_EMPTY;
             int best = -1;
-            if (best_fi >= 0) {
+            if (best_fi >= 0 && !(CAT_ABLATE & 128)) {
                 best = best_fi >> 6;
                 const int f = best_fi & 63;
                 const double t = best_a;
@@ -768,7 +720,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
                     }
                 }
                 d16 = obs_distance_f16(px, py, ax, ay);
-                ty = (best < S) ? CAT_WALL : ((best - S) >= n_cops ? CAT_THIEF : CAT_COP);
+                ty = (best < S) ? CAT_WALL : ((best - S) >= p.n_cops ? CAT_THIEF : CAT_COP);
             }
             if (active) {  // observations go to LDS; one coalesced burst to HBM after the agent loop
                 const int q = i * R + k;
@@ -1275,12 +1227,12 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
     PHASE(pc, 1);
 
     const int step = uni(L.cnt[0]) + 1;                           // :372
-    const int captured = termination_captured(L, p, S, lane);     // :378
+    const int captured = (CAT_ABLATE & 2) ? 0 : termination_captured(L, p, S, lane);     // :378
     const int timeout = (!captured && step >= p.max_step) ? 1 : 0;
 
     // Entity._perform_action (entity.py:126-134), every lane computes all agents identically
     const double m_inv = 1.0 / p.mass;
-    for (int i = 0; i < A; i++) {
+    for (int i = 0; i < ((CAT_ABLATE & 1) ? 0 : A); i++) {
         int act;
         if (la.actions) act = uni(la.actions[(size_t)env * A + i]);
         else { unsigned rnd[4]; philox_env(p, env, (unsigned)la.synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
@@ -1295,14 +1247,15 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
 
     PHASE(pc, 2);
     LateOut late;
-    observe_env(L, p, la, gd, env, lane, S, 1, captured, timeout, pc, late);    // entity.py:143-144, :388-390
+    late.reward = 0; late.tp16 = 0;
+    if (!(CAT_ABLATE & 4)) observe_env(L, p, la, gd, env, lane, S, 1, captured, timeout, pc, late);    // entity.py:143-144, :388-390
     PHASE(pc, 9);
-    physics_env(L, p, S, lane, pc);                               // :392
+    if (!(CAT_ABLATE & 8)) physics_env(L, p, S, lane, pc);                               // :392
     PHASE(pc, 10);
     const unsigned char term = (unsigned char)(captured || timeout);
     if (lane == 0) { L.cnt[0] = step; L.cnt[2] = term; }
-    store_state(L, p, env, lane);
-    emit_observations(L, p, la, env, lane, 1, late);
+    if (!(CAT_ABLATE & 16)) { store_state(L, p, env, lane);
+    emit_observations(L, p, la, env, lane, 1, late); }
     if (lane == 0) {
         if (la.out.terminated) la.out.terminated[env] = term;       // entity.py:146
         if (la.out.truncated) la.out.truncated[env] = (unsigned char)timeout;  // :397
@@ -1423,9 +1376,7 @@ thread_local char g_create_err[256] = "";
 // ---------------------------------------------------------------------- spatial-hash grids ----
 struct GridHost {
     std::vector<GridDesc> desc;
-    std::vector<unsigned long long> rows;   // per (cell, ray): count | first ids (row_words 8-byte words), see finalize_rows
-    std::vector<int> rows_of;               // rows per map
-    int max_row = 0, row_words = 1;
+    std::vector<unsigned long long> rows;   // per (cell, ray): count | first 7 ids << 8.. (one 8-byte load)
     std::vector<int> off, coff;
     std::vector<unsigned char> ent, cent;
 };
@@ -1448,7 +1399,7 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
     d.inv_cell = 1.0 / cell;
     d.off_base = (int)g.off.size(); d.ent_base = (int)g.ent.size();
     d.coff_base = (int)g.coff.size(); d.cent_base = (int)g.cent.size();
-    d.row_base = 0;   // set by finalize_rows
+    d.row_base = (int)g.rows.size();
     const double eps = 1e-6;   // cell membership is decided in floating point on the device
     std::vector<int> near;     // walls within reach of the cell (prefilter)
     for (int cy = 0; cy < d.ny; cy++) {
@@ -1480,8 +1431,12 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                     const double qmin = std::fmin(std::fmin(q0, q1), std::fmin(q2, q3)), qmax = std::fmax(std::fmax(q0, q1), std::fmax(q2, q3));
                     if (qmin <= pmax && pmin <= qmax) g.ent.push_back((unsigned char)s);
                 }
-                const int n = (int)g.ent.size() - d.ent_base - g.off.back();
-                if (n > g.max_row) g.max_row = n;
+                {   // packed row: byte 0 = count (saturating at 255), bytes 1..7 = the first seven ids
+                    const int o0 = g.off.back() + d.ent_base, n = (int)g.ent.size() - o0;
+                    unsigned long long row = (unsigned long long)(n > 255 ? 255 : n);
+                    for (int q = 0; q < n && q < 7; q++) row |= (unsigned long long)g.ent[o0 + q] << (8 * (q + 1));
+                    g.rows.push_back(row);
+                }
             }
         }
     }
@@ -1490,30 +1445,6 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
     while (g.ent.size() & 3) g.ent.push_back(0);
     while (g.cent.size() & 3) g.cent.push_back(0);
     g.desc.push_back(d);
-    g.rows_of.push_back(d.nx * d.ny * R);
-}
-
-// Packed rows, one per (cell, ray): byte 0 = count (saturating at 255), then the first 8*row_words - 1
-// candidate ids; row_words (1, 2 or 4 eight-byte words) is the smallest that holds the longest list of
-// any map of the sim, lists beyond 31 ids continue in the CSR arrays (slow path on the device).
-static void finalize_rows(GridHost &g)
-{
-    g.row_words = g.max_row <= 7 ? 1 : (g.max_row <= 15 ? 2 : 4);
-    const int cap = 8 * g.row_words - 1;
-    g.rows.clear();
-    for (size_t m = 0; m < g.desc.size(); m++) {
-        GridDesc &d = g.desc[m];
-        d.row_base = (int)(g.rows.size() / g.row_words);
-        for (int r = 0; r < g.rows_of[m]; r++) {
-            const int o0 = g.off[d.off_base + r] + d.ent_base, n = g.off[d.off_base + r + 1] + d.ent_base - o0;
-            unsigned long long w[4] = {(unsigned long long)(n > 255 ? 255 : n), 0ull, 0ull, 0ull};
-            for (int q = 0; q < n && q < cap; q++) {
-                const int byte = q + 1;
-                w[byte >> 3] |= (unsigned long long)g.ent[o0 + q] << (8 * (byte & 7));
-            }
-            for (int q = 0; q < g.row_words; q++) g.rows.push_back(w[q]);
-        }
-    }
 }
 
 struct cat_sim {
@@ -1601,11 +1532,6 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         std::vector<int> iv(ni);
         memcpy(f.data(), b + 64, nf * 8);
         memcpy(iv.data(), b + 64 + nf * 8, ni * 4);
-        for (int sidx = 0; sidx < d.S; sidx++)   // feature codes (edge, count + corner) must stay below kFeatNear; circle_poly_contact: lane = edge
-            if (iv[d.S + sidx] < 1 || iv[d.S + sidx] > CAT_MAX_HULL_EDGES) {
-                snprintf(g_create_err, sizeof g_create_err, "map blob %d: wall %d has %d hull edges (1..%d supported)", m, sidx, iv[d.S + sidx], CAT_MAX_HULL_EDGES);
-                return CAT_ERR_BAD_MAP;
-            }
         d.f64_off = (int)geo_f.size();
         geo_f.insert(geo_f.end(), f.begin() + 2, f.end());  // drop window w,h
         d.i32_off = (int)geo_i.size();
@@ -1702,8 +1628,6 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         for (int m = 0; m < n_maps; m++)
             build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, p.R, tab->ray_dx, tab->ray_dy, reach, m_ray,
                         cfg->agent_radius + 1e-6, cell, s->grid);
-        finalize_rows(s->grid);
-        p.row_words = s->grid.row_words;
         TRY_ALLOC(dev_alloc(s, const_cast<GridDesc **>(&p.grids), s->grid.desc.size(), s->grid.desc.data()));
         TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.grid_rows), s->grid.rows.size(), s->grid.rows.data()));
         TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.grid_off), s->grid.off.size(), s->grid.off.data()));
@@ -1936,7 +1860,6 @@ extern "C" int cat_grid_build_host(const cat_config *cfg, const cat_tables *tab,
     gh->R = cfg->n_rays;
     build_grids(f.data() + 2, S, cfg->n_rays, tab->ray_dx, tab->ray_dy, cfg->ray_length + cfg->ray_radius + 1e-3,
                 cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6, cfg->agent_radius + 1e-6, cell > 0 ? cell : 16.0, gh->g);
-    finalize_rows(gh->g);
     *out = gh;
     return CAT_OK;
 }

@@ -24,6 +24,7 @@ extern "C" {
 #define CAT_MAX_AGENTS 8
 #define CAT_MAX_RAYS 512
 #define CAT_MAX_SHAPES 256
+#define CAT_MAX_HULL_EDGES 31   /* edges of one convex wall */
 #define CAT_WALL_CACHE 8        /* cached wall arbiters per agent */
 
 enum {

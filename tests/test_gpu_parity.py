@@ -213,3 +213,49 @@ def test_gate_off_on_dense_map():
     m = compiled("agh-map")
     cfg = SimConfig(n_envs=8, n_rays=90, max_step_count=40, seed=4, bbtree_gate=0)
     _run(cfg, [m], None, ticks=30, rng=np.random.default_rng(2), spread=60.0)
+
+
+def _picket_map(tmp_path, n_posts):
+    """A row of thin posts: a ray shot along the row has every post as a candidate (bb gate passes them all)."""
+    import json
+    from as_cops_and_thieves_amd.maps import Map
+    blocks = [{"type": "rect", "x": 60 + 9 * q, "y": 195 + (q % 2), "w": 3, "h": 12} for q in range(n_posts)]
+    blocks += [{"type": "rect", "x": 10, "y": 10, "w": 5, "h": 380}, {"type": "rect", "x": 10, "y": 390, "w": 620, "h": 5},
+               {"type": "rect", "x": 630, "y": 10, "w": 5, "h": 385}, {"type": "rect", "x": 10, "y": 10, "w": 620, "h": 5}]
+    region = {"x": 20, "y": 150, "w": 30, "h": 100}
+    agents = [{"type": "cop", "x": 30, "y": 200, "spawn_region": region},
+              {"type": "cop", "x": 35, "y": 230, "spawn_region": {"x": 20, "y": 30, "w": 600, "h": 100}},
+              {"type": "thief", "x": 40, "y": 170, "spawn_region": {"x": 20, "y": 280, "w": 600, "h": 100}}]
+    f = tmp_path / "picket.json"
+    f.write_text(json.dumps({"window": {"w_px": 640, "h_px": 400}, "canvas": {"w": 640, "h": 400},
+                             "objects": {"blocks": blocks}, "agents": agents}))
+    return Map(f).compile()
+
+
+def test_more_than_31_candidate_walls_on_one_ray(tmp_path):
+    """Packed ray-grid rows hold 31 ids; 40 posts in a row force the CSR continuation of the candidate list."""
+    import ctypes as C
+    from as_cops_and_thieves_amd.config import SimConfig
+    m = _picket_map(tmp_path, 40)
+    cfg = SimConfig(n_envs=16, n_cops=2, n_thieves=1, n_rays=64, max_step_count=60, seed=5)
+    gpu, cpu = _pair(cfg, [m], np.zeros(16, np.int32))
+    out = (C.c_int * 256)()
+    from as_cops_and_thieves_amd import _native as nat
+    longest = max(nat.lib().cat_debug_grid_lookup(gpu._h, 0, 30.0, 201.0, k, out, 256) for k in range(64))
+    gpu.close()
+    assert longest > 31, longest
+    _run(cfg, [m], np.zeros(16, np.int32), ticks=70, rng=np.random.default_rng(3), auto_reset=True)
+
+
+def test_wall_with_too_many_hull_edges_is_rejected(tmp_path):
+    import json, math
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.maps import Map
+    from as_cops_and_thieves_amd.sim import CatSim
+    vs = [{"x": 300 + 100 * math.cos(2 * math.pi * q / 40), "y": 300 + 100 * math.sin(2 * math.pi * q / 40)} for q in range(40)]
+    agents = [{"type": "cop", "x": 50, "y": 50}, {"type": "cop", "x": 80, "y": 50}, {"type": "thief", "x": 50, "y": 550}]
+    f = tmp_path / "round.json"
+    f.write_text(json.dumps({"window": {"w_px": 640, "h_px": 640}, "canvas": {"w": 640, "h": 640},
+                             "objects": {"blocks": [{"type": "poly", "vs": vs}]}, "agents": agents}))
+    with pytest.raises(RuntimeError, match="hull edges"):
+        CatSim(SimConfig(n_envs=4, n_rays=16), [Map(f).compile()], device="cuda:0")
