@@ -86,11 +86,21 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.exit(f"bench.py --gpus {args.gpus} needs {args.gpus} ranks: launch with python -m torch.distributed.run "
+                 f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ... "
+                 f"(WORLD_SIZE is {world})")
+    rehearse = os.environ.get("CAT_BENCH_REHEARSE") == "1"   # flow check on a 1-GPU box: gloo, ranks share the GPU
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            local_rank %= torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -133,7 +143,7 @@ def main() -> None:
         sim.reset_done()                                  # reset_kernel on the device-side done mask
     fence()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, device=dev)   # the slowest rank bounds the whole-job rate
+    elapsed = max_over_ranks(elapsed, device=None if rehearse else dev)   # the slowest rank bounds the whole-job rate
     tick_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     episodes = int(sim.get_state()["reset_count"].sum().item())
 
@@ -165,7 +175,7 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "path is FP64-VALU/LDS bound, not HBM bound (SURVEY 8d); fraction reported as contracted"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(cfg, cmap)
         print(json.dumps(line), flush=True)
     if world > 1:
