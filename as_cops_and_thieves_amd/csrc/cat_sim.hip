@@ -1256,6 +1256,13 @@ __device__ __forceinline__ void store_state(const Lds &L, const Params &p, int e
     for (int o = lane; o < p.rec_bytes / 16; o += kLanes) dst[o] = src[o];
 }
 
+#ifdef CAT_WAVE_SPREAD
+__device__ unsigned long long g_wave_t[2 * 65536];   // per env slot: wave start / end clock of the last launch
+extern "C" int cat_debug_spread(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_t), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -1;
+}
+#endif
 // BaseEnv.step (base_env.py:354-413), one wave per env
 __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *__restrict__ pp, const LaunchArgs la)
 {
@@ -1263,6 +1270,9 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
     extern __shared__ __align__(16) char smem[];
     const int wave = uni(threadIdx.x / kLanes), lane = threadIdx.x % kLanes;
     PhaseClock pc;
+#ifdef CAT_WAVE_SPREAD
+    const unsigned long long spread_t0 = __builtin_readcyclecounter();
+#endif
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
     const GridDesc gd = p.grids[p.block_map[blockIdx.x]];
     stage_map(p, smem, md);
@@ -1308,6 +1318,9 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
         if (la.out.truncated) la.out.truncated[env] = (unsigned char)timeout;  // :397
         if (la.out.winner) la.out.winner[env] = (signed char)(captured ? 0 : (timeout ? 1 : -1));  // :399-406
     }
+#ifdef CAT_WAVE_SPREAD
+    if (lane == 0 && env < 65536) { g_wave_t[2 * env] = spread_t0; g_wave_t[2 * env + 1] = __builtin_readcyclecounter(); }
+#endif
     PHASE(pc, 11);
     pc.flush(lane);
 }

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Diagnostic: the same 4096 envs stepped as 1, 2 or 4 sub-batches on separate HIP streams (one handle each)."""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
