@@ -30,7 +30,7 @@
 
 namespace {
 
-constexpr int kWaves = 4;           // envs per workgroup
+constexpr int kMaxWaves = 16;       // waves (= env slots) per workgroup: Params::wpb in {1, 2, 4, 8, 16}
 constexpr int kLanes = 64;          // gfx950 wavefront
 constexpr int kK = CAT_WALL_CACHE;
 constexpr int kMaxJ = 16;          // per-ray candidate list length per pass
@@ -71,7 +71,7 @@ struct Params {
     const unsigned long long *grid_rows;
     const int *grid_off, *cgrid_off;
     const unsigned char *grid_ent, *cgrid_ent;
-    const int *work_env;    // [n_blocks*kWaves] env slot or -1
+    const int *work_env;    // [n_blocks*wpb] env slot or -1
     const int *block_map;   // [n_blocks]
     // Env state: one contiguous record per env slot (so a wave moves it with 16-byte lanes):
     //   f64  pos[2A] vel[2A] vbias[2A] tc[2A] leaf[4A] wall_jn[8A] pair_jn[NPs]
@@ -81,7 +81,8 @@ struct Params {
     int maxE, ang_ok, row_words;
     float ang0, inv_step;
     // LDS carve (bytes)
-    int lds_map_bytes, lds_wave_bytes, lds_union_bytes;
+    int lds_map_bytes, lds_env_bytes, lds_union_bytes;
+    int wpb;                // waves per workgroup (= blockDim.x / 64)
 };
 
 // Diagnostic build only (-DCAT_PHASE_TIMING): per-phase shader-clock totals, summed over waves
@@ -219,8 +220,12 @@ struct Lds {
     const double *bb;      // [S][4]            workgroup-shared
     const double *planes;  // [P][8]
     const int *fc;         // [S] first plane | plane count << 16
-    // per-wave scratch
+    // per env slot
     double *pos, *vel, *vb, *tc, *leaf;  // [A][2] x4, [A][4]
+    const double *fpos, *ftc, *fleaf;    // what the ray fan reads: the tick-start snapshot of pos / tc / leaf
+    unsigned *dmin;   // [A] minimum wanted-class distance (f16 bits), 0x10000 = none seen
+    int *flags;       // step, captured, timeout, -
+    int *ctrl;        // workgroup: [wpb][4] = chunks claimed, chunks done, published, env id
     double *wjn, *pjn;
     int *wsh, *wag, *pag;
     int *cnt;       // step_count, reset_count, done, pad (tail of the state record)
@@ -238,7 +243,7 @@ struct Lds {
     unsigned short *itemidx;  // [kPassJ][64] item index of (candidate position, ray lane)
     unsigned short *od;  // [A*R]
     unsigned char *ot;   // [A*R]
-    double *spawn;  // [A][2]
+    double *spawn;  // [8A] reset: spawn points [2A]; every kernel: pre-step pos[2A] tc[2A] leaf[4A] snapshot
 };
 
 __device__ __forceinline__ int align_up(int x, int a) { return (x + a - 1) / a * a; }
@@ -528,25 +533,22 @@ __device__ __forceinline__ void ray_cone(const Params &p, double ax, double ay, 
     cnt = c;
 }
 
-// Entity.get_observation for every agent of the env + rewards + team-shared channels.
-// rew_mode: 0 = no rewards (reset), 1 = step (captured/timeout known).
+// Entity.get_observation for every agent of the env (entity.py:159-220) is split into a per-env setup
+// (agent_setup), independent 64-ray chunks (fan_chunk: any wave of the workgroup may run one) and the
+// rewards (rewards_and_positions).  All three read the tick-start snapshot L.fpos / L.ftc / L.fleaf.
 struct LateOut { float reward; unsigned tp16; };   // per-lane values stored at the very end of the kernel
 
-__device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, int env, int lane,
-                            int S, int rew_mode, int captured, int timeout, PhaseClock &pc, LateOut &late)
+// Per-agent setup, published in the env area: grid cell, walls the origin is "inside" (alpha = 0 rule),
+// cones of the other agents' circles; resets the per-agent minimum wanted-class distance.
+__device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, int lane)
 {
     const int A = p.A, R = p.R;
     const double r2 = p.ray_radius;
-    const unsigned d_empty = f64_to_f16(p.ray_length);  // np.full(R, ray_length, float16) entity.py:200
     const double reach = p.ray_length + r2 + 1e-6;
     const double cone_m = p.gate ? 1e-6 : r2 + 1e-6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-    // ---- per-agent setup: grid cell, walls the origin is "inside" (alpha = 0 rule), cones of the other agents.
-    //      Results stay in registers (lane i / lane i*A+j) and are broadcast with readlane: no LDS round trips.
     int my_cell = -1, my_near0 = -1, my_near1 = -1, my_dk0 = 0, my_dcnt = 0;
     for (int i = 0; i < A; i++) {
-        const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];
+        const double ax = L.fpos[2 * i], ay = L.fpos[2 * i + 1];
         const int cx = (int)floor((ax - gd.x0) * gd.inv_cell), cy = (int)floor((ay - gd.y0) * gd.inv_cell);
         int cellid = -1, near0 = -1, near1 = -1;
         if (cx >= 0 && cy >= 0 && cx < gd.nx && cy < gd.ny) {
@@ -578,10 +580,10 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         const int i = lane / A, j = lane % A;
         int k0 = 0, cnt = 0, near = 0;
         if (i != j) {
-            const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];
-            const double tcx = L.tc[2 * j], tcy = L.tc[2 * j + 1];
+            const double ax = L.fpos[2 * i], ay = L.fpos[2 * i + 1];
+            const double tcx = L.ftc[2 * j], tcy = L.ftc[2 * j + 1];
             double l, b, r, t;
-            if (p.gate) { l = L.leaf[4 * j]; b = L.leaf[4 * j + 1]; r = L.leaf[4 * j + 2]; t = L.leaf[4 * j + 3]; }
+            if (p.gate) { l = L.fleaf[4 * j]; b = L.fleaf[4 * j + 1]; r = L.fleaf[4 * j + 2]; t = L.fleaf[4 * j + 3]; }
             else { l = tcx - p.rc; b = tcy - p.rc; r = tcx + p.rc; t = tcy + p.rc; }
             if ((l <= ax + reach) && (ax - reach <= r) && (b <= ay + reach) && (ay - reach <= t)) {
                 const double ex = ax - tcx, ey = ay - tcy;
@@ -591,206 +593,217 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         }
         my_dk0 = k0; my_dcnt = cnt | (near << 16);
     }
-    PHASE(pc, 4);
+    if (lane < A) { L.acell[lane] = my_cell; L.anear[2 * lane] = my_near0; L.anear[2 * lane + 1] = my_near1; L.dmin[lane] = 0x10000u; }
+    if (lane < A * A) { L.dk0[lane] = my_dk0; L.dcnt[lane] = my_dcnt; }
+    wave_sync();
+}
 
-    unsigned my_dmin = 0x10000u;  // lane i keeps agent i's minimum wanted-class distance
-    const int cpa = (R + kLanes - 1) / kLanes, nchunks = A * cpa;   // chunks per agent / in total
-    // Packed spatial-hash row of (agent cell, ray), fetched one chunk ahead.  The loads are relaxed
-    // single-thread atomics so that they are issued HERE: the compiler sinks an ordinary load to its first
-    // use (the top of the next chunk), which exposes the whole memory latency once per chunk.  Every lane loads a valid address
-    // (clamped); validity is applied when the row is consumed.
+// One 64-ray chunk c (agent c / cpa, rays (c % cpa) * 64 ...) of the env whose env area is in L; the scratch
+// union of L is the calling wave's.  Writes the chunk's observations to the env's output staging.
+__device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, int env, int lane,
+                          int S, int rew_mode, int c, PhaseClock &pc)
+{
+    const int A = p.A, R = p.R;
+    const double r2 = p.ray_radius;
+    const unsigned d_empty = f64_to_f16(p.ray_length);  // np.full(R, ray_length, float16) entity.py:200
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int cpa = (R + kLanes - 1) / kLanes;   // chunks per agent
     const int rw = uni(p.row_words), row_cap = 8 * rw - 1;
     const int gate = launder(uni(p.gate)), n_cops = launder(uni(p.n_cops));
     const double wall_r = launder(p.wall_r), rc = launder(p.rc);
-    unsigned long long n0 = 0ull, n1 = 0ull, n2 = 0ull, n3 = 0ull;
-    auto prefetch_row = [&](int c) {
-        if (c >= nchunks) return;
-        const int ci = c / cpa, ck = (c % cpa) * kLanes + lane;
-        const int cell = __builtin_amdgcn_readlane(my_cell, ci);
+    // the setup of agent_setup, back into registers (lane i / lane i*A+j), broadcast with readlane below
+    const int my_cell = lane < A ? L.acell[lane] : -1, my_near0 = lane < A ? L.anear[2 * lane] : -1,
+              my_near1 = lane < A ? L.anear[2 * lane + 1] : -1;
+    const int my_dk0 = lane < A * A ? L.dk0[lane] : 0, my_dcnt = lane < A * A ? L.dcnt[lane] : 0;
+    const int i = c / cpa, kb = (c % cpa) * kLanes;
+    // packed spatial-hash row of (agent cell, ray): every lane loads a valid address (clamped), validity is
+    // applied when the row is consumed
+    unsigned long long w0, w1 = 0ull, w2 = 0ull, w3 = 0ull;
+    {
+        const int ck = kb + lane;
+        const int cell = __builtin_amdgcn_readlane(my_cell, i);
         const size_t r = (cell < 0 || ck >= R) ? 0 : (size_t)cell * R + ck;
-        GAS unsigned long long *ptr = (GAS unsigned long long *)(G(p.grid_rows) + (gd.row_base + r) * rw);
-        n0 = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD);
-        if (rw > 1) n1 = __hip_atomic_load(ptr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD);
-        if (rw > 2) {
-            n2 = __hip_atomic_load(ptr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD);
-            n3 = __hip_atomic_load(ptr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SINGLETHREAD);
-        }
+        GAS const unsigned long long *ptr = G(p.grid_rows) + (gd.row_base + r) * rw;
+        w0 = ptr[0];
+        if (rw > 1) w1 = ptr[1];
+        if (rw > 2) { w2 = ptr[2]; w3 = ptr[3]; }
+    }
+    auto row_byte = [&](int b) -> int {   // b is wave-uniform
+        unsigned long long w = w0;
+        if (b >= 8) w = b < 16 ? w1 : (b < 24 ? w2 : w3);
+        return (int)((w >> (8 * (b & 7))) & 0xFF);
     };
-    prefetch_row(0);
+    const double ax = L.fpos[2 * i], ay = L.fpos[2 * i + 1];  // fresh body.position (entity.py:186)
+    const int cellid = __builtin_amdgcn_readlane(my_cell, i), near0 = __builtin_amdgcn_readlane(my_near0, i),
+              near1 = __builtin_amdgcn_readlane(my_near1, i);
+    unsigned dnear_mask = 0;   // other agents whose circle the origin is "inside" (alpha = 0 rule)
+    for (int j = 0; j < A; j++) dnear_mask |= (unsigned)((__builtin_amdgcn_readlane(my_dcnt, i * A + j) >> 16) & 1) << j;
+    const bool is_cop = i < n_cops;
+    const unsigned want = is_cop ? CAT_THIEF : CAT_COP;
     unsigned dmin = 0x10000u;
-    for (int c = 0; c < nchunks; c++) {
-        const int i = c / cpa, kb = (c % cpa) * kLanes;
-        const unsigned long long w0 = n0, w1 = n1, w2 = n2, w3 = n3;
-        prefetch_row(c + 1);
-        auto row_byte = [&](int b) -> int {   // b is wave-uniform
-            unsigned long long w = w0;
-            if (b >= 8) w = b < 16 ? w1 : (b < 24 ? w2 : w3);
-            return (int)((w >> (8 * (b & 7))) & 0xFF);
-        };
-        const double ax = L.pos[2 * i], ay = L.pos[2 * i + 1];  // fresh body.position (entity.py:186)
-        const int cellid = __builtin_amdgcn_readlane(my_cell, i), near0 = __builtin_amdgcn_readlane(my_near0, i),
-                  near1 = __builtin_amdgcn_readlane(my_near1, i);
-        unsigned dnear_mask = 0;   // other agents whose circle the origin is "inside" (alpha = 0 rule)
-        for (int j = 0; j < A; j++) dnear_mask |= (unsigned)((__builtin_amdgcn_readlane(my_dcnt, i * A + j) >> 16) & 1) << j;
-        const bool is_cop = i < n_cops;
-        const unsigned want = is_cop ? CAT_THIEF : CAT_COP;
-        if (kb == 0) dmin = 0x10000u;
-        {
-            const int k = kb + lane;
-            const bool active = k < R;
-            const int kk = active ? k : 0;
-            const double bx = ax + L.rayd[2 * kk], by = ay + L.rayd[2 * kk + 1];  // entity.py:191-193
-            const double rdx = bx - ax, rdy = by - ay, rix = 1.0 / rdx, riy = 1.0 / rdy;
-            // ---- candidates of this ray: walls from the spatial hash (ascending ids), then the other agents
-            int cnt_w = (active && cellid >= 0) ? (int)(w0 & 0xFF) : 0;
-            if (__ballot(cnt_w == 255) != 0ull) {   // saturated count byte (a map with >= 255 walls along one ray)
-                if (cnt_w == 255) {
-                    const size_t r0 = (size_t)cellid * R + k;
-                    cnt_w = G(p.grid_off)[gd.off_base + r0 + 1] - G(p.grid_off)[gd.off_base + r0];
-                    asm volatile("" : "+v"(cnt_w));   // consume the loads inside this branch
-                }
+    {
+        const int k = kb + lane;
+        const bool active = k < R;
+        const int kk = active ? k : 0;
+        const double bx = ax + L.rayd[2 * kk], by = ay + L.rayd[2 * kk + 1];  // entity.py:191-193
+        const double rdx = bx - ax, rdy = by - ay, rix = 1.0 / rdx, riy = 1.0 / rdy;
+        // ---- candidates of this ray: walls from the spatial hash (ascending ids), then the other agents
+        int cnt_w = (active && cellid >= 0) ? (int)(w0 & 0xFF) : 0;
+        if (__ballot(cnt_w == 255) != 0ull) {   // saturated count byte (a map with >= 255 walls along one ray)
+            if (cnt_w == 255) {
+                const size_t r0 = (size_t)cellid * R + k;
+                cnt_w = G(p.grid_off)[gd.off_base + r0 + 1] - G(p.grid_off)[gd.off_base + r0];
+                asm volatile("" : "+v"(cnt_w));   // consume the loads inside this branch
             }
-            unsigned dynmask = 0;
-            if (active)
-                for (int j = 0; j < A; j++) {
-                    if (j == i) continue;
-                    const int dc = __builtin_amdgcn_readlane(my_dcnt, i * A + j) & 0xFFFF, dk = __builtin_amdgcn_readlane(my_dk0, i * A + j);
-                    int rel = k - dk; if (rel < 0) rel += R;
-                    if (rel < dc) dynmask |= 1u << j;
-                }
-            const int cnt = cnt_w + __popc(dynmask);
-            double best_a = 1.0;
-            int best_fi = -1;   // id << 6 | feature of the accepted item
-            int jj0 = 0;
-            while (__ballot(cnt > jj0) != 0ull) {
-                // ---- pack the items (ray, jj) for jj in [jj0, jj1) j-major
-                int n_items = 0, jj = jj0;
-                for (; jj < jj0 + kPassJ; jj++) {
-                    const bool has = cnt > jj;
-                    if (__ballot(has) == 0ull) break;
-                    int id = 0;
-                    double tbb = 0.0;
-                    if (has) {
-                        if (jj < cnt_w) {
-                            if (jj < row_cap) id = row_byte(jj + 1);
-                            else {   // more than 31 candidate walls on one ray: the rest of the list, from the CSR arrays
-                                const size_t r0 = (size_t)cellid * R + k;
-                                id = G(p.grid_ent)[gd.ent_base + G(p.grid_off)[gd.off_base + r0] + jj];
-                                asm volatile("" : "+v"(id));   // consume the load inside this branch
-                            }
-                        } else {
-                            unsigned dj = dynmask;
-                            for (int q = jj - cnt_w; q > 0; q--) dj &= dj - 1;
-                            id = S + __builtin_ctz(dj);
-                        }
-                        // the BBTree gate value, by the ray's own lane.  A candidate whose t_bb is not below the
-                        // ray's best alpha NOW can never be visited (best only decreases): it gets no item.
-                        if (gate) tbb = bb_segment_query((id < S) ? (L.bb + 4 * id) : (L.leaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy);
-                    }
-                    const bool live = has && tbb < best_a;
-                    const unsigned long long m = __ballot(live);
-                    const int c = __popcll(m);
-                    if (n_items + c > kItemCap) break;
-                    int t = 0xFFFF;
-                    if (live) {
-                        t = n_items + __popcll(m & lt_mask);
-                        L.itm[t] = (unsigned short)(lane | (id << 6));
-                        L.itbb[t] = tbb;
-                    }
-                    L.itemidx[(jj - jj0) * kLanes + lane] = (unsigned short)t;
-                    n_items += c;
-                }
-                const int jj1 = jj;
-                wave_sync();
-                PHASE(pc, 5);
-                // ---- one item per lane
-                for (int t0 = 0; t0 < n_items; t0 += kLanes) {
-                    const int t = t0 + lane;
-                    if (t < n_items) {
-                        const int d = L.itm[t];
-                        const int il = d & 63, id = d >> 6;
-                        const int k2 = kb + il;
-                        const double cbx = ax + L.rayd[2 * k2], cby = ay + L.rayd[2 * k2 + 1];
-                        double alpha = 2.0;   // 2.0 = no hit (never below a best alpha <= 1)
-                        int feat = 0;
-                        {
-                            if (id < S) {
-                                if (id == near0 || id == near1) { alpha = 0.0; feat = kFeatNear; }
-                                else { int f; poly_query_feat(L, id, wall_r, ax, ay, cbx, cby, r2, alpha, f); feat = f < 0 ? 0 : f; }
-                            } else {
-                                const int j = id - S;
-                                if ((dnear_mask >> j) & 1u) { alpha = 0.0; feat = kFeatNear; }
-                                else {
-                                    SegInfo ci = {0, 1.0, cbx, cby};
-                                    circle_segment_query(L.tc[2 * j], L.tc[2 * j + 1], rc, ax, ay, cbx, cby, r2, ci);
-                                    if (ci.hit) alpha = ci.alpha;
-                                }
-                            }
-                        }
-                        L.ialpha[t] = alpha; L.itm[t] = (unsigned short)((id << 6) | feat);
-                    }
-                }
-                wave_sync();
-                PHASE(pc, 6);
-                // ---- each ray walks its own items in index order
-                for (int q = jj0; q < jj1; q++) {
-                    const int t = cnt > q ? (int)L.itemidx[(q - jj0) * kLanes + lane] : 0xFFFF;
-                    if (t != 0xFFFF) {
-                        const double al = L.ialpha[t];
-                        if (al < best_a && L.itbb[t] < best_a) { best_a = al; best_fi = L.itm[t]; }   // t_exit == best alpha
-                    }
-                }
-                wave_sync();
-                PHASE(pc, 7);
-                jj0 = jj1;
+        }
+        unsigned dynmask = 0;
+        if (active)
+            for (int j = 0; j < A; j++) {
+                if (j == i) continue;
+                const int dc = __builtin_amdgcn_readlane(my_dcnt, i * A + j) & 0xFFFF, dk = __builtin_amdgcn_readlane(my_dk0, i * A + j);
+                int rel = k - dk; if (rel < 0) rel += R;
+                if (rel < dc) dynmask |= 1u << j;
             }
-            // ---- hit point -> f16 distance and class (entity.py:200-215, :222-241)
-            unsigned d16 = d_empty, ty = CAT_EMPTY;
-            int best = -1;
-            if (best_fi >= 0) {
-                best = best_fi >> 6;
-                const int f = best_fi & 63;
-                const double t = best_a;
-                double px = bx, py = by;  // alpha = 0 hits keep the segment end as their point
-                if (f != kFeatNear) {
-                    if (best < S) {
-                        const int fc = L.fc[best], first = fc & 0xFFFF, count = fc >> 16;
-                        if (f < count) {
-                            const double2 n = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f));
-                            px = (ax * (1.0 - t) + bx * t) - n.x * r2;
-                            py = (ay * (1.0 - t) + by * t) - n.y * r2;
-                        } else {
-                            const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f - count) + 2);
-                            circle_hit_point(v.x, v.y, ax, ay, bx, by, t, r2, px, py);
+        const int cnt = cnt_w + __popc(dynmask);
+        double best_a = 1.0;
+        int best_fi = -1;   // id << 6 | feature of the accepted item
+        int jj0 = 0;
+        while (__ballot(cnt > jj0) != 0ull) {
+            // ---- pack the items (ray, jj) for jj in [jj0, jj1) j-major
+            int n_items = 0, jj = jj0;
+            for (; jj < jj0 + kPassJ; jj++) {
+                const bool has = cnt > jj;
+                if (__ballot(has) == 0ull) break;
+                int id = 0;
+                double tbb = 0.0;
+                if (has) {
+                    if (jj < cnt_w) {
+                        if (jj < row_cap) id = row_byte(jj + 1);
+                        else {   // more than 31 candidate walls on one ray: the rest of the list, from the CSR arrays
+                            const size_t r0 = (size_t)cellid * R + k;
+                            id = G(p.grid_ent)[gd.ent_base + G(p.grid_off)[gd.off_base + r0] + jj];
+                            asm volatile("" : "+v"(id));   // consume the load inside this branch
                         }
                     } else {
-                        circle_hit_point(L.tc[2 * (best - S)], L.tc[2 * (best - S) + 1], ax, ay, bx, by, t, r2, px, py);
+                        unsigned dj = dynmask;
+                        for (int q = jj - cnt_w; q > 0; q--) dj &= dj - 1;
+                        id = S + __builtin_ctz(dj);
                     }
+                    // the BBTree gate value, by the ray's own lane.  A candidate whose t_bb is not below the
+                    // ray's best alpha NOW can never be visited (best only decreases): it gets no item.
+                    if (gate) tbb = bb_segment_query((id < S) ? (L.bb + 4 * id) : (L.fleaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy);
                 }
-                d16 = obs_distance_f16(px, py, ax, ay);
-                ty = (best < S) ? CAT_WALL : ((best - S) >= n_cops ? CAT_THIEF : CAT_COP);
+                const bool live = has && tbb < best_a;
+                const unsigned long long m = __ballot(live);
+                const int c = __popcll(m);
+                if (n_items + c > kItemCap) break;
+                int t = 0xFFFF;
+                if (live) {
+                    t = n_items + __popcll(m & lt_mask);
+                    L.itm[t] = (unsigned short)(lane | (id << 6));
+                    L.itbb[t] = tbb;
+                }
+                L.itemidx[(jj - jj0) * kLanes + lane] = (unsigned short)t;
+                n_items += c;
             }
-            if (active) {  // observations go to LDS; one coalesced burst to HBM after the agent loop
-                const int q = i * R + k;
-                L.od[q] = (unsigned short)d16;
-                L.ot[q] = (unsigned char)ty;
-                if (la.out.hit_shape) la.out.hit_shape[(size_t)env * A * R + q] = best;  // parity/debug only
-                if (ty == want && d16 < dmin) dmin = d16;  // non-negative f16: bit order = value order
+            const int jj1 = jj;
+            wave_sync();
+            PHASE(pc, 5);
+            // ---- one item per lane
+            for (int t0 = 0; t0 < n_items; t0 += kLanes) {
+                const int t = t0 + lane;
+                if (t < n_items) {
+                    const int d = L.itm[t];
+                    const int il = d & 63, id = d >> 6;
+                    const int k2 = kb + il;
+                    const double cbx = ax + L.rayd[2 * k2], cby = ay + L.rayd[2 * k2 + 1];
+                    double alpha = 2.0;   // 2.0 = no hit (never below a best alpha <= 1)
+                    int feat = 0;
+                    {
+                        if (id < S) {
+                            if (id == near0 || id == near1) { alpha = 0.0; feat = kFeatNear; }
+                            else { int f; poly_query_feat(L, id, wall_r, ax, ay, cbx, cby, r2, alpha, f); feat = f < 0 ? 0 : f; }
+                        } else {
+                            const int j = id - S;
+                            if ((dnear_mask >> j) & 1u) { alpha = 0.0; feat = kFeatNear; }
+                            else {
+                                SegInfo ci = {0, 1.0, cbx, cby};
+                                circle_segment_query(L.ftc[2 * j], L.ftc[2 * j + 1], rc, ax, ay, cbx, cby, r2, ci);
+                                if (ci.hit) alpha = ci.alpha;
+                            }
+                        }
+                    }
+                    L.ialpha[t] = alpha; L.itm[t] = (unsigned short)((id << 6) | feat);
+                }
             }
-            PHASE(pc, 8);
+            wave_sync();
+            PHASE(pc, 6);
+            // ---- each ray walks its own items in index order
+            for (int q = jj0; q < jj1; q++) {
+                const int t = cnt > q ? (int)L.itemidx[(q - jj0) * kLanes + lane] : 0xFFFF;
+                if (t != 0xFFFF) {
+                    const double al = L.ialpha[t];
+                    if (al < best_a && L.itbb[t] < best_a) { best_a = al; best_fi = L.itm[t]; }   // t_exit == best alpha
+                }
+            }
+            wave_sync();
+            PHASE(pc, 7);
+            jj0 = jj1;
         }
-        if (rew_mode && kb + kLanes >= R) {  // last chunk of agent i: min over the wave; LUT lookups are issued together below
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                unsigned o2 = (unsigned)__shfl_xor((int)dmin, off);
-                dmin = o2 < dmin ? o2 : dmin;
+        // ---- hit point -> f16 distance and class (entity.py:200-215, :222-241)
+        unsigned d16 = d_empty, ty = CAT_EMPTY;
+        int best = -1;
+        if (best_fi >= 0) {
+            best = best_fi >> 6;
+            const int f = best_fi & 63;
+            const double t = best_a;
+            double px = bx, py = by;  // alpha = 0 hits keep the segment end as their point
+            if (f != kFeatNear) {
+                if (best < S) {
+                    const int fc = L.fc[best], first = fc & 0xFFFF, count = fc >> 16;
+                    if (f < count) {
+                        const double2 n = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f));
+                        px = (ax * (1.0 - t) + bx * t) - n.x * r2;
+                        py = (ay * (1.0 - t) + by * t) - n.y * r2;
+                    } else {
+                        const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f - count) + 2);
+                        circle_hit_point(v.x, v.y, ax, ay, bx, by, t, r2, px, py);
+                    }
+                } else {
+                    circle_hit_point(L.ftc[2 * (best - S)], L.ftc[2 * (best - S) + 1], ax, ay, bx, by, t, r2, px, py);
+                }
             }
-            if (lane == i) my_dmin = dmin;
+            d16 = obs_distance_f16(px, py, ax, ay);
+            ty = (best < S) ? CAT_WALL : ((best - S) >= n_cops ? CAT_THIEF : CAT_COP);
         }
+        if (active) {  // observations go to LDS; one coalesced burst to HBM after the agent loop
+            const int q = i * R + k;
+            L.od[q] = (unsigned short)d16;
+            L.ot[q] = (unsigned char)ty;
+            if (la.out.hit_shape) la.out.hit_shape[(size_t)env * A * R + q] = best;  // parity/debug only
+            if (ty == want && d16 < dmin) dmin = d16;  // non-negative f16: bit order = value order
+        }
+        PHASE(pc, 8);
     }
-    wave_sync();
+    if (rew_mode) {  // min over the wave, then into the agent's slot (other chunks of the agent may run on other waves)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned o2 = (unsigned)__shfl_xor((int)dmin, off);
+            dmin = o2 < dmin ? o2 : dmin;
+        }
+        if (lane == 0 && dmin < 0x10000u) __hip_atomic_fetch_min(&L.dmin[i], dmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// Cop.reward / Thief.reward (cop.py:49-75, thief.py:48-69; lane = agent) from the per-agent minimum the
+// chunks left in L.dmin, and the f16 team positions (observation_spaces.py:92-95: positions BEFORE Space.step).
+__device__ void rewards_and_positions(const Lds &L, const Params &p, const LaunchArgs &la, int lane, int rew_mode,
+                                      int captured, int timeout, LateOut &late)
+{
+    const int A = p.A;
     late.reward = 0.0f; late.tp16 = 0;
-    if (rew_mode && lane < A && la.out.reward) {  // cop.py:49-75 / thief.py:48-69, lane = agent
+    if (rew_mode && lane < A && la.out.reward) {
+        const unsigned my_dmin = L.dmin[lane];
         const bool is_cop = lane < p.n_cops;
         float r;
         if (captured) r = is_cop ? 1.0f : -1.0f;
@@ -799,7 +812,7 @@ __device__ void observe_env(const Lds &L, const Params &p, const LaunchArgs &la,
         else r = is_cop ? (float)(-0.02 - 0.02) : (float)0.15;
         late.reward = r;
     }
-    if (lane < 2 * A) late.tp16 = f64_to_f16(L.pos[lane]);  // observation_spaces.py:92-95 (positions BEFORE Space.step)
+    if (lane < 2 * A) late.tp16 = f64_to_f16(L.fpos[lane]);
 }
 
 // LDS -> HBM copy of n bytes with the widest store both sides allow (LDS side is 16-byte aligned)
@@ -1170,15 +1183,20 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
 }
 
 // ------------------------------------------------------------------ kernel plumbing -----------
-__device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc &md, int wave)
+// LDS of a workgroup: [map | ctrl | wpb env areas | wpb scratch unions].  An env area holds the state
+// record, the snapshot, the per-agent ray-fan setup and the output staging of ONE env slot; a scratch
+// union belongs to ONE wave (contact arrays / ray-fan items: disjoint phases).  A wave working on
+// another slot's ray chunks combines that slot's env area with its own scratch.
+__device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc &md, int slot, int wave)
 {
     Lds L;
-    const int S = md.S, P = md.P;
+    const int S = md.S, P = md.P, W = p.wpb;
     L.bb = reinterpret_cast<const double *>(smem);
     L.planes = L.bb + 4 * S;
     L.fc = reinterpret_cast<const int *>(L.planes + 8 * P);
     L.rayd = reinterpret_cast<const double *>(smem + p.lds_map_bytes - 16 * p.R);
-    char *w = smem + p.lds_map_bytes + wave * p.lds_wave_bytes;
+    L.ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+    char *w = smem + p.lds_map_bytes + 16 * W + slot * p.lds_env_bytes;
     const int A = p.A, R = p.R, NPs = p.NP > 0 ? p.NP : 1;
     L.rec = w;
     double *d = reinterpret_cast<double *>(w);
@@ -1189,17 +1207,11 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
         L.wsh = ri; ri += A * kK; L.wag = ri; ri += A * kK; L.pag = ri; ri += NPs; L.cnt = ri;
     }
     d = reinterpret_cast<double *>(w + p.rec_bytes);
-    L.spawn = d; d += 2 * A;
-    // union: contact arrays (physics) / ray-fan scratch
-    char *u = reinterpret_cast<char *>(d);
-    L.conf = reinterpret_cast<double *>(u);
-    L.coni = reinterpret_cast<int *>(L.conf + 12 * p.maxc);
-    L.itbb = reinterpret_cast<double *>(u);
-    L.ialpha = L.itbb + kItemCap;
-    L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
-    L.itemidx = L.itm + kItemCap;
-    int *iv = reinterpret_cast<int *>(u + p.lds_union_bytes);
+    L.spawn = d; L.fpos = d; L.ftc = d + 2 * A; L.fleaf = d + 4 * A; d += 8 * A;
+    int *iv = reinterpret_cast<int *>(d);
     L.acell = iv; iv += A; L.anear = iv; iv += 2 * A; L.dk0 = iv; iv += A * A; L.dcnt = iv; iv += A * A;
+    L.dmin = reinterpret_cast<unsigned *>(iv); iv += A;
+    L.flags = iv; iv += 4;
     {   // output staging, every array 16-byte aligned
         char *o = reinterpret_cast<char *>(iv);
         o = w + align_up((int)(o - w), 16);
@@ -1208,6 +1220,14 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
         L.sd = reinterpret_cast<unsigned short *>(o); o += align_up(2 * R * 2, 16);
         L.st = reinterpret_cast<unsigned char *>(o);
     }
+    // union: contact arrays (physics) / ray-fan scratch
+    char *u = smem + p.lds_map_bytes + 16 * W + W * p.lds_env_bytes + wave * p.lds_union_bytes;
+    L.conf = reinterpret_cast<double *>(u);
+    L.coni = reinterpret_cast<int *>(L.conf + 12 * p.maxc);
+    L.itbb = reinterpret_cast<double *>(u);
+    L.ialpha = L.itbb + kItemCap;
+    L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
+    L.itemidx = L.itm + kItemCap;
     return L;
 }
 
@@ -1263,11 +1283,102 @@ extern "C" int cat_debug_spread(unsigned long long *out, int n)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_t), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -1;
 }
 #endif
-// BaseEnv.step (base_env.py:354-413), one wave per env
-__global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *__restrict__ pp, const LaunchArgs la)
+// Workgroup control words (LDS, L.ctrl): one wave (lane 0) operates, the result is broadcast.
+__device__ __forceinline__ int ctrl_load(const int *w, int lane)
+{
+    int v = 0;
+    if (lane == 0) v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    v = uni(v);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return v;
+}
+__device__ __forceinline__ int ctrl_add(int *w, int lane)   // fetch-and-increment, release + acquire
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    v = uni(v);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return v;
+}
+__device__ __forceinline__ void copy_snapshot(const Lds &L, int A, int lane)
+{   // record order is pos vel vb tc leaf: the snapshot keeps pos[2A] tc[2A] leaf[4A]
+    if (lane < 8 * A) L.spawn[lane] = L.pos[lane + (lane < 2 * A ? 0 : 4 * A)];
+    wave_sync();
+}
+
+__device__ __forceinline__ void publish_slot(const Lds &L, int wave, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&L.ctrl[4 * wave + 2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The shared part of both kernels.  Units of a published slot, claimed in order by any wave of the workgroup:
+// ray chunks 0 .. nchunks-1, then (tick only) Space.step.  A wave starts with its own slot.  The wave that completes
+// a slot's last unit writes that slot back: rewards, state record and outputs to HBM.
+// L.flags of a slot = {step_count to store, captured, timeout, reset_count to store or -1}.
+__device__ __forceinline__ void run_units(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
+                                          const GridDesc &gd, char *smem, int wave, int lane, int tick, PhaseClock &pc)
+{
+    const int W = p.wpb, S = md.S;
+    const int nchunks = p.A * ((p.R + kLanes - 1) / kLanes), last_unit = tick ? nchunks : nchunks - 1;
+    unsigned fin_mask = 0u;
+    bool pending = true;
+    while (pending) {
+        pending = false;
+        for (int k = 0; k < W; k++) {
+            const int slot = uni((wave + k) % W);
+            const int e_s = ctrl_load(&L.ctrl[4 * slot + 3], lane);
+            if (e_s < 0 || ctrl_load(&L.ctrl[4 * slot + 0], lane) > last_unit) continue;
+            if (!ctrl_load(&L.ctrl[4 * slot + 2], lane)) { pending = true; continue; }   // its owner has not published yet
+            const Lds Ls = carve(p, smem, md, slot, wave);
+            for (;;) {
+                const int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
+                if (c > last_unit) break;
+                if (c < nchunks) fan_chunk(Ls, p, la, gd, e_s, lane, S, tick, c, pc);   // entity.py:143-144, base_env.py:388-390 / :334-344
+                else {
+                    PHASE(pc, 9);
+                    physics_env(Ls, p, S, lane, pc);                                // base_env.py:392
+                    PHASE(pc, 10);
+                }
+                if (ctrl_add(&L.ctrl[4 * slot + 1], lane) == last_unit) { fin_mask |= 1u << slot; break; }   // no unit is left unclaimed
+            }
+        }
+        if (pending) __builtin_amdgcn_s_sleep(8);
+    }
+    while (fin_mask) {
+        const int slot = uni(__builtin_ctz(fin_mask));
+        fin_mask &= fin_mask - 1;
+        const Lds Ls = carve(p, smem, md, slot, wave);
+        const int e_s = uni(L.ctrl[4 * slot + 3]);
+        const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
+        LateOut late;
+        rewards_and_positions(Ls, p, la, lane, tick, captured2, timeout2, late);
+        const unsigned char term = (unsigned char)(captured2 || timeout2);
+        if (lane == 0) { Ls.cnt[0] = step2; Ls.cnt[2] = term; if (rcount >= 0) Ls.cnt[1] = rcount; }   // base_env.py:350
+        store_state(Ls, p, e_s, lane);
+        emit_observations(Ls, p, la, e_s, lane, tick, late);
+        if (tick && lane == 0) {
+            if (la.out.terminated) la.out.terminated[e_s] = term;       // entity.py:146
+            if (la.out.truncated) la.out.truncated[e_s] = (unsigned char)timeout2;  // :397
+            if (la.out.winner) la.out.winner[e_s] = (signed char)(captured2 ? 0 : (timeout2 ? 1 : -1));  // :399-406
+        }
+    }
+}
+
+// BaseEnv.step (base_env.py:354-413).  A workgroup of wpb waves advances wpb envs sharing one map.  Wave w OWNS
+// env slot w: it loads the state, decides termination, applies the actions, publishes the ray-fan setup, runs the
+// physics and writes everything back.  The ray fan itself is cut into 64-ray chunks that ANY wave of the
+// workgroup may claim (LDS counters): the SIMD arbitrates oldest-first, so with one env per wave the youngest
+// waves of a SIMD finish far behind the oldest and the launch ends on a lone wave; with shared chunks the
+// waves that get ahead take the others' chunks and the workgroup finishes together.  The observations read
+// the tick-start snapshot (pos, circle caches, leaf bbs) and Space.step reads nothing the observations
+// produce, so the owner's physics may overlap the chunks other waves run for it.
+__global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *__restrict__ pp, const LaunchArgs la)
 {
     const Params &p = *pp;
     extern __shared__ __align__(16) char smem[];
+    const int W = uni((int)(blockDim.x / kLanes));
     const int wave = uni(threadIdx.x / kLanes), lane = threadIdx.x % kLanes;
     PhaseClock pc;
 #ifdef CAT_WAVE_SPREAD
@@ -1275,63 +1386,64 @@ __global__ __launch_bounds__(kWaves *kLanes, 4) void tick_kernel(const Params *_
 #endif
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
     const GridDesc gd = p.grids[p.block_map[blockIdx.x]];
-    stage_map(p, smem, md);
+    const int env = uni(p.work_env[blockIdx.x * W + wave]);
+    const Lds L = carve(p, smem, md, wave, wave);
+    if (lane < 4) L.ctrl[4 * wave + lane] = lane == 3 ? env : 0;   // claimed, done, published, env id
+    stage_map(p, smem, md);   // ends with the workgroup barrier
     PHASE(pc, 0);
-    const int env = uni(p.work_env[blockIdx.x * kWaves + wave]);
-    if (env < 0) return;
-    const Lds L = carve(p, smem, md, wave);
     const int S = md.S, A = p.A;
-    load_state(L, p, env, lane);
-    PHASE(pc, 1);
+    const bool has = env >= 0;
+    int captured = 0, timeout = 0, step = 0;
+    if (has) {
+        load_state(L, p, env, lane);
+        PHASE(pc, 1);
+        step = uni(L.cnt[0]) + 1;                                 // :372
+        captured = termination_captured(L, p, S, lane);           // :378
+        timeout = (!captured && step >= p.max_step) ? 1 : 0;
+        copy_snapshot(L, A, lane);
 
-    const int step = uni(L.cnt[0]) + 1;                           // :372
-    const int captured = termination_captured(L, p, S, lane);     // :378
-    const int timeout = (!captured && step >= p.max_step) ? 1 : 0;
-
-    // Entity._perform_action (entity.py:126-134), every lane computes all agents identically
-    const double m_inv = 1.0 / p.mass;
-    for (int i = 0; i < A; i++) {
-        int act;
-        if (la.actions) act = uni(la.actions[(size_t)env * A + i]);
-        else { unsigned rnd[4]; philox_env(p, env, (unsigned)la.synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
-        double jx = 0.0, jy = 0.0;
-        if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
-        else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
-        double vx = L.vel[2 * i] + jx * m_inv, vy = L.vel[2 * i + 1] + jy * m_inv;
-        double len = sqrt(vx * vx + vy * vy);
-        if (len > p.max_speed) { vx = vx / len * p.max_speed; vy = vy / len * p.max_speed; }
-        L.vel[2 * i] = vx; L.vel[2 * i + 1] = vy;
+        // Entity._perform_action (entity.py:126-134), every lane computes all agents identically
+        const double m_inv = 1.0 / p.mass;
+        for (int i = 0; i < A; i++) {
+            int act;
+            if (la.actions) act = uni(la.actions[(size_t)env * A + i]);
+            else { unsigned rnd[4]; philox_env(p, env, (unsigned)la.synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
+            double jx = 0.0, jy = 0.0;
+            if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
+            else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
+            double vx = L.vel[2 * i] + jx * m_inv, vy = L.vel[2 * i + 1] + jy * m_inv;
+            double len = sqrt(vx * vx + vy * vy);
+            if (len > p.max_speed) { vx = vx / len * p.max_speed; vy = vy / len * p.max_speed; }
+            L.vel[2 * i] = vx; L.vel[2 * i + 1] = vy;
+        }
+        PHASE(pc, 2);
+        agent_setup(L, p, gd, lane);                              // entity.py:143-144, :388-390 (setup part)
+        PHASE(pc, 4);
     }
 
-    PHASE(pc, 2);
-    LateOut late;
-    observe_env(L, p, la, gd, env, lane, S, 1, captured, timeout, pc, late);    // entity.py:143-144, :388-390
-    PHASE(pc, 9);
-    physics_env(L, p, S, lane, pc);                               // :392
-    PHASE(pc, 10);
-    const unsigned char term = (unsigned char)(captured || timeout);
-    if (lane == 0) { L.cnt[0] = step; L.cnt[2] = term; }
-    store_state(L, p, env, lane);
-    emit_observations(L, p, la, env, lane, 1, late);
-    if (lane == 0) {
-        if (la.out.terminated) la.out.terminated[env] = term;       // entity.py:146
-        if (la.out.truncated) la.out.truncated[env] = (unsigned char)timeout;  // :397
-        if (la.out.winner) la.out.winner[env] = (signed char)(captured ? 0 : (timeout ? 1 : -1));  // :399-406
+    if (has) {
+        if (lane == 0) { L.flags[0] = step; L.flags[1] = captured; L.flags[2] = timeout; L.flags[3] = -1; }
+        publish_slot(L, wave, lane);
     }
+    run_units(L, p, la, md, gd, smem, wave, lane, 1, pc);
 #ifdef CAT_WAVE_SPREAD
-    if (lane == 0 && env < 65536) { g_wave_t[2 * env] = spread_t0; g_wave_t[2 * env + 1] = __builtin_readcyclecounter(); }
+    if (lane == 0 && env >= 0 && env < 65536) { g_wave_t[2 * env] = spread_t0; g_wave_t[2 * env + 1] = __builtin_readcyclecounter(); }
 #endif
     PHASE(pc, 11);
     pc.flush(lane);
 }
 
+__device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
+                                           const GridDesc &gd, int env, int wave, int lane);
+
 // BaseEnv.reset (base_env.py:286-352) for masked envs
-__global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__restrict__ pp, const LaunchArgs la)
+__global__ __launch_bounds__(kMaxWaves *kLanes) void reset_kernel(const Params *__restrict__ pp, const LaunchArgs la)
 {
     const Params &p = *pp;
     extern __shared__ __align__(16) char smem[];
+    const int W = uni((int)(blockDim.x / kLanes));
     const int wave = uni(threadIdx.x / kLanes), lane = threadIdx.x % kLanes;
-    const int env = uni(p.work_env[blockIdx.x * kWaves + wave]);
+    const int env = uni(p.work_env[blockIdx.x * W + wave]);
     bool need = env >= 0;
     if (need) {
         if (la.use_done_mask)
@@ -1341,9 +1453,18 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__r
     if (!__syncthreads_or(need ? 1 : 0)) return;  // nothing to reset in this workgroup: skip the map staging
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
     const GridDesc gd = p.grids[p.block_map[blockIdx.x]];
-    stage_map(p, smem, md);
-    if (!need) return;
-    const Lds L = carve(p, smem, md, wave);
+    const Lds L = carve(p, smem, md, wave, wave);
+    if (lane < 4) L.ctrl[4 * wave + lane] = lane == 3 ? (need ? env : -1) : 0;   // claimed, done, published, env id
+    stage_map(p, smem, md);   // ends with the workgroup barrier
+    PhaseClock pc;
+    if (need) reset_slot(L, p, la, md, gd, env, wave, lane);
+    run_units(L, p, la, md, gd, smem, wave, lane, 0, pc);   // waves with nothing to reset help with the others' ray chunks
+}
+
+// Spawn sampling + Entity.reset of one env, then its ray-fan setup is published (reset_kernel).
+__device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
+                                           const GridDesc &gd, int env, int wave, int lane)
+{
     const int S = md.S, A = p.A;
     load_state(L, p, env, lane);
     const unsigned rc = (unsigned)(uni(L.cnt[1]) + 1);
@@ -1397,12 +1518,11 @@ __global__ __launch_bounds__(kWaves *kLanes) void reset_kernel(const Params *__r
         L.pos[2 * i] = L.spawn[2 * i]; L.pos[2 * i + 1] = L.spawn[2 * i + 1];
         L.vel[2 * i] = 0.0; L.vel[2 * i + 1] = 0.0;
     }
-    PhaseClock pc;
-    LateOut late;
-    observe_env(L, p, la, gd, env, lane, S, 0, 0, 0, pc, late);   // :334-344
-    if (lane == 0) { L.cnt[0] = 0; L.cnt[1] = (int)rc; L.cnt[2] = 0; }  // :350
-    store_state(L, p, env, lane);
-    emit_observations(L, p, la, env, lane, 0, late);
+    wave_sync();
+    copy_snapshot(L, A, lane);   // fresh positions, stale circle caches and leaf bbs (Q1); overwrites the spawn points
+    agent_setup(L, p, gd, lane);                                  // :334-344 (setup part)
+    if (lane == 0) { L.flags[0] = 0; L.flags[1] = 0; L.flags[2] = 0; L.flags[3] = (int)rc; }  // :350
+    publish_slot(L, wave, lane);
 }
 
 __global__ void random_actions_kernel(const Params *__restrict__ pp, unsigned long long tick, int *actions)
@@ -1529,12 +1649,35 @@ static void finalize_rows(GridHost &g)
     }
 }
 
+// LDS carve sizes (must match carve())
+struct LdsSizes {
+    int map, env, uni;
+    size_t total(int wpb) const { return (size_t)map + 16 * (size_t)wpb + (size_t)wpb * ((size_t)env + (size_t)uni); }
+};
+static LdsSizes lds_sizes(int A, int R, int maxS, int maxP)
+{
+    auto up = [](int x, int a) { return (x + a - 1) / a * a; };
+    const int NP = A * (A - 1) / 2, NPs = NP > 0 ? NP : 1, maxc = A * kK + NP;
+    LdsSizes z;
+    z.map = up((4 * maxS + 8 * maxP) * 8 + maxS * 4, 16) + 16 * R;
+    const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
+    const int fan_bytes = 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;
+    z.uni = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 16);
+    const int rec_doubles = 12 * A + A * kK + NPs, ni = 2 * A * kK + NPs + 4;
+    const int rec_bytes = (rec_doubles * 8 + ni * 4 + 15) / 16 * 16;
+    int eb = rec_bytes + 8 * A * 8;                                // record, spawn/snapshot
+    eb += (3 * A + 2 * A * A + A + 4) * 4;                         // acell, anear, dk0, dcnt, dmin, flags
+    eb = up(eb, 16) + up(A * R * 2, 16) + up(A * R, 16) + up(2 * R * 2, 16) + up(2 * R, 16);   // output staging
+    z.env = up(eb, 16);
+    return z;
+}
+
 struct cat_sim {
     GridHost grid;
     Params p;
     Params *dev_p;
     int device;
-    int n_blocks;
+    int n_blocks, wpb;
     size_t lds_bytes;
     std::vector<MapDesc> maps;
     std::vector<void *> allocs;
@@ -1637,17 +1780,42 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
             return CAT_ERR_BAD_SLOT_MAP;
         }
     }
+    // ---- LDS carve sizes (must match carve()) and the workgroup size
+    LdsSizes ls = lds_sizes(A, cfg->n_rays, maxS, maxP);
+    int wpb = 0;
+    {   // waves (= env slots) per workgroup.  Most resident waves per CU first (cap 16 = 4 per SIMD at <= 128 VGPRs);
+        // among equals a launch of at most two rounds takes the LARGEST workgroup (its waves share ray chunks, which
+        // removes the lone-wave tail of a single round), a longer launch the SMALLEST (workgroups of a CU overlap
+        // each other's drain).  CAT_WAVES_PER_BLOCK overrides (tuning).
+        const int cu = 256;
+        int forced = 0;
+        if (const char *e = getenv("CAT_WAVES_PER_BLOCK")) forced = atoi(e);
+        int best_score = -1;
+        for (int w = 1; w <= kMaxWaves; w *= 2) {
+            const size_t bytes = ls.total(w);
+            if (bytes > 160 * 1024) continue;
+            if (forced == w) { wpb = w; break; }
+            int resident = (int)((160 * 1024) / bytes) * w;
+            if (resident > 16) resident = 16;
+            const bool small_launch = (long long)N <= 2LL * 16 * cu;
+            if (resident > best_score || (resident == best_score && small_launch)) { best_score = resident; wpb = w; }
+        }
+        if (wpb == 0) {
+            snprintf(g_create_err, sizeof g_create_err, "LDS budget exceeded: %zu bytes for one env slot", ls.total(1));
+            return CAT_ERR_BAD_CONFIG;
+        }
+    }
     // ---- work list: workgroups are map-homogeneous; env slots grouped by map, padded with -1
     std::vector<int> work, block_map;
     for (int m = 0; m < n_maps; m++) {
         int cnt = 0;
         for (int e = 0; e < N; e++)
             if (slot[e] == m) {
-                if (cnt % kWaves == 0) block_map.push_back(m);
+                if (cnt % wpb == 0) block_map.push_back(m);
                 work.push_back(e);
                 cnt++;
             }
-        while (cnt % kWaves) { work.push_back(-1); cnt++; }
+        while (cnt % wpb) { work.push_back(-1); cnt++; }
     }
 
     cat_sim *s = new cat_sim();
@@ -1743,23 +1911,10 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         p.ang0 = (float)a0;
         p.inv_step = (float)(1.0 / step);
     }
-    // ---- LDS carve sizes (must match carve())
-    auto up = [](int x, int a) { return (x + a - 1) / a * a; };
     p.maxE = maxS + A;
-    p.lds_map_bytes = up((4 * maxS + 8 * maxP) * 8 + maxS * 4, 16) + 16 * p.R;
-    const int NPs = p.NP > 0 ? p.NP : 1;
-    const int phys_bytes = 12 * p.maxc * 8 + 4 * p.maxc * 4;
-    const int fan_bytes = 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;
-    p.lds_union_bytes = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 8);
-    int wb = p.rec_bytes + 2 * A * 8 + p.lds_union_bytes;          // record, spawn, union
-    wb += (3 * A + 2 * A * A) * 4;                                 // acell, anear, dk0, dcnt
-    wb = up(wb, 16) + up(A * p.R * 2, 16) + up(A * p.R, 16) + up(2 * p.R * 2, 16) + up(2 * p.R, 16);   // output staging
-    p.lds_wave_bytes = up(wb, 16);
-    s->lds_bytes = (size_t)p.lds_map_bytes + (size_t)kWaves * p.lds_wave_bytes;
-    if (s->lds_bytes > 160 * 1024) {
-        snprintf(s->err, sizeof s->err, "LDS budget exceeded: %zu bytes", s->lds_bytes);
-        return fail(CAT_ERR_BAD_CONFIG);
-    }
+    p.lds_map_bytes = ls.map; p.lds_env_bytes = ls.env; p.lds_union_bytes = ls.uni; p.wpb = wpb;
+    s->wpb = wpb;
+    s->lds_bytes = ls.total(wpb);
     if (s->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(tick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
@@ -1796,7 +1951,7 @@ static int launch_reset(cat_sim *s, const uint8_t *mask, const double *positions
     memset(&la, 0, sizeof la);
     if (out) la.out = *out;
     la.mask = mask; la.positions = positions; la.use_done_mask = use_done;
-    hipLaunchKernelGGL(reset_kernel, dim3(s->n_blocks), dim3(kWaves * kLanes), s->lds_bytes,
+    hipLaunchKernelGGL(reset_kernel, dim3(s->n_blocks), dim3(s->wpb * kLanes), s->lds_bytes,
                        static_cast<hipStream_t>(stream), s->dev_p, la);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
@@ -1820,7 +1975,7 @@ extern "C" int cat_step(cat_sim *s, const int32_t *actions, const cat_outputs *o
     memset(&la, 0, sizeof la);
     if (out) la.out = *out;
     la.actions = actions;
-    hipLaunchKernelGGL(tick_kernel, dim3(s->n_blocks), dim3(kWaves * kLanes), s->lds_bytes,
+    hipLaunchKernelGGL(tick_kernel, dim3(s->n_blocks), dim3(s->wpb * kLanes), s->lds_bytes,
                        static_cast<hipStream_t>(stream), s->dev_p, la);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
@@ -1835,7 +1990,7 @@ extern "C" int cat_step_fused(cat_sim *s, const int32_t *actions, uint64_t synth
     memset(&la, 0, sizeof la);
     if (out) la.out = *out;
     la.actions = actions; la.synth_tick = synth_tick;
-    hipLaunchKernelGGL(tick_kernel, dim3(s->n_blocks), dim3(kWaves * kLanes), s->lds_bytes,
+    hipLaunchKernelGGL(tick_kernel, dim3(s->n_blocks), dim3(s->wpb * kLanes), s->lds_bytes,
                        static_cast<hipStream_t>(stream), s->dev_p, la);
     HIP_TRY(s, hipGetLastError());
     // the reset stays its own (early-exiting) launch: inlining it into tick_kernel costs 40+ spilled
