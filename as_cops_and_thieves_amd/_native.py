@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
     L.cat_set_state.argtypes = [vp, vp, vp]
     L.cat_random_actions.argtypes = [vp, u64, vp, vp]
     L.cat_set_seed.argtypes = [vp, u64, vp]
+    L.cat_arm_kernel_timing.argtypes = [vp, vp, vp]
     L.cat_num_agents.argtypes = [vp]
     L.cat_num_shapes.argtypes = [vp, i32]
     L.cat_selftest_arith.argtypes = [i32, vp, vp, vp, i32, i32, vp]
@@ -104,7 +105,7 @@ def lib() -> C.CDLL:
     L.cat_grid_free_host.argtypes = [vp]
     L.cat_grid_free_host.restype = None
     for name in ("cat_create", "cat_destroy", "cat_reset", "cat_reset_done", "cat_step", "cat_step_fused", "cat_get_state",
-                 "cat_set_state", "cat_random_actions", "cat_set_seed", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup"):
+                 "cat_set_state", "cat_random_actions", "cat_set_seed", "cat_arm_kernel_timing", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -112,5 +113,5 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = ("cat_abi_version", "cat_last_error", "cat_create", "cat_destroy", "cat_reset",
                     "cat_reset_done", "cat_step", "cat_step_fused", "cat_get_state", "cat_set_state", "cat_random_actions",
-                    "cat_set_seed", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup",
+                    "cat_set_seed", "cat_arm_kernel_timing", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup",
                     "cat_grid_build_host", "cat_grid_lookup_host", "cat_grid_bytes_host", "cat_grid_free_host")

@@ -18,6 +18,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cfloat>
 #include <cmath>
@@ -94,7 +95,7 @@ struct PhaseClock {   // accumulators live in LDS (one row per wave) to keep reg
     unsigned long long *acc;
     __device__ PhaseClock()
     {
-        __shared__ unsigned long long rows[4][24];
+        __shared__ unsigned long long rows[kMaxWaves][24];
         acc = rows[threadIdx.x / 64];
         if (threadIdx.x % 64 < 24) acc[threadIdx.x % 64] = 0;
         prev = __builtin_readcyclecounter();
@@ -1283,23 +1284,19 @@ extern "C" int cat_debug_spread(unsigned long long *out, int n)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_t), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -1;
 }
 #endif
-// Workgroup control words (LDS, L.ctrl): one wave (lane 0) operates, the result is broadcast.
-__device__ __forceinline__ int ctrl_load(const int *w, int lane)
+// Workgroup control words (LDS, L.ctrl): lane 0 operates, the result is broadcast.  Relaxed accesses; the
+// callers place the workgroup-scope release / acquire fences where data is handed over.
+__device__ __forceinline__ int ctrl_peek(const int *w, int lane)
 {
     int v = 0;
     if (lane == 0) v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    v = uni(v);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    return v;
+    return uni(v);
 }
-__device__ __forceinline__ int ctrl_add(int *w, int lane)   // fetch-and-increment, release + acquire
+__device__ __forceinline__ int ctrl_add(int *w, int lane)   // fetch-and-increment
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     int v = 0;
     if (lane == 0) v = __hip_atomic_fetch_add(w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    v = uni(v);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    return v;
+    return uni(v);
 }
 __device__ __forceinline__ void copy_snapshot(const Lds &L, int A, int lane)
 {   // record order is pos vel vb tc leaf: the snapshot keeps pos[2A] tc[2A] leaf[4A]
@@ -1328,9 +1325,12 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         pending = false;
         for (int k = 0; k < W; k++) {
             const int slot = uni((wave + k) % W);
-            const int e_s = ctrl_load(&L.ctrl[4 * slot + 3], lane);
-            if (e_s < 0 || ctrl_load(&L.ctrl[4 * slot + 0], lane) > last_unit) continue;
-            if (!ctrl_load(&L.ctrl[4 * slot + 2], lane)) { pending = true; continue; }   // its owner has not published yet
+            const int e_s = uni(L.ctrl[4 * slot + 3]);   // written before the workgroup barrier
+            if (e_s < 0 || ctrl_peek(&L.ctrl[4 * slot + 0], lane) > last_unit) continue;
+            if (k > 0) {   // another wave's slot: only once its owner has published it
+                if (!ctrl_peek(&L.ctrl[4 * slot + 2], lane)) { pending = true; continue; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
             const Lds Ls = carve(p, smem, md, slot, wave);
             for (;;) {
                 const int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
@@ -1341,11 +1341,13 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
                     physics_env(Ls, p, S, lane, pc);                                // base_env.py:392
                     PHASE(pc, 10);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the unit's LDS writes, before it counts as done
                 if (ctrl_add(&L.ctrl[4 * slot + 1], lane) == last_unit) { fin_mask |= 1u << slot; break; }   // no unit is left unclaimed
             }
         }
         if (pending) __builtin_amdgcn_s_sleep(8);
     }
+    if (fin_mask) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the other waves' units of those slots
     while (fin_mask) {
         const int slot = uni(__builtin_ctz(fin_mask));
         fin_mask &= fin_mask - 1;
@@ -1678,6 +1680,7 @@ struct cat_sim {
     Params *dev_p;
     int device;
     int n_blocks, wpb;
+    hipEvent_t t_start = nullptr, t_stop = nullptr;   // cat_arm_kernel_timing
     size_t lds_bytes;
     std::vector<MapDesc> maps;
     std::vector<void *> allocs;
@@ -1967,6 +1970,27 @@ extern "C" int cat_reset_done(cat_sim *s, const cat_outputs *out, void *stream)
     return launch_reset(s, nullptr, nullptr, out, 1, stream);
 }
 
+// tick_kernel launch; when cat_arm_kernel_timing armed a pair of HIP events they are attached to THIS dispatch
+// (recorded at the kernel's own begin and end, not at the surrounding stream positions), one shot.
+static void launch_tick(cat_sim *s, const LaunchArgs &la, void *stream)
+{
+    const dim3 grid(s->n_blocks), block(s->wpb * kLanes);
+    if (s->t_start && s->t_stop) {
+        hipExtLaunchKernelGGL(tick_kernel, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->t_start, s->t_stop, 0,
+                              s->dev_p, la);
+        s->t_start = s->t_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(tick_kernel, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->dev_p, la);
+    }
+}
+
+extern "C" int cat_arm_kernel_timing(cat_sim *s, void *start_event, void *stop_event)
+{
+    if (!s || !start_event || !stop_event) return CAT_ERR_BAD_ARG;
+    s->t_start = static_cast<hipEvent_t>(start_event); s->t_stop = static_cast<hipEvent_t>(stop_event);
+    return CAT_OK;
+}
+
 extern "C" int cat_step(cat_sim *s, const int32_t *actions, const cat_outputs *out, void *stream)
 {
     if (!s || !actions) { if (s) snprintf(s->err, sizeof s->err, "cat_step: actions is NULL"); return CAT_ERR_BAD_ARG; }
@@ -1975,8 +1999,7 @@ extern "C" int cat_step(cat_sim *s, const int32_t *actions, const cat_outputs *o
     memset(&la, 0, sizeof la);
     if (out) la.out = *out;
     la.actions = actions;
-    hipLaunchKernelGGL(tick_kernel, dim3(s->n_blocks), dim3(s->wpb * kLanes), s->lds_bytes,
-                       static_cast<hipStream_t>(stream), s->dev_p, la);
+    launch_tick(s, la, stream);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -1990,8 +2013,7 @@ extern "C" int cat_step_fused(cat_sim *s, const int32_t *actions, uint64_t synth
     memset(&la, 0, sizeof la);
     if (out) la.out = *out;
     la.actions = actions; la.synth_tick = synth_tick;
-    hipLaunchKernelGGL(tick_kernel, dim3(s->n_blocks), dim3(s->wpb * kLanes), s->lds_bytes,
-                       static_cast<hipStream_t>(stream), s->dev_p, la);
+    launch_tick(s, la, stream);
     HIP_TRY(s, hipGetLastError());
     // the reset stays its own (early-exiting) launch: inlining it into tick_kernel costs 40+ spilled
     // VGPRs on the common path, far more than the ~4 us launch it would save

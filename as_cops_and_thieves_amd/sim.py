@@ -143,6 +143,10 @@ class CatSim:
         self._check(self._L.cat_random_actions(self._h, int(tick), out.data_ptr(), self._stream()), "cat_random_actions")
         return out
 
+    def arm_kernel_timing(self, start_event: int, stop_event: int) -> None:
+        """Attach two raw ``hipEvent_t`` handles to the NEXT step's tick-kernel dispatch (its own begin/end)."""
+        self._check(self._L.cat_arm_kernel_timing(self._h, start_event, stop_event), "cat_arm_kernel_timing")
+
     def set_seed(self, seed: int) -> None:
         self.cfg.seed = int(seed) & (2**64 - 1)
         self._check(self._L.cat_set_seed(self._h, self.cfg.seed, self._stream()), "cat_set_seed")

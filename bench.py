@@ -64,7 +64,32 @@ def cpu_baseline(cfg, cmap, budget_s: float = 12.0):
             "allcores": {"value": va, "cores": ca}}
 
 
-EVENT_EVERY = 8   # every 8th tick_kernel launch of the timed region is bracketed by HIP events
+EVENT_EVERY = 8   # every 8th tick_kernel launch of the timed region is timed with HIP events
+
+
+class HipEvents:
+    """Raw hipEvent_t handles from the HIP runtime torch has already loaded (torch.cuda.Event creates its
+    handle lazily and cannot be attached to a dispatch)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.lib = C.CDLL("libamdhip64.so")
+        self.lib.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.lib.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+
+    def create(self) -> int:
+        h = self.C.c_void_p()
+        if self.lib.hipEventCreate(self.C.byref(h)) != 0:
+            raise RuntimeError("hipEventCreate failed")
+        return h.value
+
+    def elapsed_ms(self, a: int, b: int) -> float:
+        ms = self.C.c_float()
+        rc = self.lib.hipEventElapsedTime(self.C.byref(ms), a, b)
+        if rc != 0:
+            raise RuntimeError(f"hipEventElapsedTime failed ({rc})")
+        return float(ms.value)
 
 
 def main() -> None:
@@ -135,35 +160,34 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # HIP events (on the stream the kernels are launched on) bracket every EVENT_EVERY-th tick_kernel launch of the
-    # timed region: bracketing all of them costs ~4 us of stream bubbles per step, 7 % of the step itself
-    sampled = range(0, args.steps, EVENT_EVERY)
-    ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in sampled}
+    # HIP events time every EVENT_EVERY-th tick_kernel launch of the timed region.  They are attached to the
+    # dispatch itself (hipExtLaunchKernelGGL start/stop events, on the stream the kernel is launched on), so the
+    # figure is the kernel's own duration, as in a rocprofv3 kernel trace; events recorded AROUND the call would
+    # add the inter-kernel dispatch gap (~5 us here).
+    hip = HipEvents()
+    ev = {k: (hip.create(), hip.create()) for k in range(0, args.steps, EVENT_EVERY)}
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
         t = args.warmup + k
         if k in ev:
-            ev[k][0].record()
-            sim.step_fused(None, tick=t, auto_reset=False)   # tick_kernel (actions: in-kernel Philox)
-            ev[k][1].record()
-            sim.reset_done()                                  # reset_kernel on the device-side done mask
-        else:
-            sim.step_fused(None, tick=t, auto_reset=True)    # the same two launches, no events
+            sim.arm_kernel_timing(*ev[k])
+        sim.step_fused(None, tick=t, auto_reset=True)   # tick_kernel (actions: in-kernel Philox) + reset_kernel on the done mask
     fence()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, device=None if rehearse else dev)   # the slowest rank bounds the whole-job rate
-    tick_ms = sum(a.elapsed_time(b) for a, b in ev.values()) / len(ev)
+    tick_ms = sum(hip.elapsed_ms(a, b) for a, b in ev.values()) / len(ev)
     episodes = int(sim.get_state()["reset_count"].sum().item())
 
     if rank == 0:
         A, R = cfg.n_agents, cfg.n_rays
         bytes_launch = algorithmic_bytes_per_env_step(A, R) * cfg.n_envs
         achieved = bytes_launch / (tick_ms * 1e-3) / 1e9
-        traffic = None   # HBM bytes per launch from the committed PMC passes of this exact workload, if any
+        traffic = valu = None   # HBM bytes per launch / VALU figures from the committed PMC passes of this exact workload, if any
         tfile = ROOT / "profiles" / "r01_traffic.json"
         if tfile.exists() and (args.map, cfg.n_envs, R, args.cops, args.thieves) == ("labyrinth", 4096, 64, 2, 1):
-            traffic = json.loads(tfile.read_text())["hbm_bytes_per_launch"]
+            prof = json.loads(tfile.read_text())
+            traffic, valu = prof["hbm_bytes_per_launch"], prof.get("valu")
         line = {
             "metric": "env-steps/sec (whole node) at 4096 parallel envs, 2v1 agents, 64-ray sensors",
             "value": world * cfg.n_envs * args.steps / elapsed,
@@ -181,7 +205,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "tick_kernel", "kernel_ms": tick_ms, "kernel_launches_timed": len(ev),
-                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "algorithmic_bytes_per_launch": bytes_launch, "valu": valu,
                          "note": "path is FP64-VALU/LDS bound, not HBM bound (SURVEY 8d); fraction reported as contracted"},
         }
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only

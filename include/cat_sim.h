@@ -156,6 +156,12 @@ int cat_random_actions(cat_sim *sim, uint64_t tick, int32_t *actions, void *stre
    used by later spawn sampling / synthetic actions. */
 int cat_set_seed(cat_sim *sim, uint64_t seed, void *stream);
 
+/* Measurement aid (bench.py's roofline leg): the NEXT cat_step / cat_step_fused launches its tick kernel with
+ * this pair of hipEvent_t attached to the dispatch itself, so hipEventElapsedTime(start, stop) is the kernel's own
+ * duration -- the figure rocprofv3 --kernel-trace reports -- without the inter-kernel dispatch gap that events
+ * recorded around the call include.  One shot.  No reference counterpart (the reference has no timers on the path). */
+int cat_arm_kernel_timing(cat_sim *sim, void *start_event, void *stop_event);
+
 /* Introspection */
 int cat_abi_version(void);
 int cat_num_agents(const cat_sim *sim);
