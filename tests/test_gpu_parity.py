@@ -259,3 +259,18 @@ def test_wall_with_too_many_hull_edges_is_rejected(tmp_path):
                              "objects": {"blocks": [{"type": "poly", "vs": vs}]}, "agents": agents}))
     with pytest.raises(RuntimeError, match="hull edges"):
         CatSim(SimConfig(n_envs=4, n_rays=16), [Map(f).compile()], device="cuda:0")
+
+
+@pytest.mark.parametrize("wpb", [1, 2, 4, 8, 16])
+def test_every_workgroup_size_gives_the_same_bits(wpb, monkeypatch):
+    """The waves of a workgroup share ray chunks and physics steps through LDS counters; the workgroup size is
+    picked per sim (16 for short launches, 4 for long ones).  Every size must reproduce the oracle, with env counts
+    that leave ragged workgroups and with two maps (workgroups are map-homogeneous)."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    monkeypatch.setenv("CAT_WAVES_PER_BLOCK", str(wpb))
+    maps = [compiled("labyrinth"), compiled("squarinth")]
+    n = 37
+    slot = (np.arange(n) % 2).astype(np.int32)
+    cfg = SimConfig(n_envs=n, n_rays=64, max_step_count=25, seed=11)
+    stats = _run(cfg, maps, slot, ticks=60, rng=np.random.default_rng(5), auto_reset=True)
+    assert stats["done"] >= n
