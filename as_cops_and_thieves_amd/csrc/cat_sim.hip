@@ -86,6 +86,30 @@ struct Params {
     int wpb;                // waves per workgroup (= blockDim.x / 64)
 };
 
+// Problem dimensions as seen by the device code: either read from the parameter block (DynDims) or compile-time
+// constants for the rosters / ray counts that are instantiated (FixDims): constant LDS offsets, unrolled agent
+// loops and far fewer live scalars (the generic kernel spills ~150 SGPRs to VGPR lanes, the fixed ones ~25).
+struct DynDims {
+    static __device__ __forceinline__ int A(const Params &p) { return p.A; }
+    static __device__ __forceinline__ int R(const Params &p) { return p.R; }
+    static __device__ __forceinline__ int n_cops(const Params &p) { return p.n_cops; }
+    static __device__ __forceinline__ int NP(const Params &p) { return p.NP; }
+    static __device__ __forceinline__ int maxc(const Params &p) { return p.maxc; }
+    static __device__ __forceinline__ int rec_bytes(const Params &p) { return p.rec_bytes; }
+    static __device__ __forceinline__ int rec_doubles(const Params &p) { return p.rec_doubles; }
+};
+template <int TA, int TR, int TC> struct FixDims {
+    static constexpr int kNP = TA * (TA - 1) / 2, kNPs = kNP > 0 ? kNP : 1;
+    static constexpr int kRecDoubles = 12 * TA + TA * CAT_WALL_CACHE + kNPs;
+    static __device__ __forceinline__ constexpr int A(const Params &) { return TA; }
+    static __device__ __forceinline__ constexpr int R(const Params &) { return TR; }
+    static __device__ __forceinline__ constexpr int n_cops(const Params &) { return TC; }
+    static __device__ __forceinline__ constexpr int NP(const Params &) { return kNP; }
+    static __device__ __forceinline__ constexpr int maxc(const Params &) { return TA * CAT_WALL_CACHE + kNP; }
+    static __device__ __forceinline__ constexpr int rec_bytes(const Params &) { return (kRecDoubles * 8 + (2 * TA * CAT_WALL_CACHE + kNPs + 4) * 4 + 15) / 16 * 16; }
+    static __device__ __forceinline__ constexpr int rec_doubles(const Params &) { return kRecDoubles; }
+};
+
 // Diagnostic build only (-DCAT_PHASE_TIMING): per-phase shader-clock totals, summed over waves
 // into a debug buffer no other kernel code reads.  The shipped library is built without it.
 #ifdef CAT_PHASE_TIMING
@@ -541,9 +565,10 @@ struct LateOut { float reward; unsigned tp16; };   // per-lane values stored at 
 
 // Per-agent setup, published in the env area: grid cell, walls the origin is "inside" (alpha = 0 rule),
 // cones of the other agents' circles; resets the per-agent minimum wanted-class distance.
+template <class D>
 __device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, int lane)
 {
-    const int A = p.A, R = p.R;
+    const int A = D::A(p), R = D::R(p);
     const double r2 = p.ray_radius;
     const double reach = p.ray_length + r2 + 1e-6;
     const double cone_m = p.gate ? 1e-6 : r2 + 1e-6;
@@ -601,16 +626,17 @@ __device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, i
 
 // One 64-ray chunk c (agent c / cpa, rays (c % cpa) * 64 ...) of the env whose env area is in L; the scratch
 // union of L is the calling wave's.  Writes the chunk's observations to the env's output staging.
+template <class D>
 __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, int env, int lane,
                           int S, int rew_mode, int c, PhaseClock &pc)
 {
-    const int A = p.A, R = p.R;
+    const int A = D::A(p), R = D::R(p);
     const double r2 = p.ray_radius;
     const unsigned d_empty = f64_to_f16(p.ray_length);  // np.full(R, ray_length, float16) entity.py:200
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int cpa = (R + kLanes - 1) / kLanes;   // chunks per agent
     const int rw = uni(p.row_words), row_cap = 8 * rw - 1;
-    const int gate = launder(uni(p.gate)), n_cops = launder(uni(p.n_cops));
+    const int gate = launder(uni(p.gate)), n_cops = launder(uni(D::n_cops(p)));
     const double wall_r = launder(p.wall_r), rc = launder(p.rc);
     // the setup of agent_setup, back into registers (lane i / lane i*A+j), broadcast with readlane below
     const int my_cell = lane < A ? L.acell[lane] : -1, my_near0 = lane < A ? L.anear[2 * lane] : -1,
@@ -798,14 +824,15 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
 
 // Cop.reward / Thief.reward (cop.py:49-75, thief.py:48-69; lane = agent) from the per-agent minimum the
 // chunks left in L.dmin, and the f16 team positions (observation_spaces.py:92-95: positions BEFORE Space.step).
+template <class D>
 __device__ void rewards_and_positions(const Lds &L, const Params &p, const LaunchArgs &la, int lane, int rew_mode,
                                       int captured, int timeout, LateOut &late)
 {
-    const int A = p.A;
+    const int A = D::A(p);
     late.reward = 0.0f; late.tp16 = 0;
     if (rew_mode && lane < A && la.out.reward) {
         const unsigned my_dmin = L.dmin[lane];
-        const bool is_cop = lane < p.n_cops;
+        const bool is_cop = lane < D::n_cops(p);
         float r;
         if (captured) r = is_cop ? 1.0f : -1.0f;
         else if (timeout) r = is_cop ? -1.0f : 1.0f;
@@ -833,17 +860,18 @@ __device__ __forceinline__ void wide_store(void *gdst, const void *lsrc, int n, 
 
 // All output stores, issued at the very end of the kernel: the compiler's s_waitcnt vmcnt(0) (in-order
 // with stores, and forced by every flat access) would otherwise stall mid-kernel on HBM write latency.
+template <class D>
 __device__ __forceinline__ void emit_observations(const Lds &L, const Params &p, const LaunchArgs &la, int env, int lane,
                                                   int rew_mode, const LateOut &late)
 {
-    const int A = p.A, R = p.R;
+    const int A = D::A(p), R = D::R(p);
     if (rew_mode && lane < A && la.out.reward) la.out.reward[(size_t)env * A + lane] = late.reward;
     if (lane < 2 * A && la.out.team_positions) la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)late.tp16;
     // get_shared_observations (observation_spaces.py:98-129): first team member, roster order,
     // with a non-EMPTY ray supplies (type, distance); else EMPTY with the last member's distance
     for (int k = lane; k < R; k += kLanes) {
         for (int team = 0; team < 2; team++) {
-            const int lo = team ? p.n_cops : 0, hi = team ? A : p.n_cops;
+            const int lo = team ? D::n_cops(p) : 0, hi = team ? A : D::n_cops(p);
             unsigned ty = CAT_EMPTY, d = 0;
             for (int i = lo; i < hi; i++)
                 if (ty == CAT_EMPTY) { ty = L.ot[i * R + k]; d = L.od[i * R + k]; }
@@ -862,9 +890,10 @@ __device__ __forceinline__ void emit_observations(const Lds &L, const Params &p,
 // ------------------------------------------------------------------ termination ---------------
 // BaseEnv._termination_criterion (base_env.py:521-554).  The wall-only LOS query is only consulted
 // for pairs inside the capture radius, so it is evaluated only there; lanes stride the walls.
+template <class D>
 __device__ int termination_captured(const Lds &L, const Params &p, int S, int lane)
 {
-    const int A = p.A, nc = p.n_cops;
+    const int A = D::A(p), nc = D::n_cops(p);
     for (int t = nc; t < A; t++) {
         for (int c = 0; c < nc; c++) {
             const double ax = L.pos[2 * t], ay = L.pos[2 * t + 1], bx = L.pos[2 * c], by = L.pos[2 * c + 1];
@@ -977,9 +1006,10 @@ __device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, d
 //                        coni[q*4 + ..] = a b first cache_index (wall: i*K+slot, pair: 1<<20 | pi)
 // [CP cpSpaceStep] for one env.  Executed wave-uniformly (every lane computes the same values and
 // stores them to the same LDS words) except the bb-overlap test, where lanes stride the walls.
+template <class D>
 __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, PhaseClock &pc)
 {
-    const int A = p.A;
+    const int A = D::A(p);
     const double dt = p.dt, rc = p.rc;
     if (lane < A) {   // lane = agent
         const int i = lane;
@@ -1056,7 +1086,7 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
     PHASE(pc, 13);
     {   // [CP CircleToCircle] candidates: lane = pair index, then the (rare) overlapping pairs in order
         bool touch = false;
-        if (lane < p.NP) {
+        if (lane < D::NP(p)) {
             int i = 0, rem = lane;
             while (rem >= A - 1 - i) { rem -= A - 1 - i; i++; }
             const int j = i + 1 + rem;
@@ -1107,7 +1137,7 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
             else L.wag[lane] = a;
         }
     }
-    if (lane < p.NP) {
+    if (lane < D::NP(p)) {
         const int page = L.pag[lane];
         if (page >= 0 && !((seen_p >> lane) & 1u)) {
             const int a = page + 1;
@@ -1188,6 +1218,7 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
 // record, the snapshot, the per-agent ray-fan setup and the output staging of ONE env slot; a scratch
 // union belongs to ONE wave (contact arrays / ray-fan items: disjoint phases).  A wave working on
 // another slot's ray chunks combines that slot's env area with its own scratch.
+template <class D>
 __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc &md, int slot, int wave)
 {
     Lds L;
@@ -1195,10 +1226,10 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.bb = reinterpret_cast<const double *>(smem);
     L.planes = L.bb + 4 * S;
     L.fc = reinterpret_cast<const int *>(L.planes + 8 * P);
-    L.rayd = reinterpret_cast<const double *>(smem + p.lds_map_bytes - 16 * p.R);
+    L.rayd = reinterpret_cast<const double *>(smem + p.lds_map_bytes - 16 * D::R(p));
     L.ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
     char *w = smem + p.lds_map_bytes + 16 * W + slot * p.lds_env_bytes;
-    const int A = p.A, R = p.R, NPs = p.NP > 0 ? p.NP : 1;
+    const int A = D::A(p), R = D::R(p), NPs = D::NP(p) > 0 ? D::NP(p) : 1;
     L.rec = w;
     double *d = reinterpret_cast<double *>(w);
     L.pos = d; d += 2 * A; L.vel = d; d += 2 * A; L.vb = d; d += 2 * A; L.tc = d; d += 2 * A;
@@ -1207,7 +1238,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
         int *ri = reinterpret_cast<int *>(d);
         L.wsh = ri; ri += A * kK; L.wag = ri; ri += A * kK; L.pag = ri; ri += NPs; L.cnt = ri;
     }
-    d = reinterpret_cast<double *>(w + p.rec_bytes);
+    d = reinterpret_cast<double *>(w + D::rec_bytes(p));
     L.spawn = d; L.fpos = d; L.ftc = d + 2 * A; L.fleaf = d + 4 * A; d += 8 * A;
     int *iv = reinterpret_cast<int *>(d);
     L.acell = iv; iv += A; L.anear = iv; iv += 2 * A; L.dk0 = iv; iv += A * A; L.dcnt = iv; iv += A * A;
@@ -1224,7 +1255,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     // union: contact arrays (physics) / ray-fan scratch
     char *u = smem + p.lds_map_bytes + 16 * W + W * p.lds_env_bytes + wave * p.lds_union_bytes;
     L.conf = reinterpret_cast<double *>(u);
-    L.coni = reinterpret_cast<int *>(L.conf + 12 * p.maxc);
+    L.coni = reinterpret_cast<int *>(L.conf + 12 * D::maxc(p));
     L.itbb = reinterpret_cast<double *>(u);
     L.ialpha = L.itbb + kItemCap;
     L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
@@ -1232,6 +1263,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     return L;
 }
 
+template <class D>
 __device__ __forceinline__ void stage_map(const Params &p, char *smem, const MapDesc &md)
 {
     const int nf = 4 * md.S + 8 * md.P;
@@ -1256,25 +1288,27 @@ __device__ __forceinline__ void stage_map(const Params &p, char *smem, const Map
     int *di = reinterpret_cast<int *>(dst + nf);
     GAS const int *si = G(p.geo_i32) + md.i32_off;
     for (int i = threadIdx.x; i < md.S; i += blockDim.x) di[i] = si[i] | (si[md.S + i] << 16);
-    double *rd = reinterpret_cast<double *>(smem + p.lds_map_bytes - 16 * p.R);
-    for (int i = threadIdx.x; i < p.R; i += blockDim.x) { rd[2 * i] = G(p.ray_dx)[i]; rd[2 * i + 1] = G(p.ray_dy)[i]; }
+    double *rd = reinterpret_cast<double *>(smem + p.lds_map_bytes - 16 * D::R(p));
+    for (int i = threadIdx.x; i < D::R(p); i += blockDim.x) { rd[2 * i] = G(p.ray_dx)[i]; rd[2 * i + 1] = G(p.ray_dy)[i]; }
     __syncthreads();
 }
 
+template <class D>
 __device__ __forceinline__ void load_state(const Lds &L, const Params &p, int env, int lane)
 {
-    GAS const u32x4 *src = (GAS const u32x4 *)(G(p.state) + (size_t)env * p.rec_bytes);
+    GAS const u32x4 *src = (GAS const u32x4 *)(G(p.state) + (size_t)env * D::rec_bytes(p));
     u32x4 *dst = reinterpret_cast<u32x4 *>(L.rec);
-    for (int o = lane; o < p.rec_bytes / 16; o += kLanes) dst[o] = src[o];
+    for (int o = lane; o < D::rec_bytes(p) / 16; o += kLanes) dst[o] = src[o];
     wave_sync();
 }
 
+template <class D>
 __device__ __forceinline__ void store_state(const Lds &L, const Params &p, int env, int lane)
 {
     wave_sync();
-    GAS u32x4 *dst = (GAS u32x4 *)(G(p.state) + (size_t)env * p.rec_bytes);
+    GAS u32x4 *dst = (GAS u32x4 *)(G(p.state) + (size_t)env * D::rec_bytes(p));
     const u32x4 *src = reinterpret_cast<const u32x4 *>(L.rec);
-    for (int o = lane; o < p.rec_bytes / 16; o += kLanes) dst[o] = src[o];
+    for (int o = lane; o < D::rec_bytes(p) / 16; o += kLanes) dst[o] = src[o];
 }
 
 #ifdef CAT_WAVE_SPREAD
@@ -1314,11 +1348,12 @@ __device__ __forceinline__ void publish_slot(const Lds &L, int wave, int lane)
 // ray chunks 0 .. nchunks-1, then (tick only) Space.step.  A wave starts with its own slot.  The wave that completes
 // a slot's last unit writes that slot back: rewards, state record and outputs to HBM.
 // L.flags of a slot = {step_count to store, captured, timeout, reset_count to store or -1}.
+template <class D>
 __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
                                           const GridDesc &gd, char *smem, int wave, int lane, int tick, PhaseClock &pc)
 {
     const int W = p.wpb, S = md.S;
-    const int nchunks = p.A * ((p.R + kLanes - 1) / kLanes), last_unit = tick ? nchunks : nchunks - 1;
+    const int nchunks = D::A(p) * ((D::R(p) + kLanes - 1) / kLanes), last_unit = tick ? nchunks : nchunks - 1;
     unsigned fin_mask = 0u;
     bool pending = true;
     while (pending) {
@@ -1331,14 +1366,14 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
                 if (!ctrl_peek(&L.ctrl[4 * slot + 2], lane)) { pending = true; continue; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            const Lds Ls = carve(p, smem, md, slot, wave);
+            const Lds Ls = carve<D>(p, smem, md, slot, wave);
             for (;;) {
                 const int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
                 if (c > last_unit) break;
-                if (c < nchunks) fan_chunk(Ls, p, la, gd, e_s, lane, S, tick, c, pc);   // entity.py:143-144, base_env.py:388-390 / :334-344
+                if (c < nchunks) fan_chunk<D>(Ls, p, la, gd, e_s, lane, S, tick, c, pc);   // entity.py:143-144, base_env.py:388-390 / :334-344
                 else {
                     PHASE(pc, 9);
-                    physics_env(Ls, p, S, lane, pc);                                // base_env.py:392
+                    physics_env<D>(Ls, p, S, lane, pc);                                // base_env.py:392
                     PHASE(pc, 10);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the unit's LDS writes, before it counts as done
@@ -1351,15 +1386,15 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
     while (fin_mask) {
         const int slot = uni(__builtin_ctz(fin_mask));
         fin_mask &= fin_mask - 1;
-        const Lds Ls = carve(p, smem, md, slot, wave);
+        const Lds Ls = carve<D>(p, smem, md, slot, wave);
         const int e_s = uni(L.ctrl[4 * slot + 3]);
         const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
         LateOut late;
-        rewards_and_positions(Ls, p, la, lane, tick, captured2, timeout2, late);
+        rewards_and_positions<D>(Ls, p, la, lane, tick, captured2, timeout2, late);
         const unsigned char term = (unsigned char)(captured2 || timeout2);
         if (lane == 0) { Ls.cnt[0] = step2; Ls.cnt[2] = term; if (rcount >= 0) Ls.cnt[1] = rcount; }   // base_env.py:350
-        store_state(Ls, p, e_s, lane);
-        emit_observations(Ls, p, la, e_s, lane, tick, late);
+        store_state<D>(Ls, p, e_s, lane);
+        emit_observations<D>(Ls, p, la, e_s, lane, tick, late);
         if (tick && lane == 0) {
             if (la.out.terminated) la.out.terminated[e_s] = term;       // entity.py:146
             if (la.out.truncated) la.out.truncated[e_s] = (unsigned char)timeout2;  // :397
@@ -1376,6 +1411,7 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
 // waves that get ahead take the others' chunks and the workgroup finishes together.  The observations read
 // the tick-start snapshot (pos, circle caches, leaf bbs) and Space.step reads nothing the observations
 // produce, so the owner's physics may overlap the chunks other waves run for it.
+template <class D>
 __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *__restrict__ pp, const LaunchArgs la)
 {
     const Params &p = *pp;
@@ -1389,18 +1425,18 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
     const GridDesc gd = p.grids[p.block_map[blockIdx.x]];
     const int env = uni(p.work_env[blockIdx.x * W + wave]);
-    const Lds L = carve(p, smem, md, wave, wave);
+    const Lds L = carve<D>(p, smem, md, wave, wave);
     if (lane < 4) L.ctrl[4 * wave + lane] = lane == 3 ? env : 0;   // claimed, done, published, env id
-    stage_map(p, smem, md);   // ends with the workgroup barrier
+    stage_map<D>(p, smem, md);   // ends with the workgroup barrier
     PHASE(pc, 0);
-    const int S = md.S, A = p.A;
+    const int S = md.S, A = D::A(p);
     const bool has = env >= 0;
     int captured = 0, timeout = 0, step = 0;
     if (has) {
-        load_state(L, p, env, lane);
+        load_state<D>(L, p, env, lane);
         PHASE(pc, 1);
         step = uni(L.cnt[0]) + 1;                                 // :372
-        captured = termination_captured(L, p, S, lane);           // :378
+        captured = termination_captured<D>(L, p, S, lane);           // :378
         timeout = (!captured && step >= p.max_step) ? 1 : 0;
         copy_snapshot(L, A, lane);
 
@@ -1419,7 +1455,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
             L.vel[2 * i] = vx; L.vel[2 * i + 1] = vy;
         }
         PHASE(pc, 2);
-        agent_setup(L, p, gd, lane);                              // entity.py:143-144, :388-390 (setup part)
+        agent_setup<D>(L, p, gd, lane);                              // entity.py:143-144, :388-390 (setup part)
         PHASE(pc, 4);
     }
 
@@ -1427,7 +1463,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
         if (lane == 0) { L.flags[0] = step; L.flags[1] = captured; L.flags[2] = timeout; L.flags[3] = -1; }
         publish_slot(L, wave, lane);
     }
-    run_units(L, p, la, md, gd, smem, wave, lane, 1, pc);
+    run_units<D>(L, p, la, md, gd, smem, wave, lane, 1, pc);
 #ifdef CAT_WAVE_SPREAD
     if (lane == 0 && env >= 0 && env < 65536) { g_wave_t[2 * env] = spread_t0; g_wave_t[2 * env + 1] = __builtin_readcyclecounter(); }
 #endif
@@ -1435,10 +1471,12 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
     pc.flush(lane);
 }
 
+template <class D>
 __device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
                                            const GridDesc &gd, int env, int wave, int lane);
 
 // BaseEnv.reset (base_env.py:286-352) for masked envs
+template <class D>
 __global__ __launch_bounds__(kMaxWaves *kLanes) void reset_kernel(const Params *__restrict__ pp, const LaunchArgs la)
 {
     const Params &p = *pp;
@@ -1449,26 +1487,27 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void reset_kernel(const Params *
     bool need = env >= 0;
     if (need) {
         if (la.use_done_mask)
-            need = ((GAS const int *)(G(p.state) + (size_t)env * p.rec_bytes + 8 * p.rec_doubles))[2 * p.A * kK + (p.NP > 0 ? p.NP : 1) + 2] != 0;
+            need = ((GAS const int *)(G(p.state) + (size_t)env * D::rec_bytes(p) + 8 * D::rec_doubles(p)))[2 * D::A(p) * kK + (D::NP(p) > 0 ? D::NP(p) : 1) + 2] != 0;
         else if (la.mask) need = la.mask[env] != 0;
     }
     if (!__syncthreads_or(need ? 1 : 0)) return;  // nothing to reset in this workgroup: skip the map staging
     const MapDesc md = p.maps[p.block_map[blockIdx.x]];
     const GridDesc gd = p.grids[p.block_map[blockIdx.x]];
-    const Lds L = carve(p, smem, md, wave, wave);
+    const Lds L = carve<D>(p, smem, md, wave, wave);
     if (lane < 4) L.ctrl[4 * wave + lane] = lane == 3 ? (need ? env : -1) : 0;   // claimed, done, published, env id
-    stage_map(p, smem, md);   // ends with the workgroup barrier
+    stage_map<D>(p, smem, md);   // ends with the workgroup barrier
     PhaseClock pc;
-    if (need) reset_slot(L, p, la, md, gd, env, wave, lane);
-    run_units(L, p, la, md, gd, smem, wave, lane, 0, pc);   // waves with nothing to reset help with the others' ray chunks
+    if (need) reset_slot<D>(L, p, la, md, gd, env, wave, lane);
+    run_units<D>(L, p, la, md, gd, smem, wave, lane, 0, pc);   // waves with nothing to reset help with the others' ray chunks
 }
 
 // Spawn sampling + Entity.reset of one env, then its ray-fan setup is published (reset_kernel).
+template <class D>
 __device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
                                            const GridDesc &gd, int env, int wave, int lane)
 {
-    const int S = md.S, A = p.A;
-    load_state(L, p, env, lane);
+    const int S = md.S, A = D::A(p);
+    load_state<D>(L, p, env, lane);
     const unsigned rc = (unsigned)(uni(L.cnt[1]) + 1);
     GAS const double *start = G(p.geo_f64) + md.f64_off + 4 * md.S + 8 * md.P;
     GAS const double *regions = start + 2 * md.A;
@@ -1522,17 +1561,18 @@ __device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const 
     }
     wave_sync();
     copy_snapshot(L, A, lane);   // fresh positions, stale circle caches and leaf bbs (Q1); overwrites the spawn points
-    agent_setup(L, p, gd, lane);                                  // :334-344 (setup part)
+    agent_setup<D>(L, p, gd, lane);                                  // :334-344 (setup part)
     if (lane == 0) { L.flags[0] = 0; L.flags[1] = 0; L.flags[2] = 0; L.flags[3] = (int)rc; }  // :350
     publish_slot(L, wave, lane);
 }
 
 __global__ void random_actions_kernel(const Params *__restrict__ pp, unsigned long long tick, int *actions)
 {
+    using D = DynDims;
     const Params &p = *pp;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.N * p.A) return;
-    const int env = idx / p.A, i = idx % p.A;
+    if (idx >= p.N * D::A(p)) return;
+    const int env = idx / D::A(p), i = idx % D::A(p);
     unsigned rnd[4];
     philox_env(p, env, (unsigned)tick, (unsigned)i, 0xAC710u, rnd);
     actions[idx] = (int)(rnd[0] & 3u);
@@ -1651,6 +1691,21 @@ static void finalize_rows(GridHost &g)
     }
 }
 
+// Kernel instantiations: fixed dimensions for the rosters / ray counts of the BASELINE configurations and of the
+// reference's defaults, the generic one for everything else (CAT_GENERIC_KERNEL=1 forces it: A/B tests).
+using KernelFn = void (*)(const Params *, const LaunchArgs);
+template <class D> static void kernels_of(KernelFn &tick, KernelFn &reset) { tick = tick_kernel<D>; reset = reset_kernel<D>; }
+static const char *select_kernels(int A, int R, int n_cops, KernelFn &tick, KernelFn &reset)
+{
+    const char *e = getenv("CAT_GENERIC_KERNEL");
+    const bool generic = e && atoi(e) != 0;
+    if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(tick, reset); return "3 agents (2 cops), 64 rays"; }
+    if (!generic && A == 3 && n_cops == 2 && R == 90) { kernels_of<FixDims<3, 90, 2>>(tick, reset); return "3 agents (2 cops), 90 rays"; }
+    if (!generic && A == 5 && n_cops == 3 && R == 64) { kernels_of<FixDims<5, 64, 3>>(tick, reset); return "5 agents (3 cops), 64 rays"; }
+    kernels_of<DynDims>(tick, reset);
+    return "generic";
+}
+
 // LDS carve sizes (must match carve())
 struct LdsSizes {
     int map, env, uni;
@@ -1680,6 +1735,8 @@ struct cat_sim {
     Params *dev_p;
     int device;
     int n_blocks, wpb;
+    KernelFn tick_fn = nullptr, reset_fn = nullptr;   // the instantiation matching (agents, rays, cops)
+    const char *kernel_variant = "";
     hipEvent_t t_start = nullptr, t_stop = nullptr;   // cat_arm_kernel_timing
     size_t lds_bytes;
     std::vector<MapDesc> maps;
@@ -1918,9 +1975,10 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     p.lds_map_bytes = ls.map; p.lds_env_bytes = ls.env; p.lds_union_bytes = ls.uni; p.wpb = wpb;
     s->wpb = wpb;
     s->lds_bytes = ls.total(wpb);
+    s->kernel_variant = select_kernels(A, p.R, p.n_cops, s->tick_fn, s->reset_fn);
     if (s->lds_bytes > 64 * 1024) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(tick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->tick_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) {
             snprintf(s->err, sizeof s->err, "cannot raise dynamic LDS limit to %zu", s->lds_bytes);
             return fail(CAT_ERR_HIP);
@@ -1954,7 +2012,7 @@ static int launch_reset(cat_sim *s, const uint8_t *mask, const double *positions
     memset(&la, 0, sizeof la);
     if (out) la.out = *out;
     la.mask = mask; la.positions = positions; la.use_done_mask = use_done;
-    hipLaunchKernelGGL(reset_kernel, dim3(s->n_blocks), dim3(s->wpb * kLanes), s->lds_bytes,
+    hipLaunchKernelGGL(s->reset_fn, dim3(s->n_blocks), dim3(s->wpb * kLanes), s->lds_bytes,
                        static_cast<hipStream_t>(stream), s->dev_p, la);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
@@ -1976,11 +2034,11 @@ static void launch_tick(cat_sim *s, const LaunchArgs &la, void *stream)
 {
     const dim3 grid(s->n_blocks), block(s->wpb * kLanes);
     if (s->t_start && s->t_stop) {
-        hipExtLaunchKernelGGL(tick_kernel, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->t_start, s->t_stop, 0,
+        hipExtLaunchKernelGGL(s->tick_fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->t_start, s->t_stop, 0,
                               s->dev_p, la);
         s->t_start = s->t_stop = nullptr;
     } else {
-        hipLaunchKernelGGL(tick_kernel, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->dev_p, la);
+        hipLaunchKernelGGL(s->tick_fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->dev_p, la);
     }
 }
 

@@ -274,3 +274,15 @@ def test_every_workgroup_size_gives_the_same_bits(wpb, monkeypatch):
     cfg = SimConfig(n_envs=n, n_rays=64, max_step_count=25, seed=11)
     stats = _run(cfg, maps, slot, ticks=60, rng=np.random.default_rng(5), auto_reset=True)
     assert stats["done"] >= n
+
+
+@pytest.mark.parametrize("name,rays,cops,thieves", [("labyrinth", 64, 2, 1), ("squarinth", 90, 2, 1), ("grandbyrinth", 64, 3, 2)])
+def test_generic_kernel_on_the_rosters_that_have_a_fixed_instantiation(name, rays, cops, thieves, monkeypatch):
+    """(agents, rays, cops) = (3, 64, 2), (3, 90, 2), (5, 64, 3) run compile-time-dimension instantiations of the
+    kernels; CAT_GENERIC_KERNEL=1 forces the generic one.  Both must reproduce the oracle (the default path is
+    what every other test in this file exercises)."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    monkeypatch.setenv("CAT_GENERIC_KERNEL", "1")
+    m = compiled(name, cops, thieves)
+    cfg = SimConfig(n_envs=24, n_cops=cops, n_thieves=thieves, n_rays=rays, max_step_count=30, seed=23)
+    _run(cfg, [m], np.zeros(24, np.int32), ticks=45, rng=np.random.default_rng(9), auto_reset=True)
