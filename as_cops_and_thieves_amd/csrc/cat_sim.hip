@@ -1,20 +1,22 @@
 // cat_sim.hip -- MI355X (gfx950 / CDNA4) batched Cops-and-Thieves env core + its C ABI.
 //
-// One 64-lane wavefront advances one env; a 256-thread workgroup = 4 envs that share one map,
-// whose geometry (hull planes + shape bbs) is staged once per workgroup in LDS.  All body state
-// and ray arithmetic is FP64 with contraction off, so results are bit-comparable with a non-FMA
-// CPU evaluation of the same formulas.  No MFMA: the path is geometry/indexing, bounded by FP64
-// VALU issue and LDS latency (DESIGN.md "Kernels").
+// A workgroup of 1..16 wavefronts advances as many envs that share one map, whose geometry (hull planes +
+// shape bbs) is staged once per workgroup in LDS.  A wavefront owns one env for the serial part of the tick;
+// the 64-ray chunks of the ray fan and the physics step are work units any wave of the workgroup may claim.
+// All body state and ray arithmetic is FP64 with contraction off, so results are bit-comparable with a non-FMA
+// CPU evaluation of the same formulas.  No MFMA: the path is geometry/indexing, bounded by FP64 VALU issue and
+// LDS latency (DESIGN.md "Kernels").
 //
 // What each device function reproduces (paths relative to the reference repo; [CP x] = the
 // Chipmunk2D 7.0.x function of that name, a third-party dependency of the reference whose
 // published algorithm is followed -- SURVEY.md appendix A):
 //   tick_kernel   BaseEnv.step                       src/environments/base_env.py:354-413
 //   reset_kernel  BaseEnv.reset                      src/environments/base_env.py:286-352
-//   observe_*     Entity.get_observation/_query_body src/agents/entity.py:159-241
-//   rewards       Cop.reward / Thief.reward          src/agents/cop.py:49-75, thief.py:48-69
-//   shared obs    get_shared_observations            src/environments/observation_spaces.py:67-131
-//   physics_step  pymunk Space.step -> [CP cpSpaceStep]  (call site base_env.py:392)
+//   agent_setup, fan_chunk   Entity.get_observation/_query_body   src/agents/entity.py:159-241
+//   rewards_and_positions    Cop.reward / Thief.reward            src/agents/cop.py:49-75, thief.py:48-69
+//   emit_observations        get_shared_observations              src/environments/observation_spaces.py:67-131
+//   physics_env              pymunk Space.step -> [CP cpSpaceStep]  (call site base_env.py:392)
+//   termination_captured     BaseEnv._termination_criterion       src/environments/base_env.py:521-554
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
 #include <hip/hip_runtime.h>
