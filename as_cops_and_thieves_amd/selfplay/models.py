@@ -24,6 +24,19 @@ def conv_out_len(num_rays: int) -> int:
     return (l1 - 5) // 3 + 1
 
 
+def conv1d_as_gemm(x: torch.Tensor, conv: nn.Conv1d) -> torch.Tensor:
+    """``conv(x)`` for an unpadded, undilated Conv1d, evaluated as ONE GEMM over the whole batch: windows are
+    gathered with ``unfold`` and multiplied by the [out, in*k] weight matrix (hipBLASLt).  MIOpen's choices for these
+    tiny sequences -- im2col per sample, naive bf16 kernels for the weight gradient -- took > 40 % of a training
+    step.  Same parameters and same result as ``nn.Conv1d``."""
+    k, stride = conv.kernel_size[0], conv.stride[0]
+    cols = x.unfold(2, k, stride)                                   # [B, C, L_out, k]
+    B, C, L, _ = cols.shape
+    cols = cols.permute(0, 2, 1, 3).reshape(B * L, C * k)
+    out = nn.functional.linear(cols, conv.weight.reshape(conv.out_channels, C * k), conv.bias)
+    return out.reshape(B, L, conv.out_channels).transpose(1, 2)      # [B, out, L_out]
+
+
 class _Trunk(nn.Module):
     def __init__(self, channels: int, num_rays: int, hidden: int, layers: int):
         super().__init__()
@@ -41,20 +54,36 @@ class _Trunk(nn.Module):
 
     def forward(self, x: torch.Tensor, state, starts: Optional[torch.Tensor] = None):
         """x: [B, T, channels*R]; state: (h, c) each [layers, B, hidden]; starts: [B, T] bool, True where
-        a new episode begins at that step (state is zeroed before consuming it)."""
+        a new episode begins at that step (state is zeroed before consuming it).
+
+        The recurrence is evaluated here, step by step, from ``self.lstm``'s own parameters (``nn.LSTM`` keeps
+        the reference's parameter names and checkpoint layout) with the fused LSTM cell, and episode starts are
+        a multiplication by a mask -- no host synchronisation, no per-step library RNN call, and the same
+        launch sequence every time (so a rollout can be captured in a HIP graph)."""
         B, T, _ = x.shape
-        f = self.features(x.reshape(B * T, self.channels, self.num_rays)).reshape(B, T, 256)
-        if starts is None or not bool(starts.any()):
-            out, state = self.lstm(f, state)
-            return out, state
-        outs = []
+        z = x.reshape(B * T, self.channels, self.num_rays)
+        z = torch.relu(conv1d_as_gemm(z, self.features[0]))
+        z = torch.relu(conv1d_as_gemm(z, self.features[2]))
+        f = torch.tanh(self.features[5](z.flatten(1))).reshape(B, T, 256)      # == self.features(...)
         h, c = state
-        for t in range(T):
-            keep = (~starts[:, t]).to(h.dtype).view(1, B, 1)
-            h, c = h * keep, c * keep
-            o, (h, c) = self.lstm(f[:, t:t + 1], (h, c))
-            outs.append(o)
-        return torch.cat(outs, dim=1), (h, c)
+        keep = None if starts is None else (~starts).unsqueeze(-1)                     # [B, T, 1]
+        hs, cs = list(h.unbind(0)), list(c.unbind(0))
+        inp = f
+        for layer in range(self.layers):
+            w_ih, w_hh = getattr(self.lstm, f"weight_ih_l{layer}"), getattr(self.lstm, f"weight_hh_l{layer}")
+            b_ih, b_hh = getattr(self.lstm, f"bias_ih_l{layer}"), getattr(self.lstm, f"bias_hh_l{layer}")
+            hl, cl = hs[layer], cs[layer]
+            outs = []
+            for t in range(T):
+                if keep is not None:
+                    # every layer's state restarts with the episode (nn.LSTM semantics with a zeroed state)
+                    hl, cl = hl * keep[:, t].to(hl.dtype), cl * keep[:, t].to(cl.dtype)
+                # two GEMMs + one fused gate kernel (the cell nn.LSTMCell uses); gate order i, f, g, o
+                hl, cl = torch._VF.lstm_cell(inp[:, t], (hl.to(inp.dtype), cl.to(inp.dtype)), w_ih, w_hh, b_ih, b_hh)
+                outs.append(hl)
+            hs[layer], cs[layer] = hl, cl
+            inp = torch.stack(outs, dim=1)
+        return inp, (torch.stack(hs, 0), torch.stack(cs, 0))
 
 
 class LSTMPolicy(nn.Module):

@@ -119,3 +119,33 @@ def test_two_rank_gradient_allreduce_keeps_replicas_identical():
         assert p.exitcode == 0
     # different env shards (different data), same seed for the nets: after all-reduced updates the replicas agree
     assert np.array_equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("layers,channels", [(1, 2), (2, 4)])
+def test_manual_recurrence_equals_nn_lstm(layers, channels):
+    """The trunk evaluates the LSTM recurrence itself from nn.LSTM's parameters; it must match nn.LSTM (fp32)."""
+    from as_cops_and_thieves_amd.selfplay.models import _Trunk
+    torch.manual_seed(3)
+    tr = _Trunk(channels, 16, 24, layers)
+    x = torch.randn(5, 7, channels * 16)
+    h0, c0 = torch.randn(layers, 5, 24), torch.randn(layers, 5, 24)
+    out, (h, c) = tr(x, (h0, c0))
+    f = tr.features(x.reshape(35, channels, 16)).reshape(5, 7, 256)
+    want, (hw, cw) = tr.lstm(f, (h0, c0))
+    assert torch.allclose(out, want, atol=1e-5) and torch.allclose(h, hw, atol=1e-5) and torch.allclose(c, cw, atol=1e-5)
+    # gradients flow to the nn.LSTM parameters
+    out.sum().backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in tr.lstm.parameters())
+
+
+def test_conv_as_gemm_equals_conv1d():
+    from as_cops_and_thieves_amd.selfplay.models import _Trunk, conv1d_as_gemm
+    torch.manual_seed(4)
+    tr = _Trunk(4, 64, 16, 1)
+    x = torch.randn(6, 4, 64)
+    assert torch.allclose(conv1d_as_gemm(x, tr.features[0]), tr.features[0](x), atol=1e-5)
+    y = torch.relu(tr.features[0](x))
+    assert torch.allclose(conv1d_as_gemm(y, tr.features[2]), tr.features[2](y), atol=1e-5)
+    # and the trunk's feature path as a whole
+    z = torch.relu(conv1d_as_gemm(torch.relu(conv1d_as_gemm(x, tr.features[0])), tr.features[2]))
+    assert torch.allclose(torch.tanh(tr.features[5](z.flatten(1))), tr.features(x), atol=1e-5)
