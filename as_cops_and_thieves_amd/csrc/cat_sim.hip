@@ -57,6 +57,7 @@ struct GridDesc {
     int nx, ny;
     int off_base, ent_base;     // into grid_off / grid_ent ; rows = nx*ny*R (+1); row_base == off_base - map index
     int coff_base, cent_base;   // into cgrid_off / cgrid_ent ; rows = nx*ny (+1)
+    int crow_base, pad2;        // into cgrid_rows (one packed 8-byte row per cell)
     int row_base, pad1;         // into grid_rows, in rows of Params::row_words words
 };
 
@@ -74,6 +75,7 @@ struct Params {
     const unsigned long long *grid_rows;
     const int *grid_off, *cgrid_off;
     const unsigned char *grid_ent, *cgrid_ent;
+    const unsigned long long *cgrid_rows;   // per cell: count | first 7 contact-candidate wall ids (longer lists: the CSR arrays)
     const int *work_env;    // [n_blocks*wpb] env slot or -1
     const int *block_map;   // [n_blocks]
     // Env state: one contiguous record per env slot (so a wave moves it with 16-byte lanes):
@@ -575,34 +577,70 @@ __device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, i
     const double reach = p.ray_length + r2 + 1e-6;
     const double cone_m = p.gate ? 1e-6 : r2 + 1e-6;
     int my_cell = -1, my_near0 = -1, my_near1 = -1, my_dk0 = 0, my_dcnt = 0;
-    for (int i = 0; i < A; i++) {
-        const double ax = L.fpos[2 * i], ay = L.fpos[2 * i + 1];
+    // lane i < A: grid cell of agent i and the cell's packed contact row -- ONE global round trip for all agents
+    unsigned long long crow = 0ull;
+    if (lane < A) {
+        const double ax = L.fpos[2 * lane], ay = L.fpos[2 * lane + 1];
         const int cx = (int)floor((ax - gd.x0) * gd.inv_cell), cy = (int)floor((ay - gd.y0) * gd.inv_cell);
-        int cellid = -1, near0 = -1, near1 = -1;
         if (cx >= 0 && cy >= 0 && cx < gd.nx && cy < gd.ny) {
-            cellid = cy * gd.nx + cx;
-            const int c0 = uni(G(p.cgrid_off)[gd.coff_base + cellid]), c1 = uni(G(p.cgrid_off)[gd.coff_base + cellid + 1]);
-            for (int base = c0; base < c1; base += kLanes) {   // lanes stride the cell's contact candidates
-                const int e = base + lane;
-                bool near = false;
-                int sh = 0;
-                if (e < c1) {
-                    sh = G(p.cgrid_ent)[gd.cent_base + e];
-                    const double *bb = L.bb + 4 * sh;
-                    const double m = r2 + 1e-6;
-                    if ((bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m))
-                        near = poly_point_distance(L, sh, p.wall_r, ax, ay) <= r2;  // [CP cpShapeSegmentQuery] alpha = 0 rule
-                }
-                unsigned long long m = __ballot(near);
-                while (m) {  // ascending wall ids; more than two such walls cannot matter: the first visited wins at alpha 0
-                    const int src = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int id = __builtin_amdgcn_readlane(sh, src);
-                    if (near0 < 0) near0 = id; else if (near1 < 0) near1 = id;
-                }
+            my_cell = cy * gd.nx + cx;
+            crow = G(p.cgrid_rows)[gd.crow_base + my_cell];
+        }
+    }
+    {   // lane = 8 i + q: is agent i's origin within the ray radius of the cell's q-th candidate wall?
+        const int pi = lane >> 3, pq = lane & 7;
+        const unsigned lo = (unsigned)__shfl((int)(unsigned)crow, pi), hi = (unsigned)__shfl((int)(unsigned)(crow >> 32), pi);
+        const unsigned long long row = ((unsigned long long)hi << 32) | lo;
+        const int n_i = (int)(row & 0xFF);
+        bool near = false;
+        int sh = 0;
+        if (pi < A && pq < 7 && pq < n_i) {
+            sh = (int)((row >> (8 * (pq + 1))) & 0xFF);
+            const double ax = L.fpos[2 * pi], ay = L.fpos[2 * pi + 1];
+            const double *bb = L.bb + 4 * sh;
+            const double m = r2 + 1e-6;
+            if ((bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m))
+                near = poly_point_distance(L, sh, p.wall_r, ax, ay) <= r2;  // [CP cpShapeSegmentQuery] alpha = 0 rule
+        }
+        const unsigned long long m = __ballot(near);
+        // ascending wall ids; more than two such walls cannot matter: the first visited wins at alpha 0
+        unsigned mi = lane < A ? (unsigned)((m >> (8 * lane)) & 0x7Full) : 0u;
+        const int b0 = mi ? __builtin_ctz(mi) : 0;
+        const unsigned mi2 = mi & (mi - 1u);
+        const int b1 = mi2 ? __builtin_ctz(mi2) : 0;
+        const int id0 = __shfl(sh, (8 * lane + b0) & 63), id1 = __shfl(sh, (8 * lane + b1) & 63);
+        if (mi) my_near0 = id0;
+        if (mi2) my_near1 = id1;
+    }
+    // cells with more than 7 contact candidates (dense maps): that agent's list is walked from the CSR arrays
+    unsigned long long longm = __ballot(lane < A && (int)(crow & 0xFF) > 7);
+    while (longm) {
+        const int i = __builtin_ctzll(longm);
+        longm &= longm - 1;
+        const double ax = L.fpos[2 * i], ay = L.fpos[2 * i + 1];
+        const int cellid = __builtin_amdgcn_readlane(my_cell, i);
+        int near0 = -1, near1 = -1;
+        const int c0 = uni(G(p.cgrid_off)[gd.coff_base + cellid]), c1 = uni(G(p.cgrid_off)[gd.coff_base + cellid + 1]);
+        for (int base = c0; base < c1; base += kLanes) {   // lanes stride the cell's contact candidates
+            const int e = base + lane;
+            bool near = false;
+            int sh = 0;
+            if (e < c1) {
+                sh = G(p.cgrid_ent)[gd.cent_base + e];
+                const double *bb = L.bb + 4 * sh;
+                const double m = r2 + 1e-6;
+                if ((bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m))
+                    near = poly_point_distance(L, sh, p.wall_r, ax, ay) <= r2;
+            }
+            unsigned long long m = __ballot(near);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const int id = __builtin_amdgcn_readlane(sh, src);
+                if (near0 < 0) near0 = id; else if (near1 < 0) near1 = id;
             }
         }
-        if (lane == i) { my_cell = cellid; my_near0 = near0; my_near1 = near1; }
+        if (lane == i) { my_near0 = near0; my_near1 = near1; }
     }
     if (lane < A * A) {   // lane = (i, j): cone of agent j's circle seen from agent i
         const int i = lane / A, j = lane % A;
@@ -1304,6 +1342,27 @@ __device__ __forceinline__ void load_state(const Lds &L, const Params &p, int en
     wave_sync();
 }
 
+// The same copy in two halves, so that the HBM round trip overlaps the map staging: fetch into registers
+// before stage_map (whose barrier keeps the loads in front of it), write to LDS after it.
+struct StateRegs { u32x4 v[3]; };   // 3 x 64 lanes x 16 B = 3 KB >= the largest record (A = 8: 2.1 KB)
+template <class D>
+__device__ __forceinline__ void fetch_state(StateRegs &r, const Params &p, int env, int lane)
+{
+    GAS const u32x4 *src = (GAS const u32x4 *)(G(p.state) + (size_t)(env < 0 ? 0 : env) * D::rec_bytes(p));
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+        if (lane + q * kLanes < D::rec_bytes(p) / 16) r.v[q] = src[lane + q * kLanes];
+}
+template <class D>
+__device__ __forceinline__ void commit_state(const Lds &L, const StateRegs &r, const Params &p, int lane)
+{
+    u32x4 *dst = reinterpret_cast<u32x4 *>(L.rec);
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+        if (lane + q * kLanes < D::rec_bytes(p) / 16) dst[lane + q * kLanes] = r.v[q];
+    wave_sync();
+}
+
 template <class D>
 __device__ __forceinline__ void store_state(const Lds &L, const Params &p, int env, int lane)
 {
@@ -1429,13 +1488,15 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
     const int env = uni(p.work_env[blockIdx.x * W + wave]);
     const Lds L = carve<D>(p, smem, md, wave, wave);
     if (lane < 4) L.ctrl[4 * wave + lane] = lane == 3 ? env : 0;   // claimed, done, published, env id
+    StateRegs sregs;
+    fetch_state<D>(sregs, p, env, lane);
     stage_map<D>(p, smem, md);   // ends with the workgroup barrier
     PHASE(pc, 0);
     const int S = md.S, A = D::A(p);
     const bool has = env >= 0;
     int captured = 0, timeout = 0, step = 0;
     if (has) {
-        load_state<D>(L, p, env, lane);
+        commit_state<D>(L, sregs, p, lane);
         PHASE(pc, 1);
         step = uni(L.cnt[0]) + 1;                                 // :372
         captured = termination_captured<D>(L, p, S, lane);           // :378
@@ -1602,6 +1663,7 @@ struct GridHost {
     std::vector<GridDesc> desc;
     std::vector<unsigned long long> rows;   // per (cell, ray): count | first ids (row_words 8-byte words), see finalize_rows
     std::vector<int> rows_of;               // rows per map
+    std::vector<unsigned long long> crows;  // per cell: count | first 7 contact candidates
     int max_row = 0, row_words = 1;
     std::vector<int> off, coff;
     std::vector<unsigned char> ent, cent;
@@ -1664,6 +1726,13 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
     }
     g.off.push_back((int)g.ent.size() - d.ent_base);
     g.coff.push_back((int)g.cent.size() - d.cent_base);
+    d.crow_base = (int)g.crows.size();
+    for (int c = 0; c < d.nx * d.ny; c++) {
+        const int o0 = g.coff[d.coff_base + c] + d.cent_base, n = g.coff[d.coff_base + c + 1] + d.cent_base - o0;
+        unsigned long long w = (unsigned long long)(n > 255 ? 255 : n);
+        for (int q = 0; q < n && q < 7; q++) w |= (unsigned long long)g.cent[o0 + q] << (8 * (q + 1));
+        g.crows.push_back(w);
+    }
     while (g.ent.size() & 3) g.ent.push_back(0);
     while (g.cent.size() & 3) g.cent.push_back(0);
     g.desc.push_back(d);
@@ -1909,6 +1978,10 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         const int ni = 2 * A * kK + NPs_rec + 4;
         p.rec_bytes = (p.rec_doubles * 8 + ni * 4 + 15) / 16 * 16;
     }
+    if (p.rec_bytes > 3 * kLanes * 16) {   // StateRegs
+        snprintf(s->err, sizeof s->err, "state record of %d bytes exceeds the kernels' register staging", p.rec_bytes);
+        return fail(CAT_ERR_BAD_CONFIG);
+    }
     std::vector<char> rec0((size_t)N * p.rec_bytes, 0);
     for (int e = 0; e < N; e++) {
         const MapDesc &d = descs[slot[e]];
@@ -1953,6 +2026,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.grid_ent), s->grid.ent.size(), s->grid.ent.data()));
         TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.cgrid_off), s->grid.coff.size(), s->grid.coff.data()));
         TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.cgrid_ent), s->grid.cent.size(), s->grid.cent.data()));
+        TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.cgrid_rows), s->grid.crows.size(), s->grid.crows.data()));
     }
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.work_env), work.size(), work.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.block_map), block_map.size(), block_map.data()));
