@@ -933,12 +933,21 @@ __device__ __forceinline__ void emit_observations(const Lds &L, const Params &p,
 template <class D>
 __device__ int termination_captured(const Lds &L, const Params &p, int S, int lane)
 {
-    const int A = D::A(p), nc = D::n_cops(p);
-    for (int t = nc; t < A; t++) {
-        for (int c = 0; c < nc; c++) {
+    const int A = D::A(p), nc = D::n_cops(p), npairs = (A - nc) * nc;   // <= 16
+    // lane = pair (thief-major, as the reference's nested loops): inside the capture radius?
+    bool within = false;
+    if (lane < npairs) {
+        const int t = nc + lane / nc, c = lane % nc;
+        const double ddx = L.pos[2 * t] - L.pos[2 * c], ddy = L.pos[2 * t + 1] - L.pos[2 * c + 1];  // Vec2d.get_distance
+        within = sqrt(ddx * ddx + ddy * ddy) < p.term_radius;
+    }
+    unsigned long long cand = __ballot(within);
+    while (cand) {   // in pair order; the first pair with a clear line of sight captures
+        {
+            const int pair = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const int t = nc + pair / nc, c = pair % nc;
             const double ax = L.pos[2 * t], ay = L.pos[2 * t + 1], bx = L.pos[2 * c], by = L.pos[2 * c + 1];
-            const double ddx = ax - bx, ddy = ay - by;  // Vec2d.get_distance
-            if (!(sqrt(ddx * ddx + ddy * ddy) < p.term_radius)) continue;
             const double dx = bx - ax, dy = by - ay, idx = 1.0 / dx, idy = 1.0 / dy;
             bool any = false;
             for (int base = 0; base < S; base += kLanes) {
@@ -1503,11 +1512,14 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
         timeout = (!captured && step >= p.max_step) ? 1 : 0;
         copy_snapshot(L, A, lane);
 
-        // Entity._perform_action (entity.py:126-134), every lane computes all agents identically
-        const double m_inv = 1.0 / p.mass;
-        for (int i = 0; i < A; i++) {
+        // Entity._perform_action (entity.py:126-134), lane = agent.  (As a wave-uniform loop over the agents -- the
+        // synthetic-action Philox rounds and the sqrt/divide chain of each agent one after the other, on the scalar
+        // unit -- this was 6 us of the tick, in the part of the kernel every wave of the launch executes in step.)
+        if (lane < A) {
+            const int i = lane;
+            const double m_inv = 1.0 / p.mass;
             int act;
-            if (la.actions) act = uni(la.actions[(size_t)env * A + i]);
+            if (la.actions) act = la.actions[(size_t)env * A + i];
             else { unsigned rnd[4]; philox_env(p, env, (unsigned)la.synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
             double jx = 0.0, jy = 0.0;
             if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
@@ -1517,6 +1529,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
             if (len > p.max_speed) { vx = vx / len * p.max_speed; vy = vy / len * p.max_speed; }
             L.vel[2 * i] = vx; L.vel[2 * i + 1] = vy;
         }
+        wave_sync();
         PHASE(pc, 2);
         agent_setup<D>(L, p, gd, lane);                              // entity.py:143-144, :388-390 (setup part)
         PHASE(pc, 4);
