@@ -150,6 +150,7 @@ struct LaunchArgs {
     const unsigned char *mask;
     const double *positions;
     int use_done_mask;
+    int auto_reset;                 // tick_kernel: episodes that end this tick are reset inside the same launch
     unsigned long long synth_tick;  // tick_kernel with actions == NULL: Philox actions of this tick
 };
 
@@ -1408,10 +1409,11 @@ __device__ __forceinline__ void copy_snapshot(const Lds &L, int A, int lane)
     wave_sync();
 }
 
-__device__ __forceinline__ void publish_slot(const Lds &L, int wave, int lane)
+// ctrl word 2 of a slot: 0 = not published yet, else the number of its work units (ray chunks [+ Space.step])
+__device__ __forceinline__ void publish_slot(const Lds &L, int wave, int lane, int n_units)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(&L.ctrl[4 * wave + 2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(&L.ctrl[4 * wave + 2], n_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // The shared part of both kernels.  Units of a published slot, claimed in order by any wave of the workgroup:
@@ -1423,7 +1425,7 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
                                           const GridDesc &gd, char *smem, int wave, int lane, int tick, PhaseClock &pc)
 {
     const int W = p.wpb, S = md.S;
-    const int nchunks = D::A(p) * ((D::R(p) + kLanes - 1) / kLanes), last_unit = tick ? nchunks : nchunks - 1;
+    const int nchunks = D::A(p) * ((D::R(p) + kLanes - 1) / kLanes);
     unsigned fin_mask = 0u;
     bool pending = true;
     while (pending) {
@@ -1431,11 +1433,12 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         for (int k = 0; k < W; k++) {
             const int slot = uni((wave + k) % W);
             const int e_s = uni(L.ctrl[4 * slot + 3]);   // written before the workgroup barrier
-            if (e_s < 0 || ctrl_peek(&L.ctrl[4 * slot + 0], lane) > last_unit) continue;
-            if (k > 0) {   // another wave's slot: only once its owner has published it
-                if (!ctrl_peek(&L.ctrl[4 * slot + 2], lane)) { pending = true; continue; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
+            if (e_s < 0) continue;
+            const int n_units = ctrl_peek(&L.ctrl[4 * slot + 2], lane);
+            if (n_units == 0) { pending = true; continue; }   // its owner has not published it yet
+            const int last_unit = n_units - 1;
+            if (ctrl_peek(&L.ctrl[4 * slot + 0], lane) > last_unit) continue;
+            if (k > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // another wave's slot
             const Lds Ls = carve<D>(p, smem, md, slot, wave);
             for (;;) {
                 const int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
@@ -1462,7 +1465,10 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         LateOut late;
         rewards_and_positions<D>(Ls, p, la, lane, tick, captured2, timeout2, late);
         const unsigned char term = (unsigned char)(captured2 || timeout2);
-        if (lane == 0) { Ls.cnt[0] = step2; Ls.cnt[2] = term; if (rcount >= 0) Ls.cnt[1] = rcount; }   // base_env.py:350
+        if (lane == 0) {   // a slot that went through a reset (rcount >= 0) starts its new episode: base_env.py:350
+            Ls.cnt[0] = step2; Ls.cnt[2] = rcount >= 0 ? 0 : term;
+            if (rcount >= 0) Ls.cnt[1] = rcount;
+        }
         store_state<D>(Ls, p, e_s, lane);
         emit_observations<D>(Ls, p, la, e_s, lane, tick, late);
         if (tick && lane == 0) {
@@ -1472,6 +1478,10 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         }
     }
 }
+
+template <class D>
+__device__ __forceinline__ void spawn_and_reset(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
+                                                int env, unsigned rc, int lane);
 
 // BaseEnv.step (base_env.py:354-413).  A workgroup of wpb waves advances wpb envs sharing one map.  Wave w OWNS
 // env slot w: it loads the state, decides termination, applies the actions, publishes the ray-fan setup, runs the
@@ -1502,6 +1512,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
     stage_map<D>(p, smem, md);   // ends with the workgroup barrier
     PHASE(pc, 0);
     const int S = md.S, A = D::A(p);
+    const int nchunks = A * ((D::R(p) + kLanes - 1) / kLanes);
     const bool has = env >= 0;
     int captured = 0, timeout = 0, step = 0;
     if (has) {
@@ -1531,13 +1542,23 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
         }
         wave_sync();
         PHASE(pc, 2);
+        int n_units = nchunks + 1, rcount = -1, step_store = step;
+        if (la.auto_reset && (captured || timeout)) {
+            // The episode ends with this tick and the caller wants the slot reset in the same call: the terminal
+            // observations would be overwritten by the reset's (the rewards of a terminal tick are constants), so the
+            // slot's ray chunks are those of the NEW episode.  The reset needs the stepped state (stale circle caches
+            // and leaf bbs, quirk Q1), so the owner runs Space.step here instead of queueing it.
+            physics_env<D>(L, p, S, lane, pc);                        // :392
+            rcount = uni(L.cnt[1]) + 1;
+            spawn_and_reset<D>(L, p, la, md, env, (unsigned)rcount, lane);   // base_env.py:286-352
+            wave_sync();
+            copy_snapshot(L, A, lane);
+            n_units = nchunks; step_store = 0;
+        }
         agent_setup<D>(L, p, gd, lane);                              // entity.py:143-144, :388-390 (setup part)
         PHASE(pc, 4);
-    }
-
-    if (has) {
-        if (lane == 0) { L.flags[0] = step; L.flags[1] = captured; L.flags[2] = timeout; L.flags[3] = -1; }
-        publish_slot(L, wave, lane);
+        if (lane == 0) { L.flags[0] = step_store; L.flags[1] = captured; L.flags[2] = timeout; L.flags[3] = rcount; }
+        publish_slot(L, wave, lane, n_units);
     }
     run_units<D>(L, p, la, md, gd, smem, wave, lane, 1, pc);
 #ifdef CAT_WAVE_SPREAD
@@ -1585,6 +1606,21 @@ __device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const 
     const int S = md.S, A = D::A(p);
     load_state<D>(L, p, env, lane);
     const unsigned rc = (unsigned)(uni(L.cnt[1]) + 1);
+    spawn_and_reset<D>(L, p, la, md, env, rc, lane);
+    wave_sync();
+    copy_snapshot(L, A, lane);   // fresh positions, stale circle caches and leaf bbs (Q1); overwrites the spawn points
+    agent_setup<D>(L, p, gd, lane);                                  // :334-344 (setup part)
+    if (lane == 0) { L.flags[0] = 0; L.flags[1] = 0; L.flags[2] = 0; L.flags[3] = (int)rc; }  // :350
+    publish_slot(L, wave, lane, A * ((D::R(p) + kLanes - 1) / kLanes));
+}
+
+// _get_non_colliding_position + Entity.reset for every agent of the env in L (base_env.py:313-332, 123-166;
+// entity.py:148-157): new positions, zero velocities; the circle caches and leaf bbs stay stale (quirk Q1).
+template <class D>
+__device__ __forceinline__ void spawn_and_reset(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
+                                                int env, unsigned rc, int lane)
+{
+    const int S = md.S, A = D::A(p);
     GAS const double *start = G(p.geo_f64) + md.f64_off + 4 * md.S + 8 * md.P;
     GAS const double *regions = start + 2 * md.A;
     GAS const int *region_off = G(p.geo_i32) + md.i32_off + 2 * md.S;
@@ -1635,11 +1671,6 @@ __device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const 
         L.pos[2 * i] = L.spawn[2 * i]; L.pos[2 * i + 1] = L.spawn[2 * i + 1];
         L.vel[2 * i] = 0.0; L.vel[2 * i + 1] = 0.0;
     }
-    wave_sync();
-    copy_snapshot(L, A, lane);   // fresh positions, stale circle caches and leaf bbs (Q1); overwrites the spawn points
-    agent_setup<D>(L, p, gd, lane);                                  // :334-344 (setup part)
-    if (lane == 0) { L.flags[0] = 0; L.flags[1] = 0; L.flags[2] = 0; L.flags[3] = (int)rc; }  // :350
-    publish_slot(L, wave, lane);
 }
 
 __global__ void random_actions_kernel(const Params *__restrict__ pp, unsigned long long tick, int *actions)
@@ -2160,11 +2191,10 @@ extern "C" int cat_step_fused(cat_sim *s, const int32_t *actions, uint64_t synth
     memset(&la, 0, sizeof la);
     if (out) la.out = *out;
     la.actions = actions; la.synth_tick = synth_tick;
+    la.auto_reset = auto_reset ? 1 : 0;   // finished episodes are reset inside the same launch (no second kernel)
     launch_tick(s, la, stream);
     HIP_TRY(s, hipGetLastError());
-    // the reset stays its own (early-exiting) launch: inlining it into tick_kernel costs 40+ spilled
-    // VGPRs on the common path, far more than the ~4 us launch it would save
-    return auto_reset ? launch_reset(s, nullptr, nullptr, out, 1, stream) : CAT_OK;
+    return CAT_OK;
 }
 
 extern "C" int cat_random_actions(cat_sim *s, uint64_t tick, int32_t *actions, void *stream)

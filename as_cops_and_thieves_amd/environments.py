@@ -330,12 +330,12 @@ class VecCopsEnv:
             acts = self._actions
         else:
             acts = actions
-        out = self._sim.step(acts)
+        # one launch: finished episodes are reset inside the tick kernel, which leaves the NEW episode's first
+        # observations in the buffers of those slots (rewards / flags / winner are the terminal tick's)
+        out = self._sim.step_fused(acts, auto_reset=self.auto_reset)
         rewards = {aid: out["reward"][:, i] for i, aid in enumerate(self.possible_agents)}
         terminated, truncated = out["terminated"].bool(), out["truncated"].bool()   # fresh tensors
         infos = {"winner": out["winner"].clone(), "terminated": terminated, "truncated": truncated}
-        if self.auto_reset:
-            self._sim.reset_done()      # overwrites the observation buffers of finished slots only
         terminations = {aid: terminated for aid in self.possible_agents}
         truncations = {aid: truncated for aid in self.possible_agents}
         return self._obs(), rewards, terminations, truncations, infos

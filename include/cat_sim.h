@@ -138,9 +138,12 @@ int cat_reset_done(cat_sim *sim, const cat_outputs *out, void *stream);
    actions: DEVICE [N,A] int32 in {0,1,2,3}. */
 int cat_step(cat_sim *sim, const int32_t *actions, const cat_outputs *out, void *stream);
 
-/* One-call form of the rollout tick: cat_step followed by cat_reset_done (auto_reset != 0) and,
-   when actions == NULL, the synthetic Philox actions of cat_random_actions for tick `synth_tick`
-   generated inside the step kernel.  Results are identical to the three separate calls. */
+/* One-LAUNCH form of the rollout tick: cat_step, the auto-reset of cat_reset_done (auto_reset != 0) and,
+   when actions == NULL, the synthetic Philox actions of cat_random_actions for tick `synth_tick`, all inside
+   the step kernel.  Results are identical to the three separate calls: for an episode that ends with this
+   tick, reward / terminated / truncated / winner are the terminal tick's and the observation buffers hold
+   the first observations of the new episode (the terminal observations, which the separate calls compute
+   and then overwrite, are not computed). */
 int cat_step_fused(cat_sim *sim, const int32_t *actions, uint64_t synth_tick, int auto_reset,
                    const cat_outputs *out, void *stream);
 
