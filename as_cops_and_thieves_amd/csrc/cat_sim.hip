@@ -1085,17 +1085,32 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
     unsigned seen_p = 0u;
     // arbiter cache snapshot: lane q = (agent, slot)
     const int my_wsh = lane < A * kK ? L.wsh[lane] : -1;
-    for (int i = 0; i < A; i++) {
-        const double cx = L.tc[2 * i], cy = L.tc[2 * i + 1];
-        const double bl = cx - rc, bb_ = cy - rc, br = cx + rc, bt = cy + rc;
-        for (int base = 0; base < S; base += kLanes) {
-            const int s = base + lane;
-            bool ov = false;
-            if (s < S) {
-                const double *sb = L.bb + 4 * s;  // [CP cpBBIntersects]
-                ov = (bl <= sb[2] && sb[0] <= br && bb_ <= sb[3] && sb[1] <= bt);
+    // lane = wall: its bb against every agent's circle bb, all walls in one LDS round; bit i of ovm[q]: wall 64 q + lane
+    // overlaps agent i.  The contacts are then created agent by agent, walls ascending (the order fixes the solver's).
+    unsigned ovm[CAT_MAX_SHAPES / kLanes] = {0u, 0u, 0u, 0u};
+    bool any_ov = false;
+#pragma unroll
+    for (int q = 0; q < CAT_MAX_SHAPES / kLanes; q++) {
+        const int s = q * kLanes + lane;
+        if (s < S) {
+            const double *sb = L.bb + 4 * s;  // [CP cpBBIntersects]
+            const double s0 = sb[0], s1 = sb[1], s2 = sb[2], s3 = sb[3];
+            for (int i = 0; i < A; i++) {
+                const double cx = L.tc[2 * i], cy = L.tc[2 * i + 1];
+                const double bl = cx - rc, bb_ = cy - rc, br = cx + rc, bt = cy + rc;
+                ovm[q] |= (unsigned)(bl <= s2 && s0 <= br && bb_ <= s3 && s1 <= bt) << i;
             }
-            unsigned long long m = __ballot(ov);
+            any_ov = any_ov || ovm[q] != 0u;
+        }
+    }
+    const bool some = __ballot(any_ov) != 0ull;
+    for (int i = 0; some && i < A; i++) {
+        const double cx = L.tc[2 * i], cy = L.tc[2 * i + 1];
+#pragma unroll
+        for (int q = 0; q < CAT_MAX_SHAPES / kLanes; q++) {
+            const int base = q * kLanes;
+            if (base >= S) break;
+            unsigned long long m = __ballot((ovm[q] >> i) & 1u);
             while (m) {
                 const int sh = base + __builtin_ctzll(m);
                 m &= m - 1;
