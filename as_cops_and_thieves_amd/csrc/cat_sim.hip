@@ -1442,33 +1442,47 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
     const int W = p.wpb, S = md.S;
     const int nchunks = D::A(p) * ((D::R(p) + kLanes - 1) / kLanes);
     unsigned fin_mask = 0u;
-    bool pending = true;
-    while (pending) {
-        pending = false;
-        for (int k = 0; k < W; k++) {
-            const int slot = uni((wave + k) % W);
-            const int e_s = uni(L.ctrl[4 * slot + 3]);   // written before the workgroup barrier
-            if (e_s < 0) continue;
-            const int n_units = ctrl_peek(&L.ctrl[4 * slot + 2], lane);
-            if (n_units == 0) { pending = true; continue; }   // its owner has not published it yet
-            const int last_unit = n_units - 1;
-            if (ctrl_peek(&L.ctrl[4 * slot + 0], lane) > last_unit) continue;
-            if (k > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // another wave's slot
-            const Lds Ls = carve<D>(p, smem, md, slot, wave);
-            for (;;) {
-                const int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
-                if (c > last_unit) break;
-                if (c < nchunks) fan_chunk<D>(Ls, p, la, gd, e_s, lane, S, tick, c, pc);   // entity.py:143-144, base_env.py:388-390 / :334-344
-                else {
-                    PHASE(pc, 9);
-                    physics_env<D>(Ls, p, S, lane, pc);                                // base_env.py:392
-                    PHASE(pc, 10);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the unit's LDS writes, before it counts as done
-                if (ctrl_add(&L.ctrl[4 * slot + 1], lane) == last_unit) { fin_mask |= 1u << slot; break; }   // no unit is left unclaimed
-            }
+    bool own_first = true;
+    for (;;) {
+        // one LDS round trip for the whole workgroup: lane s < W reads the control words of slot s
+        int e_l = -1, nu_l = 0, cl_l = 0;
+        if (lane < W) {
+            e_l = L.ctrl[4 * lane + 3];   // written before the workgroup barrier
+            nu_l = __hip_atomic_load(&L.ctrl[4 * lane + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            cl_l = __hip_atomic_load(&L.ctrl[4 * lane + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (pending) __builtin_amdgcn_s_sleep(8);
+        const unsigned open = (unsigned)__ballot(e_l >= 0 && nu_l > 0 && cl_l < nu_l);      // published, units left to claim
+        const unsigned unpublished = (unsigned)__ballot(e_l >= 0 && nu_l == 0);
+        if (open == 0u) {
+            if (unpublished == 0u) break;
+            __builtin_amdgcn_s_sleep(8);   // an owner is still in its serial part
+            continue;
+        }
+        // the own slot first, then the next open slot after the own index (spreads the helpers over the slots)
+        int slot;
+        if (own_first && ((open >> wave) & 1u)) slot = wave;
+        else {
+            const unsigned rot = wave == 0 ? open : ((open >> wave) | (open << (32 - wave)));
+            slot = (wave + __builtin_ctz(rot)) & 31;   // bits >= W are never set (W <= 16)
+        }
+        own_first = false;
+        slot = uni(slot);
+        const int e_s = uni(L.ctrl[4 * slot + 3]);
+        const int last_unit = uni(L.ctrl[4 * slot + 2]) - 1;
+        if (slot != wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // another wave's slot
+        const Lds Ls = carve<D>(p, smem, md, slot, wave);
+        for (;;) {
+            const int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
+            if (c > last_unit) break;
+            if (c < nchunks) fan_chunk<D>(Ls, p, la, gd, e_s, lane, S, tick, c, pc);   // entity.py:143-144, base_env.py:388-390 / :334-344
+            else {
+                PHASE(pc, 9);
+                physics_env<D>(Ls, p, S, lane, pc);                                // base_env.py:392
+                PHASE(pc, 10);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the unit's LDS writes, before it counts as done
+            if (ctrl_add(&L.ctrl[4 * slot + 1], lane) == last_unit) { fin_mask |= 1u << slot; break; }   // no unit is left unclaimed
+        }
     }
     if (fin_mask) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the other waves' units of those slots
     while (fin_mask) {
