@@ -906,8 +906,6 @@ __device__ __forceinline__ void emit_observations(const Lds &L, const Params &p,
                                                   int rew_mode, const LateOut &late)
 {
     const int A = D::A(p), R = D::R(p);
-    if (rew_mode && lane < A && la.out.reward) la.out.reward[(size_t)env * A + lane] = late.reward;
-    if (lane < 2 * A && la.out.team_positions) la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)late.tp16;
     // get_shared_observations (observation_spaces.py:98-129): first team member, roster order,
     // with a non-EMPTY ray supplies (type, distance); else EMPTY with the last member's distance
     for (int k = lane; k < R; k += kLanes) {
@@ -926,6 +924,9 @@ __device__ __forceinline__ void emit_observations(const Lds &L, const Params &p,
     if (la.out.obs_type) wide_store(la.out.obs_type + g0, L.ot, A * R, lane);
     if (la.out.shared_distance) wide_store(la.out.shared_distance + (size_t)env * 2 * R, L.sd, 2 * R * 2, lane);
     if (la.out.shared_type) wide_store(la.out.shared_type + (size_t)env * 2 * R, L.st, 2 * R, lane);
+    // last: the reward comes from a LUT load issued by rewards_and_positions, whose latency the stores above cover
+    if (rew_mode && lane < A && la.out.reward) la.out.reward[(size_t)env * A + lane] = late.reward;
+    if (lane < 2 * A && la.out.team_positions) la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)late.tp16;
 }
 
 // ------------------------------------------------------------------ termination ---------------
