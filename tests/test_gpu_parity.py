@@ -286,3 +286,12 @@ def test_generic_kernel_on_the_rosters_that_have_a_fixed_instantiation(name, ray
     m = compiled(name, cops, thieves)
     cfg = SimConfig(n_envs=24, n_cops=cops, n_thieves=thieves, n_rays=rays, max_step_count=30, seed=23)
     _run(cfg, [m], np.zeros(24, np.int32), ticks=45, rng=np.random.default_rng(9), auto_reset=True)
+
+
+def test_one_cop_vs_one_thief_on_squarinth():
+    """BASELINE configs[0]'s roster (the reference's plumbing case): A = 2, one agent pair, 90 rays, generic kernel."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    m = compiled("squarinth", 1, 1)
+    cfg = SimConfig(n_envs=20, n_cops=1, n_thieves=1, n_rays=90, max_step_count=35, seed=13)
+    stats = _run(cfg, [m], np.zeros(20, np.int32), ticks=80, rng=np.random.default_rng(11), auto_reset=True)
+    assert stats["done"] >= 20
