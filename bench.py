@@ -74,7 +74,13 @@ class HipEvents:
     def __init__(self):
         import ctypes as C
         self.C = C
-        self.lib = C.CDLL("libamdhip64.so")
+        path = "libamdhip64.so"
+        with open("/proc/self/maps") as f:      # the very copy of the runtime this process already uses
+            for line in f:
+                if "libamdhip64.so" in line:
+                    path = line.split()[-1]
+                    break
+        self.lib = C.CDLL(path)
         self.lib.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
         self.lib.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
 
