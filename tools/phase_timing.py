@@ -28,9 +28,12 @@ for t in range(100, 100 + T):
     sim.step(sim.random_actions(t)); sim.reset_done()
 torch.cuda.synchronize()
 L.cat_debug_phase_cycles(buf, 1)
-names = {0: "stage_map", 1: "load_state", 2: "termination+actions", 3: "ray setup", 4: "agent setup (cells, cones)",
-         5: "item packing", 6: "dense items (gate+query)", 7: "per-ray resolve", 8: "hit point + f16", 9: "shared obs", 10: "physics",
-         11: "store", 12: "phys: integrate", 13: "phys: wall broadphase+narrow", 14: "phys: pairs", 15: "phys: aging"}
+# a mark closes the span since the previous mark of the same wave, so with shared work units the spans also contain
+# the claim/scan steps that precede them; "tail" = everything after a wave's last unit (scan, waits, write-back)
+names = {0: "stage_map", 1: "state -> LDS", 2: "termination+actions", 4: "agent setup (cells, cones)",
+         5: "unit claim + chunk prologue + packing (gate)", 6: "dense items (hull query)", 7: "per-ray resolve", 8: "hit point + f16",
+         9: "before physics unit", 10: "physics (rest)", 11: "tail: scan, waits, write-back", 12: "phys: integrate",
+         13: "phys: wall broadphase+narrow", 14: "phys: pairs", 15: "phys: aging"}
 tot = sum(buf)
 for i in range(24):
     if buf[i]:
