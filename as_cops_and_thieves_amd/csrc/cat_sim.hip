@@ -36,7 +36,6 @@ namespace {
 constexpr int kMaxWaves = 16;       // waves (= env slots) per workgroup: Params::wpb in {1, 2, 4, 8, 16}
 constexpr int kLanes = 64;          // gfx950 wavefront
 constexpr int kK = CAT_WALL_CACHE;
-constexpr int kMaxJ = 16;          // per-ray candidate list length per pass
 constexpr unsigned kBlobMagic = 0x31544143u;
 
 struct MapDesc {
@@ -974,7 +973,6 @@ __device__ int termination_captured(const Lds &L, const Params &p, int S, int la
 }
 
 // ------------------------------------------------------------------ physics -------------------
-__device__ __forceinline__ int pair_index(int A, int i, int j) { return i * A - i * (i + 1) / 2 + (j - i - 1); }
 
 // closest hull feature + [CP ClosestPointsNew] -> contact of [CP CircleToPoly].
 // Called wave-uniformly; lane i evaluates hull edge i (ClosestT / LerpT of its Minkowski edge), the
@@ -1407,12 +1405,6 @@ extern "C" int cat_debug_spread(unsigned long long *out, int n)
 #endif
 // Workgroup control words (LDS, L.ctrl): lane 0 operates, the result is broadcast.  Relaxed accesses; the
 // callers place the workgroup-scope release / acquire fences where data is handed over.
-__device__ __forceinline__ int ctrl_peek(const int *w, int lane)
-{
-    int v = 0;
-    if (lane == 0) v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return uni(v);
-}
 __device__ __forceinline__ int ctrl_add(int *w, int lane)   // fetch-and-increment
 {
     int v = 0;
@@ -1633,7 +1625,7 @@ template <class D>
 __device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
                                            const GridDesc &gd, int env, int wave, int lane)
 {
-    const int S = md.S, A = D::A(p);
+    const int A = D::A(p);
     load_state<D>(L, p, env, lane);
     const unsigned rc = (unsigned)(uni(L.cnt[1]) + 1);
     spawn_and_reset<D>(L, p, la, md, env, rc, lane);
