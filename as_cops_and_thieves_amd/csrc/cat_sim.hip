@@ -433,16 +433,19 @@ constexpr int kPassJ = 8;           // candidate positions per ray per pass
 // classifies every edge (can the segment cross its face line / can it touch its corner circle), then
 // the exact face test and the exact corner test each run once per surviving candidate (ascending edge
 // order, so "a later face overwrites" is kept) instead of being entered from inside every edge iteration.
-__device__ __forceinline__ void poly_query_feat(const Lds &L, int sh, double r, double ax, double ay,
+// An agent's circle goes through the same code as a hull with no edges and one "corner" (its cached centre, radius
+// r = the agent radius): the lanes of a round hold walls and agents side by side, and a separate circle path would be
+// executed for the whole wave whenever one lane needs it.  cx, cy: that centre (ignored for walls).
+__device__ __forceinline__ void poly_query_feat(const Lds &L, bool wall, int sh, double r, double cx, double cy, double ax, double ay,
                                                 double bx, double by, double r2, double &alpha, int &feat)
 {
-    const int fc = L.fc[sh], first = fc & 0xFFFF, count = fc >> 16;
+    const int fc = wall ? L.fc[sh] : 0, first = fc & 0xFFFF, count = fc >> 16;
     const double rsum = r + r2, rr = rsum * rsum;
     // conservative f32 pre-test for the bevels (see poly_segment_query)
     const float dxf = (float)(bx - ax), dyf = (float)(by - ay);
     const float thr = ((float)rsum + 0.01f) * sqrtf(dxf * dxf + dyf * dyf) * 1.00001f + 0.25f;
     const bool bevels = rsum > 0.0;
-    unsigned pm = 0u, vm = 0u;
+    unsigned pm = 0u, vm = wall ? 0u : 1u;
     const double *pl0 = L.planes + 8 * first;
     {
         const double *pl = pl0;
@@ -481,7 +484,8 @@ __device__ __forceinline__ void poly_query_feat(const Lds &L, int sh, double r, 
     while (vm) {   // [CP CircleSegmentQuery] on the corner circle
         const int i = __builtin_ctz(vm);
         vm &= vm - 1;
-        const double2 v = *reinterpret_cast<const double2 *>(pl0 + 8 * i + 2);
+        double2 v = *reinterpret_cast<const double2 *>(pl0 + 8 * i + 2);
+        if (!wall) { v.x = cx; v.y = cy; }
         const double dax = ax - v.x, day = ay - v.y, dbx = bx - v.x, dby = by - v.y;
         const double dada = dax * dax + day * day, dadb = dax * dbx + day * dby, dbdb = dbx * dbx + dby * dby;
         const double qa = dada - 2.0 * dadb + dbdb;
@@ -787,17 +791,14 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
                     double alpha = 2.0;   // 2.0 = no hit (never below a best alpha <= 1)
                     int feat = 0;
                     {
-                        if (id < S) {
-                            if (id == near0 || id == near1) { alpha = 0.0; feat = kFeatNear; }
-                            else { int f; poly_query_feat(L, id, wall_r, ax, ay, cbx, cby, r2, alpha, f); feat = f < 0 ? 0 : f; }
-                        } else {
-                            const int j = id - S;
-                            if ((dnear_mask >> j) & 1u) { alpha = 0.0; feat = kFeatNear; }
-                            else {
-                                SegInfo ci = {0, 1.0, cbx, cby};
-                                circle_segment_query(L.ftc[2 * j], L.ftc[2 * j + 1], rc, ax, ay, cbx, cby, r2, ci);
-                                if (ci.hit) alpha = ci.alpha;
-                            }
+                        const bool wall = id < S;
+                        const int j = wall ? 0 : id - S;
+                        const bool inside = wall ? (id == near0 || id == near1) : (((dnear_mask >> j) & 1u) != 0u);
+                        if (inside) { alpha = 0.0; feat = kFeatNear; }
+                        else {   // an accepted circle hit at alpha == 1 could never beat the initial best of 1: "t < 1" is equivalent
+                            int f;
+                            poly_query_feat(L, wall, wall ? id : 0, wall ? wall_r : rc, L.ftc[2 * j], L.ftc[2 * j + 1], ax, ay, cbx, cby, r2, alpha, f);
+                            feat = f < 0 ? 0 : f;
                         }
                     }
                     L.ialpha[t] = alpha; L.itm[t] = (unsigned short)((id << 6) | feat);
@@ -826,18 +827,16 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
             const double t = best_a;
             double px = bx, py = by;  // alpha = 0 hits keep the segment end as their point
             if (f != kFeatNear) {
-                if (best < S) {
-                    const int fc = L.fc[best], first = fc & 0xFFFF, count = fc >> 16;
-                    if (f < count) {
-                        const double2 n = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f));
-                        px = (ax * (1.0 - t) + bx * t) - n.x * r2;
-                        py = (ay * (1.0 - t) + by * t) - n.y * r2;
-                    } else {
-                        const double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f - count) + 2);
-                        circle_hit_point(v.x, v.y, ax, ay, bx, by, t, r2, px, py);
-                    }
-                } else {
-                    circle_hit_point(L.ftc[2 * (best - S)], L.ftc[2 * (best - S) + 1], ax, ay, bx, by, t, r2, px, py);
+                const bool wall = best < S;
+                const int fc = wall ? L.fc[best] : 0, first = fc & 0xFFFF, count = fc >> 16;
+                if (wall && f < count) {
+                    const double2 n = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f));
+                    px = (ax * (1.0 - t) + bx * t) - n.x * r2;
+                    py = (ay * (1.0 - t) + by * t) - n.y * r2;
+                } else {   // corner circle of the hull or the agent's circle: the same formula around a different centre
+                    double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + (wall ? f - count : 0)) + 2);
+                    if (!wall) { v.x = L.ftc[2 * (best - S)]; v.y = L.ftc[2 * (best - S) + 1]; }
+                    circle_hit_point(v.x, v.y, ax, ay, bx, by, t, r2, px, py);
                 }
             }
             d16 = obs_distance_f16(px, py, ax, ay);
