@@ -869,17 +869,22 @@ __device__ void rewards_and_positions(const Lds &L, const Params &p, const Launc
 {
     const int A = D::A(p);
     late.reward = 0.0f; late.tp16 = 0;
+    GAS const float *cop_lut = G(p.cop_lut), *thief_lut = G(p.thief_lut);   // both uniform: scalar loads, one vector load below
     if (rew_mode && lane < A && la.out.reward) {
         const unsigned my_dmin = L.dmin[lane];
         const bool is_cop = lane < D::n_cops(p);
         float r;
         if (captured) r = is_cop ? 1.0f : -1.0f;
         else if (timeout) r = is_cop ? -1.0f : 1.0f;
-        else if (my_dmin < 0x10000u) r = G(is_cop ? p.cop_lut : p.thief_lut)[my_dmin & 0x7FFFu];
+        else if (my_dmin < 0x10000u) r = (is_cop ? cop_lut : thief_lut)[my_dmin & 0x7FFFu];
         else r = is_cop ? (float)(-0.02 - 0.02) : (float)0.15;
         late.reward = r;
     }
     if (lane < 2 * A) late.tp16 = f64_to_f16(L.fpos[lane]);
+    // Wait for the LUT value HERE, while no store is in flight: a load still pending when the write-back stores
+    // start makes the compiler's (in-order) vmcnt waits sit on the acknowledgement of every store issued before
+    // them -- 18 k cycles per slot in the write-back before this line.
+    asm volatile("" : "+v"(late.reward));
 }
 
 // LDS -> HBM copy of n bytes with the widest store both sides allow (LDS side is 16-byte aligned)
@@ -904,6 +909,8 @@ __device__ __forceinline__ void emit_observations(const Lds &L, const Params &p,
                                                   int rew_mode, const LateOut &late)
 {
     const int A = D::A(p), R = D::R(p);
+    if (rew_mode && lane < A && la.out.reward) la.out.reward[(size_t)env * A + lane] = late.reward;
+    if (lane < 2 * A && la.out.team_positions) la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)late.tp16;
     // get_shared_observations (observation_spaces.py:98-129): first team member, roster order,
     // with a non-EMPTY ray supplies (type, distance); else EMPTY with the last member's distance
     for (int k = lane; k < R; k += kLanes) {
@@ -922,9 +929,6 @@ __device__ __forceinline__ void emit_observations(const Lds &L, const Params &p,
     if (la.out.obs_type) wide_store(la.out.obs_type + g0, L.ot, A * R, lane);
     if (la.out.shared_distance) wide_store(la.out.shared_distance + (size_t)env * 2 * R, L.sd, 2 * R * 2, lane);
     if (la.out.shared_type) wide_store(la.out.shared_type + (size_t)env * 2 * R, L.st, 2 * R, lane);
-    // last: the reward comes from a LUT load issued by rewards_and_positions, whose latency the stores above cover
-    if (rew_mode && lane < A && la.out.reward) la.out.reward[(size_t)env * A + lane] = late.reward;
-    if (lane < 2 * A && la.out.team_positions) la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)late.tp16;
 }
 
 // ------------------------------------------------------------------ termination ---------------

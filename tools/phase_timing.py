@@ -37,5 +37,5 @@ names = {0: "stage_map", 1: "state -> LDS", 2: "termination+actions", 4: "agent 
 tot = sum(buf)
 for i in range(24):
     if buf[i]:
-        print(f"{names.get(i, i):22s} {buf[i] / T / N:10.0f} cycles/wave  {100.0 * buf[i] / tot:5.1f}%")
+        print(f"{str(names.get(i, i)):22s} {buf[i] / T / N:10.0f} cycles/wave  {100.0 * buf[i] / tot:5.1f}%")
 print(f"{'total':22s} {tot / T / N:10.0f} cycles/wave")
