@@ -865,11 +865,10 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
 // chunks left in L.dmin, and the f16 team positions (observation_spaces.py:92-95: positions BEFORE Space.step).
 template <class D>
 __device__ void rewards_and_positions(const Lds &L, const Params &p, const LaunchArgs &la, int lane, int rew_mode,
-                                      int captured, int timeout, LateOut &late)
+                                      int captured, int timeout, GAS const float *cop_lut, GAS const float *thief_lut, LateOut &late)
 {
     const int A = D::A(p);
     late.reward = 0.0f; late.tp16 = 0;
-    GAS const float *cop_lut = G(p.cop_lut), *thief_lut = G(p.thief_lut);   // both uniform: scalar loads, one vector load below
     if (rew_mode && lane < A && la.out.reward) {
         const unsigned my_dmin = L.dmin[lane];
         const bool is_cop = lane < D::n_cops(p);
@@ -1437,6 +1436,8 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
 {
     const int W = p.wpb, S = md.S;
     const int nchunks = D::A(p) * ((D::R(p) + kLanes - 1) / kLanes);
+    // fetched now, used at the write-back: the reward lookup then costs one global round trip, not two
+    GAS const float *cop_lut = launder(G(p.cop_lut)), *thief_lut = launder(G(p.thief_lut));
     unsigned fin_mask = 0u;
     bool own_first = true;
     for (;;) {
@@ -1488,7 +1489,7 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         const int e_s = uni(L.ctrl[4 * slot + 3]);
         const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
         LateOut late;
-        rewards_and_positions<D>(Ls, p, la, lane, tick, captured2, timeout2, late);
+        rewards_and_positions<D>(Ls, p, la, lane, tick, captured2, timeout2, cop_lut, thief_lut, late);
         const unsigned char term = (unsigned char)(captured2 || timeout2);
         if (lane == 0) {   // a slot that went through a reset (rcount >= 0) starts its new episode: base_env.py:350
             Ls.cnt[0] = step2; Ls.cnt[2] = rcount >= 0 ? 0 : term;
