@@ -1464,13 +1464,12 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         }
         own_first = false;
         slot = uni(slot);
-        const int e_s = uni(L.ctrl[4 * slot + 3]);
-        const int last_unit = uni(L.ctrl[4 * slot + 2]) - 1;
+        const int e_s = __builtin_amdgcn_readlane(e_l, slot);              // the scan already holds them
+        const int last_unit = __builtin_amdgcn_readlane(nu_l, slot) - 1;
         if (slot != wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // another wave's slot
         const Lds Ls = carve<D>(p, smem, md, slot, wave);
-        for (;;) {
-            const int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
-            if (c > last_unit) break;
+        int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
+        while (c <= last_unit) {
             if (c < nchunks) fan_chunk<D>(Ls, p, la, gd, e_s, lane, S, tick, c, pc);   // entity.py:143-144, base_env.py:388-390 / :334-344
             else {
                 PHASE(pc, 9);
@@ -1478,7 +1477,14 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
                 PHASE(pc, 10);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the unit's LDS writes, before it counts as done
-            if (ctrl_add(&L.ctrl[4 * slot + 1], lane) == last_unit) { fin_mask |= 1u << slot; break; }   // no unit is left unclaimed
+            // "done" and the next claim in one LDS round trip (if this was the slot's last unit the claim returns past the end)
+            int d = 0;
+            if (lane == 0) {
+                d = __hip_atomic_fetch_add(&L.ctrl[4 * slot + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                c = __hip_atomic_fetch_add(&L.ctrl[4 * slot + 0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            d = uni(d); c = uni(c);
+            if (d == last_unit) fin_mask |= 1u << slot;   // this wave completed the slot
         }
     }
     if (fin_mask) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the other waves' units of those slots
