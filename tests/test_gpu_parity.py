@@ -295,3 +295,12 @@ def test_one_cop_vs_one_thief_on_squarinth():
     cfg = SimConfig(n_envs=20, n_cops=1, n_thieves=1, n_rays=90, max_step_count=35, seed=13)
     stats = _run(cfg, [m], np.zeros(20, np.int32), ticks=80, rng=np.random.default_rng(11), auto_reset=True)
     assert stats["done"] >= 20
+
+
+def test_maximum_rays_and_agents_together(tmp_path):
+    """CAT_MAX_AGENTS x CAT_MAX_RAYS: 8 agents, 512 rays (64 ray chunks per env, 18 KB of output staging per slot:
+    the workgroup shrinks to fit LDS)."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    m = _arena_map(tmp_path, 4, 4)
+    cfg = SimConfig(n_envs=6, n_cops=4, n_thieves=4, n_rays=512, max_step_count=20, seed=3)
+    _run(cfg, [m], np.zeros(6, np.int32), ticks=25, rng=np.random.default_rng(4), auto_reset=True)
