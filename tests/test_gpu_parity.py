@@ -304,3 +304,27 @@ def test_maximum_rays_and_agents_together(tmp_path):
     m = _arena_map(tmp_path, 4, 4)
     cfg = SimConfig(n_envs=6, n_cops=4, n_thieves=4, n_rays=512, max_step_count=20, seed=3)
     _run(cfg, [m], np.zeros(6, np.int32), ticks=25, rng=np.random.default_rng(4), auto_reset=True)
+
+
+def test_empty_inputs():
+    """No env to create is a configuration error (clear message, no crash); a reset whose mask selects nothing
+    changes nothing; a step of a single env works (one busy wave, fifteen helpers)."""
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.sim import CatSim
+    m = compiled("squarinth")
+    with pytest.raises(RuntimeError):
+        CatSim(SimConfig(n_envs=0, n_rays=16), [m], device="cuda:0")
+    gpu, cpu = _pair(SimConfig(n_envs=1, n_rays=90, max_step_count=30, seed=8), [m])
+    g = gpu.reset(); c = cpu.reset()
+    for t in range(5):
+        a = cpu.random_actions(t)
+        g = gpu.step(torch.from_numpy(a)); c = cpu.step(a)
+    before = {k: v.clone() for k, v in gpu.get_state().items()}
+    obs_before = gpu.out["obs_distance"].clone()
+    gpu.reset(mask=torch.zeros(1, dtype=torch.uint8, device="cuda:0"))
+    torch.cuda.synchronize()
+    after = gpu.get_state()
+    assert all(torch.equal(before[k], after[k]) for k in before) and torch.equal(obs_before, gpu.out["obs_distance"])
+    assert_outputs_equal(to_np(g), c, ctx="single env")
+    gpu.close()
