@@ -76,6 +76,10 @@ def lib() -> C.CDLL:
         raise NativeLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the env core.")
+    # torch first: it ships its own HIP/HSA runtime, and the runtime loaded FIRST serves every library of the process
+    # (same soname).  Loading this library before torch would bring the system runtime in, torch's remaining bundled
+    # pieces would then start a second HSA instance, and one of the two sees no device.
+    import torch  # noqa: F401
     L = C.CDLL(str(LIB_PATH))
     vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
     L.cat_abi_version.restype = i32
