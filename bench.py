@@ -134,7 +134,17 @@ def main() -> None:
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+                probe = torch.zeros(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe)                                                        # fails here if RCCL cannot start
+                torch.cuda.synchronize()
+            except Exception as exc:   # the simulator needs no collective: only the timing barrier / MAX does
+                print(f"[bench] RCCL unavailable ({exc!r}); timing reductions over gloo", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo")
+                rehearse = True   # CPU tensors for the reductions
     else:
         torch.cuda.set_device(0)
         local_rank = 0
