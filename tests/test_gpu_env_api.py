@@ -181,3 +181,42 @@ def test_full_size_properties_4096_envs():
         cpu.set_state(tc=tc[e:e + 1])
         for i in range(3):
             assert not cpu.point_query_any(0, i, pos[e, i], 0.5)
+
+
+@pytest.mark.parametrize("label,names,cops,thieves,N", [
+    ("configs[3]", ["grandbyrinth"], 3, 2, 8192),
+    ("configs[4]", ["agh-map", "grandbyrinth", "labyrinth", "lbirinth", "squarinth"], 2, 1, 16384),
+])
+def test_full_size_other_baseline_configs(label, names, cops, thieves, N):
+    """BASELINE configs[3] (3v2, 8192 envs) and configs[4] (five maps interleaved, 16384 envs) at full size:
+    same seed -> same bits, and sampled slots equal a one-env oracle run keyed with that slot's global env id."""
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.sim import CatSim
+    from oracle.cat_oracle import OracleSim
+    maps = [compiled(n, cops, thieves) for n in names]
+    slot = (np.arange(N) % len(maps)).astype(np.int32)
+    R, T = 64, 24
+    cfg = SimConfig(n_envs=N, n_cops=cops, n_thieves=thieves, n_rays=R, max_step_count=15, seed=7)
+
+    def run():
+        sim = CatSim(cfg, maps, slot, device="cuda:0")
+        sim.reset()
+        for t in range(T):
+            sim.step_fused(None, tick=t, auto_reset=True)       # in-kernel Philox actions + in-kernel auto-reset
+        res = {k: v.clone() for k, v in sim.out.items()}, {k: v.clone() for k, v in sim.get_state().items()}
+        sim.close()
+        return res
+
+    (o1, s1), (o2, s2) = run(), run()
+    assert all(torch.equal(o1[k], o2[k]) for k in o1) and all(torch.equal(s1[k], s2[k]) for k in s1), label
+    assert int(s1["reset_count"].min()) >= 2                      # every slot saw at least one auto-reset (truncation at 15)
+    for k in (0, N // 3 + 1, N - 1):
+        cpu = OracleSim(SimConfig(n_envs=1, n_cops=cops, n_thieves=thieves, n_rays=R, max_step_count=15, seed=7,
+                                  env_id_offset=k), [maps[slot[k]]])
+        cpu.reset()
+        for t in range(T):
+            c = cpu.step(cpu.random_actions(t))
+            cpu.reset(mask=c["terminated"].copy())
+        assert np.array_equal(cpu.get_state()["pos"][0], s1["pos"][k].cpu().numpy()), (label, k)
+        assert np.array_equal(cpu.out["obs_distance"][0].view(np.uint16), o1["obs_distance"][k].cpu().numpy().view(np.uint16)), (label, k)
