@@ -195,6 +195,17 @@ def main() -> None:
     tick_ms = sum(hip.elapsed_ms(a, b) for a, b in ev.values()) / len(ev)
     episodes = int(sim.get_state()["reset_count"].sum().item())
 
+    copy_gbs = None
+    if rank == 0 and world == 1:   # the HBM peak as a stream copy measures it on this box (read + write bytes)
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev); b = torch.empty_like(a)   # 1 GiB each
+        b.copy_(a); torch.cuda.synchronize(dev)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            b.copy_(a)
+        c1.record(); torch.cuda.synchronize(dev)
+        copy_gbs = 10 * 2 * a.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del a, b
     if rank == 0:
         A, R = cfg.n_agents, cfg.n_rays
         bytes_launch = algorithmic_bytes_per_env_step(A, R) * cfg.n_envs
@@ -222,6 +233,8 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "tick_kernel", "kernel_ms": tick_ms, "kernel_launches_timed": len(ev),
                          "algorithmic_bytes_per_launch": bytes_launch, "valu": valu,
+                         "hbm_stream_copy_GBs": copy_gbs,
+                         "frac_of_stream_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "note": "path is FP64-VALU/LDS bound, not HBM bound (SURVEY 8d); fraction reported as contracted"},
         }
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
