@@ -328,3 +328,14 @@ def test_empty_inputs():
     assert all(torch.equal(before[k], after[k]) for k in before) and torch.equal(obs_before, gpu.out["obs_distance"])
     assert_outputs_equal(to_np(g), c, ctx="single env")
     gpu.close()
+
+
+@pytest.mark.parametrize("name", ["labyrinth", "agh-map"])
+def test_long_rollout_soak(name):
+    """2000 ticks with auto-reset, compared every 50 ticks and at the end: rare paths (arbiter cache eviction and
+    ageing, many captures and respawns, grazing rays) accumulate over a long rollout."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    m = compiled(name)
+    cfg = SimConfig(n_envs=32, n_rays=64, max_step_count=120, seed=29)
+    stats = _run(cfg, [m], np.zeros(32, np.int32), ticks=2000, rng=np.random.default_rng(7), check_every=50, auto_reset=True)
+    assert stats["done"] >= 32 * 10
