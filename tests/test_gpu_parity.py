@@ -339,3 +339,32 @@ def test_long_rollout_soak(name):
     cfg = SimConfig(n_envs=32, n_rays=64, max_step_count=120, seed=29)
     stats = _run(cfg, [m], np.zeros(32, np.int32), ticks=2000, rng=np.random.default_rng(7), check_every=50, auto_reset=True)
     assert stats["done"] >= 32 * 10
+
+
+def test_long_rollout_soak_single_launch_step():
+    """The one-launch rollout step (in-kernel Philox actions, in-kernel auto-reset) against oracle step + masked reset,
+    1500 ticks on the mixed five-map batch."""
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    names = ["agh-map", "grandbyrinth", "labyrinth", "lbirinth", "squarinth"]
+    maps = [compiled(n) for n in names]
+    n = 40
+    slot = (np.arange(n) % len(maps)).astype(np.int32)
+    cfg = SimConfig(n_envs=n, n_rays=64, max_step_count=90, seed=41)
+    gpu, cpu = _pair(cfg, maps, slot)
+    gpu.reset(); cpu.reset()
+    obs_keys = ("obs_distance", "obs_type", "hit_shape", "shared_distance", "shared_type", "team_positions")
+    done = 0
+    for t in range(1500):
+        g = gpu.step_fused(None, tick=t, auto_reset=True)
+        c = cpu.step(cpu.random_actions(t))
+        term = c["terminated"].copy()
+        done += int(term.sum())
+        keep = {k: c[k].copy() for k in ("reward", "terminated", "truncated", "winner")}
+        cpu.reset(mask=term)
+        if t % 100 == 0 or t == 1499:
+            torch.cuda.synchronize()
+            assert_outputs_equal(to_np(g), {**cpu.out, **keep}, keys=obs_keys + tuple(keep), ctx=f"tick {t}")
+            assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"tick {t}")
+    assert done >= n * 10
+    gpu.close()
