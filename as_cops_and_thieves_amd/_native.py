@@ -12,6 +12,8 @@ from .config import C_FIELDS_F64, C_FIELDS_I32
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 LIB_PATH = PKG / "libcat_sim.so"
+if os.environ.get("CAT_SIM_LIB"):          # diagnostic builds (tools/ab_kernel.sh): another build of the same source
+    LIB_PATH = Path(os.environ["CAT_SIM_LIB"]).resolve()
 SRC = PKG / "csrc" / "cat_sim.hip"
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared"]
 

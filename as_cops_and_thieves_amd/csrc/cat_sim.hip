@@ -736,6 +736,7 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
                 if (rel < dc) dynmask |= 1u << j;
             }
         const int cnt = cnt_w + __popc(dynmask);
+        PHASE(pc, 20);
         double best_a = 1.0;
         int best_fi = -1;   // id << 6 | feature of the accepted item
         int jj0 = 0;
@@ -1487,6 +1488,7 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
             if (d == last_unit) fin_mask |= 1u << slot;   // this wave completed the slot
         }
     }
+    PHASE(pc, 16);
     if (fin_mask) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the other waves' units of those slots
     while (fin_mask) {
         const int slot = uni(__builtin_ctz(fin_mask));
@@ -1496,13 +1498,16 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
         LateOut late;
         rewards_and_positions<D>(Ls, p, la, lane, tick, captured2, timeout2, cop_lut, thief_lut, late);
+        PHASE(pc, 17);
         const unsigned char term = (unsigned char)(captured2 || timeout2);
         if (lane == 0) {   // a slot that went through a reset (rcount >= 0) starts its new episode: base_env.py:350
             Ls.cnt[0] = step2; Ls.cnt[2] = rcount >= 0 ? 0 : term;
             if (rcount >= 0) Ls.cnt[1] = rcount;
         }
         store_state<D>(Ls, p, e_s, lane);
+        PHASE(pc, 18);
         emit_observations<D>(Ls, p, la, e_s, lane, tick, late);
+        PHASE(pc, 19);
         if (tick && lane == 0) {
             if (la.out.terminated) la.out.terminated[e_s] = term;       // entity.py:146
             if (la.out.truncated) la.out.truncated[e_s] = (unsigned char)timeout2;  // :397

@@ -1,284 +1,454 @@
-"""MAPPO on the batched env: device rollout buffer, GAE scan, PPO minibatch
-update, bf16 autocast, one flat gradient all-reduce per optimiser step (RCCL over xGMI when
-``torch.distributed`` is initialised with the ``nccl`` backend).
+"""MAPPO on the batched env.
 
-Hyper-parameters default to the reference's ``CFG_AGENT`` (``src/configs/mappo_config.py:41-50``
-over skrl's MAPPO defaults: discount 0.99, lambda 0.95): rollouts 4096, 4 epochs x 4 minibatches,
-lr 1e-4, ratio_clip 0.15, value_loss_scale 0.5, entropy_loss_scale 0.02, grad_norm_clip 0.5,
-KL early stop 0.015.  As in skrl's MAPPO every agent owns a policy and a value network and is
-optimised independently; the critic consumes the team-shared channels (``packing.py`` layout).
-The reference's ``rollouts`` counts ticks of ONE env; here a rollout is ``horizon`` ticks of
-``num_envs`` envs, so ``horizon * num_envs`` plays that role.
+What the reference runs (``src/self_play_driver.py`` -> ``training/orchestration.py`` ->
+``utils/agent_learning_utils.py:172-230`` -> skrl ``MAPPO`` + ``SequentialTrainer``) and what this module
+restates, on the device env:
+
+* every agent owns a policy and a value network and is optimised independently (skrl MAPPO); here the agents of
+  one ROLE share one stacked network evaluation (``stacked.py``) -- same per-agent parameters, one launch;
+* per-role hyper-parameters ``CFG_AGENT`` / ``CFG_AGENT_COP`` / ``CFG_AGENT_THIEF``
+  (``src/configs/mappo_config.py:5-50``; the driver passes ``CFG_AGENT`` for both roles, which is the default);
+* the timestep-driven schedule of one ``trainer.train()`` call: ``random_timesteps`` uniformly random actions,
+  no update before ``learning_starts`` (``mappo_config.py:9-10``), all policies frozen until
+  ``policy_freeze_duration`` and the value networks released at ``opponent_freeze_duration`` (``CFG_TRAINER``,
+  ``mappo_config.py:52-63``; the reference implements the two durations by a local patch to skrl's trainers,
+  ``README.md:58-154``).  A timestep is one tick of the env batch, as in the reference's single-env loop;
+* PPO as skrl writes it [SKRL-RECALL: skrl is not installed here]: GAE(0.99, 0.95) with per-agent advantage
+  normalisation, clipped surrogate, entropy bonus, scaled MSE value loss, one joint gradient-norm clip over the
+  agent's policy + value parameters, Adam, and the per-minibatch KL early stop ("break": the rest of the epoch's
+  minibatches of THAT agent are skipped, the next epoch runs again).
+
+MI355X shape of the update: one flat fp32 master buffer per role, bf16 compute copy, gradients accumulate into one
+flat buffer, ONE all-reduce per optimiser step (gradients and the KL statistics in the same buffer, so every rank
+takes the same early-stop decision), per-agent clip and a masked Adam as a few flat kernels, KL / freeze decisions
+as device-side gates -- no host synchronisation inside an update, so the minibatch step is captured in HIP graphs.
 """
 from __future__ import annotations
 
 import dataclasses
-from typing import Dict, List, Optional
+import warnings
+from typing import Dict, List, Optional, Tuple
 
 import torch
-import torch.nn as nn
 
 from .. import packing
-from .models import LSTMPolicy, LSTMValue
+from .stacked import (FlatParams, StackedNet, agent_state_dict, init_from_modules, load_agent_state_dict,
+                      role_param_shapes)
 
 
 @dataclasses.dataclass
-class MAPPOConfig:
-    horizon: int = 16                 # ticks per rollout and BPTT length (reference sequence_length = 16)
+class RoleConfig:
+    """skrl MAPPO agent configuration of one role (``src/configs/mappo_config.py:5-50``)."""
     learning_epochs: int = 4
     mini_batches: int = 4
-    discount_factor: float = 0.99
-    gae_lambda: float = 0.95
+    discount_factor: float = 0.99          # skrl MAPPO_DEFAULT_CONFIG
+    gae_lambda: float = 0.95               # skrl MAPPO_DEFAULT_CONFIG ("lambda")
     learning_rate: float = 1e-4
     ratio_clip: float = 0.15
     value_loss_scale: float = 0.5
     entropy_loss_scale: float = 0.02
     grad_norm_clip: float = 0.5
     kl_threshold: float = 0.015
-    random_timesteps: int = 0         # reference: 10 000 uniformly random ticks first
-    learning_starts: int = 0          # reference: 15 000
-    frozen_roles: tuple = ()          # e.g. ("thief",): roles whose policy is not updated (freeze schedule)
-    autocast_bf16: bool = True
-    graph_rollout: bool = True        # on a GPU, capture the T-tick rollout (env ticks + all networks) in one HIP graph
-    reference_q11: bool = False       # True: every critic sees the alphabetically first agent's channels (quirk Q11)
+    random_timesteps: int = 10_000
+    learning_starts: int = 15_000
+
+
+CFG_AGENT = RoleConfig()                                                                       # mappo_config.py:41-50
+CFG_AGENT_COP = RoleConfig()                                                                   # :19-28
+CFG_AGENT_THIEF = RoleConfig(learning_epochs=3, mini_batches=8, entropy_loss_scale=0.01,      # :30-39
+                             learning_rate=3e-4, ratio_clip=0.2)
+
+
+@dataclasses.dataclass
+class TrainerConfig:
+    """``CFG_TRAINER`` (``mappo_config.py:52-63``) plus the build-side knobs."""
+    timesteps: int = 100_000               # TrainingConfig.training_timesteps_per_role_training
+    opponent_freeze_duration: int = 15_000
+    policy_freeze_duration: int = 15_000
+    horizon: int = 16                      # ticks per rollout = BPTT window (reference LSTM sequence_length)
+    compute_bf16: bool = True              # bf16 compute copy of the weights on a GPU (fp32 master + fp32 Adam)
+    graph_rollout: bool = True             # capture the T-tick rollout (env ticks + all networks) in one HIP graph
+    graph_update: bool = True              # capture the minibatch step (forward, losses, backward / clip, Adam)
+    reference_q11: bool = False            # True: every critic sees the alphabetically first agent's channels (quirk Q11)
+    random_action_roles: Tuple[str, ...] = ()   # roles that act uniformly at random throughout (a fixed random opponent)
 
 
 def compute_gae(rewards: torch.Tensor, values: torch.Tensor, dones: torch.Tensor, last_values: torch.Tensor,
                 gamma: float, lam: float):
-    """Reverse scan over the time axis.  rewards/values/dones: [T, N]; last_values: [N].
-    ``dones[t]`` marks that the episode ended with tick t (no bootstrap across it)."""
-    T = rewards.shape[0]
+    """Reverse scan over the time axis (dim -2).  rewards/values: [..., T, N]; dones: [T, N] (the episode ended with
+    tick t: no bootstrap across it); last_values: [..., N]."""
+    T = rewards.shape[-2]
     adv = torch.zeros_like(rewards)
     last = torch.zeros_like(last_values)
     nxt = last_values
     for t in range(T - 1, -1, -1):
         nd = 1.0 - dones[t].to(rewards.dtype)
-        delta = rewards[t] + gamma * nxt * nd - values[t]
+        delta = rewards[..., t, :] + gamma * nxt * nd - values[..., t, :]
         last = delta + gamma * lam * nd * last
-        adv[t] = last
-        nxt = values[t]
+        adv[..., t, :] = last
+        nxt = values[..., t, :]
     return adv, adv + values
 
 
-class _FlatGradSync:
-    """One fused all-reduce (sum, then / world) of all gradients of a parameter set."""
+def _dist_ready() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
-    def __init__(self, params: List[nn.Parameter]):
-        self.params = [p for p in params if p.requires_grad]
 
-    def __call__(self) -> None:
+class RoleLearner:
+    """The G agents of one role: stacked policy + value networks over one flat parameter buffer, their Adam state,
+    the role's rollout buffers and its PPO minibatch step."""
+
+    BETA1, BETA2, EPS = 0.9, 0.999, 1e-8    # torch.optim.Adam defaults (what skrl constructs)
+
+    def __init__(self, role: str, agents: List[str], indices: List[int], R: int, N: int, T: int, cfg: RoleConfig,
+                 device: torch.device, compute_dtype: torch.dtype, seeds: List[int]):
+        self.role, self.agents, self.indices, self.cfg = role, agents, indices, cfg
+        self.G, self.R, self.N, self.T, self.device = len(agents), R, N, T, device
+        self.fp = FlatParams(role_param_shapes(R), self.G, device, compute_dtype)
+        init_from_modules(self.fp, R, seeds)
+        self.policy, self.value = StackedNet("policy", R, self.fp), StackedNet("value", R, self.fp)
+        G, P = self.G, self.fp.P
+        f32 = dict(dtype=torch.float32, device=device)
+        self.m, self.v, self.steps = torch.zeros(G, P, **f32), torch.zeros(G, P, **f32), torch.zeros(G, P, **f32)
+        self.col_policy, self.col_value = self.fp.column_mask("policy."), self.fp.column_mask("value.")
+        self.col_train = torch.ones(P, **f32)                  # 1 where the parameter is trainable right now
+        self.epoch_active = torch.ones(G, **f32)               # KL early stop: 0 = skip the rest of this epoch
+        self.ar = torch.zeros(G, P + 1, **f32)                 # all-reduce buffer: fp32 gradients | KL
+        self.stat = torch.zeros(3, G, **f32)                   # last policy loss, value loss, KL per agent
+        self.policy_frozen, self.value_frozen = False, False
+        B = N // cfg.mini_batches
+        self.B = B
+        self.idx = torch.zeros(B, dtype=torch.long, device=device)
+        self.buf = {"pin": torch.zeros(G, T, N, 2 * R, **f32), "vin": torch.zeros(G, T, N, 4 * R, **f32),
+                    "act": torch.zeros(G, T, N, dtype=torch.long, device=device), "logp": torch.zeros(G, T, N, **f32),
+                    "val": torch.zeros(G, T, N, **f32), "rew": torch.zeros(G, T, N, **f32),
+                    "adv": torch.zeros(G, T, N, **f32), "ret": torch.zeros(G, T, N, **f32)}
+        self.p_state = self.policy.initial_state(N)            # carried across rollouts
+        self.v_state = self.value.initial_state(N)
+        self.p0 = tuple(s.clone() for s in self.p_state)       # recurrent state at the start of the stored rollout
+        self.v0 = tuple(s.clone() for s in self.v_state)
+        self._graphs = None
+
+    # ------------------------------------------------------------------ freezing (skrl Model.freeze_parameters)
+    def set_frozen(self, policy: Optional[bool] = None, value: Optional[bool] = None) -> None:
+        if policy is not None:
+            self.policy_frozen = policy
+        if value is not None:
+            self.value_frozen = value
+        self.col_train.copy_(self.col_policy * (0.0 if self.policy_frozen else 1.0)
+                             + self.col_value * (0.0 if self.value_frozen else 1.0))
+
+    # ------------------------------------------------------------------ the PPO minibatch step
+    def _step_forward_backward(self) -> None:
+        """zero grads, gather the minibatch ``self.idx`` (sequences = env slots), forward, losses, backward; leaves the
+        fp32 gradients and the per-agent KL in ``self.ar``."""
+        cfg, b, idx = self.cfg, self.buf, self.idx
+        self.fp.grad.zero_()
+        sel = lambda x: x.index_select(2, idx)
+        keep = (~self.start.index_select(1, idx)).to(torch.float32)                    # [T, B]
+        st = lambda s: s.index_select(2, idx)
+        logits, _ = self.policy.forward(sel(b["pin"]), (st(self.p0[0]), st(self.p0[1])), keep)
+        values, _ = self.value.forward(sel(b["vin"]), (st(self.v0[0]), st(self.v0[1])), keep)
+        logp_all = torch.log_softmax(logits.float(), dim=-1)                            # [G, T, B, 4]
+        logp = logp_all.gather(-1, sel(b["act"]).unsqueeze(-1)).squeeze(-1)
+        old = sel(b["logp"])
+        ratio = torch.exp(logp - old)
+        with torch.no_grad():
+            kl = ((ratio - 1) - (logp - old)).mean(dim=(1, 2))                          # [G]
+        adv = sel(b["adv"])
+        surr = torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.ratio_clip, 1 + cfg.ratio_clip))
+        policy_loss = -surr.mean(dim=(1, 2))
+        entropy = -(logp_all.exp() * logp_all).sum(-1).mean(dim=(1, 2))
+        value_loss = cfg.value_loss_scale * ((values.float().squeeze(-1) - sel(b["ret"])) ** 2).mean(dim=(1, 2))
+        (policy_loss - cfg.entropy_loss_scale * entropy + value_loss).sum().backward()   # agents share no parameter
+        with torch.no_grad():
+            self.ar[:, :-1].copy_(self.fp.grad)
+            self.ar[:, -1].copy_(kl)
+            self.stat[0].copy_(policy_loss); self.stat[1].copy_(value_loss)
+
+    @torch.no_grad()
+    def _step_apply(self) -> None:
+        """KL gate, joint policy+value gradient-norm clip per agent, masked Adam, refresh of the compute copy."""
+        cfg = self.cfg
+        kl = self.ar[:, -1]
+        self.stat[2].copy_(kl)
+        if cfg.kl_threshold:
+            self.epoch_active.mul_((kl <= cfg.kl_threshold).to(torch.float32))
+        g = self.ar[:, :-1] * self.col_train                                           # frozen parameters: no gradient
+        norm = g.norm(dim=1, keepdim=True)
+        g = g * torch.clamp(cfg.grad_norm_clip / (norm + 1e-6), max=1.0)                 # torch.nn.utils.clip_grad_norm_
+        gate = self.epoch_active.unsqueeze(1) * self.col_train                         # [G, P]: 1 = this entry steps
+        self.steps.add_(gate)
+        self.m.add_(gate * (1 - self.BETA1) * (g - self.m))
+        self.v.add_(gate * (1 - self.BETA2) * (g * g - self.v))
+        s = self.steps.clamp_min(1.0)
+        bc1, bc2 = 1 - self.BETA1 ** s, 1 - self.BETA2 ** s
+        denom = (self.v / bc2).sqrt_().add_(self.EPS)
+        self.fp.master.sub_(gate * cfg.learning_rate * (self.m / bc1) / denom)
+        self.fp.refresh()
+
+    def minibatch_step(self, use_graph: bool) -> None:
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= dist.get_world_size()
-        off = 0
-        for p, g in zip(self.params, grads):
-            n = g.numel()
-            p.grad = flat[off:off + n].view_as(g).clone()
-            off += n
+        multi = _dist_ready()
+        if use_graph and self._graphs is None:
+            self._graphs = self._capture()
+        if use_graph and self._graphs:
+            ga, gb = self._graphs
+            ga.replay()
+        else:
+            self._step_forward_backward()
+        if multi:
+            dist.all_reduce(self.ar, op=dist.ReduceOp.SUM)                             # RCCL over xGMI on a GPU node
+            self.ar.div_(dist.get_world_size())
+        if use_graph and self._graphs:
+            gb.replay()
+        else:
+            self._step_apply()
+
+    def _capture(self):
+        """Capture the two halves of the step in HIP graphs (``torch.cuda.CUDAGraph``).  Warm-up runs on a side stream
+        first (library workspaces, autograd buffers), as whole-network capture requires; the optimiser state the warm-up
+        touched is restored, so capturing does not train.  Returns () if the runtime refuses the capture."""
+        keep = [t.clone() for t in (self.fp.master, self.m, self.v, self.steps, self.epoch_active, self.ar, self.stat)]
+
+        def restore():
+            for dst, src in zip((self.fp.master, self.m, self.v, self.steps, self.epoch_active, self.ar, self.stat), keep):
+                dst.copy_(src)
+            self.fp.refresh()
+        try:
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._step_forward_backward()
+                    self._step_apply()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            restore()
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._step_forward_backward()
+            with torch.cuda.graph(gb):
+                self._step_apply()
+            torch.cuda.synchronize(self.device)
+            restore()
+            return ga, gb
+        except Exception as exc:   # noqa: BLE001 - keep training eagerly, but say so
+            warnings.warn(f"HIP-graph capture of the {self.role} PPO step failed ({exc!r}); running it eagerly")
+            torch.cuda.synchronize(self.device)
+            restore()
+            return ()
+
+    # ------------------------------------------------------------------ update of one rollout
+    def update(self, dones: torch.Tensor, starts: torch.Tensor, last_values: torch.Tensor, gen: torch.Generator,
+               use_graph: bool) -> None:
+        """dones/starts [T, N]; last_values [G, N] (bootstrap, already zeroed where the next tick starts an episode)."""
+        cfg, b = self.cfg, self.buf
+        adv, ret = compute_gae(b["rew"], b["val"], dones, last_values, cfg.discount_factor, cfg.gae_lambda)
+        mean = adv.mean(dim=(1, 2), keepdim=True)
+        std = adv.std(dim=(1, 2), keepdim=True)
+        b["adv"].copy_((adv - mean) / (std + 1e-8))                                     # skrl: per agent, whole memory
+        b["ret"].copy_(ret)
+        self.start = starts
+        for _ in range(cfg.learning_epochs):
+            self.epoch_active.fill_(1.0)
+            perm = torch.randperm(self.N, generator=gen).to(self.device)
+            for k in range(cfg.mini_batches):
+                self.idx.copy_(perm[k * self.B:(k + 1) * self.B])
+                self.minibatch_step(use_graph)
 
 
 class MAPPOTrainer:
-    def __init__(self, env, cfg: Optional[MAPPOConfig] = None, device=None, seed: int = 0):
-        self.env, self.cfg = env, cfg or MAPPOConfig()
+    """MAPPO over a ``VecCopsEnv`` (or any env with its surface): roles ``cop`` and ``thief``."""
+
+    def __init__(self, env, role_cfg: Optional[Dict[str, RoleConfig]] = None, trainer_cfg: Optional[TrainerConfig] = None,
+                 device=None, seed: int = 0):
+        self.env, self.tcfg = env, trainer_cfg or TrainerConfig()
         self.device = torch.device(device) if device is not None else getattr(env, "device", torch.device("cpu"))
         self.agents: List[str] = list(env.possible_agents)
         self.N = env.num_envs
         self.R = env.observation_spaces[self.agents[0]]["distance"].shape[0]
-        g = torch.Generator(device="cpu").manual_seed(seed)
+        role_cfg = role_cfg or {}
+        on_gpu = self.device.type == "cuda"
+        dt = torch.bfloat16 if (self.tcfg.compute_bf16 and on_gpu) else torch.float32
+        self.roles: Dict[str, RoleLearner] = {}
+        for role in ("cop", "thief"):
+            names = [a for a in self.agents if a.startswith(role)]
+            if not names:
+                continue
+            idx = [self.agents.index(a) for a in names]
+            self.roles[role] = RoleLearner(role, names, idx, self.R, self.N, self.tcfg.horizon,
+                                           dataclasses.replace(role_cfg.get(role, CFG_AGENT)), self.device, dt,
+                                           seeds=[seed * 1000 + i for i in idx])
+        self._gen = torch.Generator(device="cpu").manual_seed(seed)
         torch.manual_seed(seed)
-        self.policies = {a: LSTMPolicy(self.R).to(self.device) for a in self.agents}
-        self.values = {a: LSTMValue(self.R).to(self.device) for a in self.agents}
-        self.optimizers = {a: torch.optim.Adam(list(self.policies[a].parameters()) + list(self.values[a].parameters()),
-                                               lr=self.cfg.learning_rate)
-                           for a in self.agents}
-        self._sync = {a: _FlatGradSync(list(self.policies[a].parameters()) + list(self.values[a].parameters()))
-                      for a in self.agents}
-        self._gen = g
         self.timestep = 0
-        self._p_state = {a: self.policies[a].initial_state(self.N, self.device) for a in self.agents}
-        self._v_state = {a: self.values[a].initial_state(self.N, self.device) for a in self.agents}
         self._obs, _ = env.reset()
-        self._starts = torch.ones(self.N, dtype=torch.bool, device=self.device)   # first tick starts an episode
-        self.stats: Dict[str, float] = {}
-        self._buf = None                  # preallocated rollout buffers [T, N, ...] per agent
-        self._graph = None                # captured rollout (GPU)
+        self._starts = torch.ones(self.N, dtype=torch.bool, device=self.device)
+        T = self.tcfg.horizon
+        self._done_buf = torch.zeros(T, self.N, dtype=torch.bool, device=self.device)
+        self._start_buf = torch.zeros(T, self.N, dtype=torch.bool, device=self.device)
+        self._actions = torch.zeros(self.N, len(self.agents), dtype=torch.int32, device=self.device)
+        self._graph = None
         self._eager_rollouts = 0
-        self._random_phase = False
+        self.stats: Dict[str, float] = {}
+        self.use_graphs = on_gpu
 
-    # ------------------------------------------------------------------ inputs
-    def _policy_in(self, obs, a):
-        return packing.pack_policy_input(obs[a])                             # [N, 2R] f32
-
-    def _value_in(self, state, a):
-        src = sorted(state)[0] if self.cfg.reference_q11 else a
-        return packing.pack_agent_state(state[src])[:, : 4 * self.R]          # the 4 ray channels
-
-    def _autocast(self):
-        on = self.cfg.autocast_bf16 and self.device.type == "cuda"
-        return torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=on)
+    # ------------------------------------------------------------------ model inputs (packing.py layouts)
+    def _inputs(self, rl: RoleLearner, obs, state) -> Tuple[torch.Tensor, torch.Tensor]:
+        pin = torch.stack([packing.pack_policy_input(obs[a]) for a in rl.agents])                       # [G, N, 2R]
+        first = sorted(state)[0]
+        vin = torch.stack([packing.pack_agent_state(state[first if self.tcfg.reference_q11 else a])[:, :4 * self.R]
+                           for a in rl.agents])                                                         # [G, N, 4R]
+        return pin, vin
 
     # ------------------------------------------------------------------ rollout
-    def _rollout_ticks(self, buf) -> None:
-        """T ticks: networks -> actions -> env.step, written into the preallocated rollout buffers ``buf``.
-        Only in-place updates of persistent tensors and no host synchronisation, so the whole loop can be
-        captured in a HIP graph (``torch.cuda.CUDAGraph`` is hipGraph on ROCm) and replayed per rollout."""
-        N, cfg = self.N, self.cfg
-        for t in range(cfg.horizon):
+    def _rollout_ticks(self, random_actions: bool) -> None:
+        """T ticks: networks -> actions -> env.step into the preallocated buffers.  In-place updates of persistent
+        tensors only and no host synchronisation: the whole loop is captured in one HIP graph and replayed."""
+        N, T = self.N, self.tcfg.horizon
+        for t in range(T):
             state = self.env.state()
-            actions = {}
-            st = self._starts.view(N, 1)
-            for a in self.agents:
-                pin, vin = self._policy_in(self._obs, a), self._value_in(state, a)
-                with self._autocast():
-                    logits, p_new = self.policies[a](pin.unsqueeze(1), self._p_state[a], st)
-                    val, v_new = self.values[a](vin.unsqueeze(1), self._v_state[a], st)
-                for old, new in zip(self._p_state[a] + self._v_state[a], p_new + v_new):
+            keep = (~self._starts).view(1, N)
+            self._start_buf[t].copy_(self._starts)
+            for rl in self.roles.values():
+                pin, vin = self._inputs(rl, self._obs, state)
+                logits, p_new = rl.policy.forward(pin.unsqueeze(1), rl.p_state, keep)
+                val, v_new = rl.value.forward(vin.unsqueeze(1), rl.v_state, keep)
+                for old, new in zip(rl.p_state + rl.v_state, p_new + v_new):
                     old.copy_(new)
-                dist = torch.distributions.Categorical(logits=logits[:, 0].float(), validate_args=False)
-                if self._random_phase:
-                    act = torch.randint(0, 4, (N,), generator=self._gen).to(self.device)
+                logp_all = torch.log_softmax(logits[:, 0].float(), dim=-1)                               # [G, N, 4]
+                if random_actions:
+                    act = torch.randint(0, 4, (rl.G, N), generator=self._gen).to(self.device)
+                elif rl.role in self.tcfg.random_action_roles:
+                    act = torch.randint(0, 4, (rl.G, N), device=self.device)
                 else:
-                    act = dist.sample()
-                b = buf[a]
-                b["pin"][t].copy_(pin); b["vin"][t].copy_(vin); b["act"][t].copy_(act)
-                b["logp"][t].copy_(dist.log_prob(act)); b["val"][t].copy_(val[:, 0].float()); b["start"][t].copy_(self._starts)
-                actions[a] = act.to(torch.int32)
-            self._obs, rewards, terms, truncs, infos = self.env.step(actions)
+                    act = torch.multinomial(logp_all.exp().view(rl.G * N, 4), 1).view(rl.G, N)
+                b = rl.buf
+                b["pin"][:, t].copy_(pin); b["vin"][:, t].copy_(vin); b["act"][:, t].copy_(act)
+                b["logp"][:, t].copy_(logp_all.gather(-1, act.unsqueeze(-1)).squeeze(-1))
+                b["val"][:, t].copy_(val[:, 0, :, 0].float())
+                self._actions[:, rl.indices] = act.t().to(torch.int32)
+            self._obs, rewards, terms, truncs, infos = self.env.step(self._actions)
             done = terms[self.agents[0]]
-            for a in self.agents:
-                buf[a]["rew"][t].copy_(rewards[a].float()); buf[a]["done"][t].copy_(done)
+            for rl in self.roles.values():
+                rl.buf["rew"][:, t].copy_(torch.stack([rewards[a].float() for a in rl.agents]))
+            self._done_buf[t].copy_(done)
             self._starts.copy_(done)               # the env auto-resets: the next tick starts a new episode
 
-    def _alloc_rollout(self):
-        T, N, R, dev = self.cfg.horizon, self.N, self.R, self.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        return {a: {"pin": torch.empty((T, N, 2 * R), **f32), "vin": torch.empty((T, N, 4 * R), **f32),
-                    "act": torch.empty((T, N), dtype=torch.long, device=dev), "logp": torch.empty((T, N), **f32),
-                    "val": torch.empty((T, N), **f32), "rew": torch.empty((T, N), **f32),
-                    "done": torch.empty((T, N), dtype=torch.bool, device=dev),
-                    "start": torch.empty((T, N), dtype=torch.bool, device=dev)} for a in self.agents}
-
     @torch.no_grad()
-    def collect(self) -> Dict[str, Dict[str, torch.Tensor]]:
-        cfg, N = self.cfg, self.N
-        if self._buf is None:
-            self._buf = self._alloc_rollout()
-        buf = self._buf
-        p0 = {a: tuple(s.clone() for s in self._p_state[a]) for a in self.agents}
-        v0 = {a: tuple(s.clone() for s in self._v_state[a]) for a in self.agents}
-        self._random_phase = self.timestep < cfg.random_timesteps
-        use_graph = cfg.graph_rollout and self.device.type == "cuda" and not self._random_phase
+    def collect(self, random_actions: bool = False) -> None:
+        """One rollout of ``horizon`` ticks into the role buffers (the recurrent state at its start is kept for BPTT)."""
+        for rl in self.roles.values():
+            for dst, src in zip(rl.p0 + rl.v0, rl.p_state + rl.v_state):
+                dst.copy_(src)
+        use_graph = self.tcfg.graph_rollout and self.use_graphs and not random_actions
         if not use_graph:
-            self._rollout_ticks(buf)
+            self._rollout_ticks(random_actions)
             self._eager_rollouts += 1
         else:
             if self._graph is None:
                 if self._eager_rollouts == 0:       # the first rollout runs eagerly: warms allocator and libraries up
-                    self._rollout_ticks(buf)
+                    self._rollout_ticks(False)
                     self._eager_rollouts += 1
-                    return self._finish_rollout(buf, p0, v0)
+                    self.timestep += self.tcfg.horizon
+                    return
                 torch.cuda.synchronize(self.device)
                 self._graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph):
-                    self._rollout_ticks(buf)
+                    self._rollout_ticks(False)
             self._graph.replay()
-        return self._finish_rollout(buf, p0, v0)
-
-    @torch.no_grad()
-    def _finish_rollout(self, buf, p0, v0):
-        cfg, N = self.cfg, self.N
-        self.timestep += cfg.horizon
-        state = self.env.state()
-        out = {}
-        for a in self.agents:
-            with self._autocast():
-                last_val, _ = self.values[a](self._value_in(state, a).unsqueeze(1),
-                                             tuple(s.clone() for s in self._v_state[a]), self._starts.view(N, 1))
-            b = {k: v.clone() for k, v in buf[a].items()}
-            adv, ret = compute_gae(b["rew"], b["val"], b["done"], last_val[:, 0].float() * (~self._starts).float(),
-                                   cfg.discount_factor, cfg.gae_lambda)
-            b.update(adv=adv, ret=ret, p0=p0[a], v0=v0[a])
-            out[a] = b
-        return out
+        self.timestep += self.tcfg.horizon
 
     # ------------------------------------------------------------------ update
-    def _minibatch_step(self, a: str, mb: Dict[str, torch.Tensor], train_policy: bool):
-        """Forward, PPO losses, backward, gradient all-reduce, clip, Adam step on one minibatch of sequences.
-        Returns (policy_loss, value_loss, kl) as 0-d tensors; no host synchronisation.  (Capturing this step in a
-        HIP graph was tried and dropped: ending the capture of the backward pass crashed inside the runtime in some
-        process states.  The rollout, which has no autograd, is captured.)"""
-        cfg = self.cfg
-        with self._autocast():
-            logits, _ = self.policies[a](mb["pin"], (mb["ph"], mb["pc"]), mb["start"])
-            values, _ = self.values[a](mb["vin"], (mb["vh"], mb["vc"]), mb["start"])
-        dist = torch.distributions.Categorical(logits=logits.float(), validate_args=False)
-        logp = dist.log_prob(mb["act"])
-        ratio = torch.exp(logp - mb["logp"])
+    def update(self) -> Dict[str, float]:
+        """PPO update of every role from the rollout just collected."""
+        N = self.N
         with torch.no_grad():
-            kl = ((ratio - 1) - (logp - mb["logp"])).mean()
-        surr = mb["adv"] * ratio
-        surr_c = mb["adv"] * torch.clamp(ratio, 1 - cfg.ratio_clip, 1 + cfg.ratio_clip)
-        policy_loss = -torch.min(surr, surr_c).mean()
-        entropy_loss = -cfg.entropy_loss_scale * dist.entropy().mean()
-        value_loss = cfg.value_loss_scale * nn.functional.mse_loss(values.float(), mb["ret"])
-        loss = value_loss + ((policy_loss + entropy_loss) if train_policy else 0.0)
-        self.optimizers[a].zero_grad(set_to_none=True)
-        loss.backward()
-        self._sync[a]()                                         # flat-buffer all-reduce over RCCL
-        nn.utils.clip_grad_norm_(list(self.policies[a].parameters()) + list(self.values[a].parameters()),
-                                 cfg.grad_norm_clip)
-        self.optimizers[a].step()
-        return policy_loss.detach(), value_loss.detach(), kl
+            state = self.env.state()
+            keep = (~self._starts).view(1, N)
+            last = {}
+            for role, rl in self.roles.items():
+                _, vin = self._inputs(rl, self._obs, state)
+                val, _ = rl.value.forward(vin.unsqueeze(1), tuple(s.clone() for s in rl.v_state), keep)
+                last[role] = val[:, 0, :, 0].float() * (~self._starts).float()
+        use_graph = self.tcfg.graph_update and self.use_graphs
+        for role, rl in self.roles.items():
+            rl.update(self._done_buf, self._start_buf, last[role], self._gen, use_graph)
+        return {}
 
-    def update(self, rollout) -> Dict[str, float]:
-        cfg, T, N = self.cfg, self.cfg.horizon, self.N
-        stats = {}
-        for a in self.agents:
-            b = rollout[a]
-            role = a.split("_")[0]
-            train_policy = role not in cfg.frozen_roles
-            adv = (b["adv"] - b["adv"].mean()) / (b["adv"].std() + 1e-8)
-            # sequences = env slots (each a length-T BPTT window starting from the stored recurrent state)
-            tr = lambda x: x.transpose(0, 1).contiguous()                    # [T,N,..] -> [N,T,..]
-            seq = dict(pin=tr(b["pin"]), vin=tr(b["vin"]), act=tr(b["act"]), logp=tr(b["logp"]), ret=tr(b["ret"]),
-                       adv=tr(adv), start=tr(b["start"]))
-            stop = False
-            for epoch in range(cfg.learning_epochs):
-                perm = torch.randperm(N, generator=self._gen).to(self.device)
-                kls = []
-                for idx in perm.chunk(cfg.mini_batches):
-                    mb = {k: v[idx] for k, v in seq.items()}
-                    mb.update(ph=b["p0"][0][:, idx].contiguous(), pc=b["p0"][1][:, idx].contiguous(),
-                              vh=b["v0"][0][:, idx].contiguous(), vc=b["v0"][1][:, idx].contiguous())
-                    policy_loss, value_loss, kl = self._minibatch_step(a, mb, train_policy)
-                    kls.append(kl.clone())
-                    pl, vl = policy_loss.clone(), value_loss.clone()
-                mean_kl = float(torch.stack(kls).mean())                      # one host sync per epoch
-                if cfg.kl_threshold and mean_kl > cfg.kl_threshold:
-                    stop = True                                              # skrl: early stop on mean KL of the epoch
-                if stop:
-                    break
-            stats[f"{a}/policy_loss"], stats[f"{a}/value_loss"], stats[f"{a}/kl"] = float(pl), float(vl), mean_kl
-        self.stats = stats
-        return stats
+    def read_stats(self) -> Dict[str, float]:
+        """Host copy of the last minibatch's losses (one synchronisation; call it when you want to look)."""
+        out = {}
+        for rl in self.roles.values():
+            s = rl.stat.cpu()
+            for g, a in enumerate(rl.agents):
+                out[f"{a}/policy_loss"], out[f"{a}/value_loss"], out[f"{a}/kl"] = float(s[0, g]), float(s[1, g]), float(s[2, g])
+        self.stats = out
+        return out
 
-    def train(self, iterations: int) -> Dict[str, float]:
-        for _ in range(iterations):
-            rollout = self.collect()
-            if self.timestep >= self.cfg.learning_starts:
-                self.update(rollout)
-        return self.stats
+    def set_frozen(self, role: Optional[str] = None, policy: Optional[bool] = None, value: Optional[bool] = None) -> None:
+        for r, rl in self.roles.items():
+            if role is None or r == role:
+                rl.set_frozen(policy, value)
 
-    # ------------------------------------------------------------------ checkpoints (per-role files for the archive)
-    def role_state_dict(self, role: str) -> dict:
-        return {a: {"policy": self.policies[a].state_dict(), "value": self.values[a].state_dict()}
-                for a in self.agents if a.startswith(role)}
+    def train(self, timesteps: Optional[int] = None, freeze_policies_first: bool = True) -> Dict[str, float]:
+        """One ``SequentialTrainer.train()`` of the reference's simultaneous mode (``agent_learning_utils.py:172-197``):
+        the timestep restarts at 0, every policy starts frozen and every value network trainable, and the durations of
+        ``CFG_TRAINER`` release them."""
+        tc = self.tcfg
+        timesteps = tc.timesteps if timesteps is None else timesteps
+        self.timestep = 0
+        if freeze_policies_first:
+            self.set_frozen(policy=tc.policy_freeze_duration > 0, value=False)
+        while self.timestep < timesteps:
+            t0, t1 = self.timestep, self.timestep + tc.horizon
+            if tc.opponent_freeze_duration > 0 and t0 <= tc.opponent_freeze_duration < t1:
+                self.set_frozen(value=False)                     # "Unfreezing opponent agent" (README.md:104-108)
+            if tc.policy_freeze_duration > 0 and t0 <= tc.policy_freeze_duration < t1:
+                self.set_frozen(policy=False)                    # "Unfreezing policy network" (:109-113)
+            random_phase = t0 < max(rl.cfg.random_timesteps for rl in self.roles.values())
+            self.collect(random_actions=random_phase)
+            if not random_phase and self.timestep >= max(rl.cfg.learning_starts for rl in self.roles.values()):
+                self.update()
+        return self.read_stats()
 
-    def load_role_state_dict(self, sd: dict) -> None:
-        for a, parts in sd.items():
-            self.policies[a].load_state_dict(parts["policy"])
-            self.values[a].load_state_dict(parts["value"])
+    # ------------------------------------------------------------------ checkpoints
+    def agent_models(self, agent: str) -> Dict[str, Dict[str, torch.Tensor]]:
+        """{"policy": sd, "value": sd} with the reference modules' parameter names (models.LSTMPolicy / LSTMValue)."""
+        rl = self.roles[agent.split("_")[0]]
+        return agent_state_dict(rl.fp, rl.agents.index(agent))
+
+    def state_dict(self) -> dict:
+        """The "full agent" (reference ``MAPPO.save``: every model and optimiser) plus the trainer position."""
+        return {"format": "cat-mappo-1", "timestep": self.timestep, "num_rays": self.R,
+                "models": {a: self.agent_models(a) for a in self.agents},
+                "optimizers": {r: {"m": rl.m.clone(), "v": rl.v.clone(), "steps": rl.steps.clone()} for r, rl in self.roles.items()}}
+
+    def load_state_dict(self, sd: dict, roles: Optional[List[str]] = None, optimizer: bool = True) -> None:
+        """``roles``: restrict to these roles' models (reference ``copy_role_models``, which copies policy and value
+        weights only: pass ``optimizer=False`` for that)."""
+        for role, rl in self.roles.items():
+            if roles is not None and role not in roles:
+                continue
+            for g, a in enumerate(rl.agents):
+                load_agent_state_dict(rl.fp, g, sd["models"][a])
+            if optimizer and "optimizers" in sd and role in sd["optimizers"]:
+                o = sd["optimizers"][role]
+                rl.m.copy_(o["m"]); rl.v.copy_(o["v"]); rl.steps.copy_(o["steps"])
+        if optimizer and roles is None:
+            self.timestep = int(sd.get("timestep", 0))
+
+    def reset_optimizers(self) -> None:
+        """A fresh Adam, as every self-play iteration of the reference constructs a new ``MAPPO`` (orchestration.py:135-144)."""
+        for rl in self.roles.values():
+            rl.m.zero_(); rl.v.zero_(); rl.steps.zero_()
+
+    def reset_episodes(self) -> None:
+        """Restart every env slot and the recurrent states (after an evaluation used the same env, or on resume)."""
+        self._obs, _ = self.env.reset()
+        self._starts.fill_(True)
+        for rl in self.roles.values():
+            for s in rl.p_state + rl.v_state:
+                s.zero_()

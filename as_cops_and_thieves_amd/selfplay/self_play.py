@@ -1,88 +1,190 @@
 #!/usr/bin/env python3
-"""Self-play loop on the batched env: the structure of reference ``src/self_play_driver.py:83-117``
-+ ``src/training/orchestration.py:100-249`` (train both roles, save one checkpoint per role into
-its archive, evaluate against archived opponents, keep PFSP win-rates) with the env tick on the
-GPU.  Evaluation follows ``src/utils/eval_pfsp_agents.py:25-49``: greedy actions, an episode is a
-cop win iff ``winner == "cop"``.
+"""Self-play on the batched env: the reference's ``src/self_play_driver.py:83-117`` loop over
+``training/orchestration.py:100-249`` (``_orchestrate_simultaneous_training_iteration``) and
+``utils/agent_learning_utils.py:172-380`` (``train_simultaneously_and_evaluate`` / ``evaluate_agent``), with
+``TrainingConfig`` of ``src/configs/training_config.py:3-12``.
 
-    python -m as_cops_and_thieves_amd.selfplay.self_play --map squarinth --envs 1024 --iterations 3
+Per iteration, as in the reference:
+
+1. both roles continue from the latest checkpoint of their archive (model weights only -- the reference builds a
+   fresh ``MAPPO`` and copies policy + value weights in, ``orchestration.py:121-211``; Adam starts fresh);
+2. one ``trainer.train()``: all roles train simultaneously under the timestep schedule (``mappo.MAPPOTrainer.train``);
+3. the newly trained cops are evaluated against up to 5 DISTINCT archived thief policies sampled by the configured
+   strategy (PFSP), ``n_trial_episodes`` episodes each; per opponent ONE outcome -- "did the archived opponent win
+   more episodes than the learner" -- is booked into that opponent's entry of the thief archive's ``win_rates.json``;
+   then the same for the thieves against archived cops (``agent_learning_utils.py:233-380``);
+4. the joint checkpoint ``joint_iter_{i}_full_agent.pt`` (every model, the optimiser state, the trainer position) is
+   saved and copied into BOTH archives as ``{role}_iter_{i}.pt`` (``orchestration.py:225-245``).
+
+Conscious deviation (quirk Q16): the reference's ``evaluate_agent`` loads each sampled opponent INTO the
+agent it has just trained (``eval_agent = learned_agent`` is an alias, ``agent_learning_utils.py:253``), so the
+checkpoint saved in step 4 holds the last sampled ARCHIVED policies of both roles instead of the trained ones.  Here
+the opponents are loaded into a separate evaluation copy and the trained weights are what gets saved.
+
+    python -m as_cops_and_thieves_amd.selfplay.self_play --map squarinth --envs 1024 --iterations 3 --timesteps 2000
 """
 from __future__ import annotations
 
 import argparse
+import dataclasses
 import random
 from pathlib import Path
-from typing import Dict
+from typing import Dict, Optional, Tuple
 
 import torch
 
 from ..environments import VecCopsEnv
 from ..maps import load_preset
 from . import archive
-from .mappo import MAPPOConfig, MAPPOTrainer
+from .mappo import CFG_AGENT, MAPPOTrainer, RoleConfig, TrainerConfig
+
+
+@dataclasses.dataclass
+class TrainingConfig:
+    """``src/configs/training_config.py:3-12``."""
+    num_self_play_iterations: int = 40
+    training_timesteps_per_role_training: int = 100_000
+    archive_save_interval: int = 1
+    policy_sample_strategy: str = "pfsp"
+    win_rate_buffer_size: int = 20
+    n_trial_episodes: int = 5
+    cop_role_prefix: str = "cop"
+    thief_role_prefix: str = "thief"
+    num_opponents_to_evaluate: int = 5        # evaluate_agent(num_additional_opponents_to_evaluate=5)
 
 
 @torch.no_grad()
-def evaluate(trainer: MAPPOTrainer, episodes: int) -> Dict[str, int]:
-    """Greedy rollouts until ``episodes`` episodes have finished; returns win counts per role."""
-    env, N = trainer.env, trainer.N
+def evaluate_agents(env, runner: MAPPOTrainer, n_episodes: int, random_roles: Tuple[str, ...] = ()) -> Tuple[float, float]:
+    """``src/utils/eval_pfsp_agents.py:7-59``: ``n_episodes`` episodes with every model frozen, actions sampled from
+    the policies (skrl ``policy.act``), an episode ends at its first termination and is a win of ``infos["winner"]``.
+    Returns (cop wins / n, thief wins / n).  The batched form plays the episodes in parallel, one per env slot
+    (``env.num_envs >= n_episodes``; the first episode of the first ``n_episodes`` slots counts).  ``random_roles``:
+    these roles act uniformly at random instead (a fixed yardstick opponent; not part of the reference protocol)."""
+    N = env.num_envs
+    assert N >= n_episodes and N == runner.N
     obs, _ = env.reset()
-    starts = torch.ones(N, dtype=torch.bool, device=trainer.device)
-    p_state = {a: trainer.policies[a].initial_state(N, trainer.device) for a in trainer.agents}
-    wins = {"cop": 0, "thief": 0}
-    finished = 0
-    while finished < episodes:
-        actions = {}
-        for a in trainer.agents:
-            with trainer._autocast():
-                logits, p_state[a] = trainer.policies[a](trainer._policy_in(obs, a).unsqueeze(1), p_state[a], starts.view(N, 1))
-            actions[a] = logits[:, 0].float().argmax(-1).to(torch.int32)
+    starts = torch.ones(N, dtype=torch.bool, device=runner.device)
+    state = {r: rl.policy.initial_state(N) for r, rl in runner.roles.items()}
+    winner = torch.full((N,), -1, dtype=torch.int8, device=runner.device)
+    open_ = torch.ones(N, dtype=torch.bool, device=runner.device)
+    open_[n_episodes:] = False
+    actions = torch.zeros(N, len(runner.agents), dtype=torch.int32, device=runner.device)
+    for _ in range(env.max_step_count + 2):
+        keep = (~starts).view(1, N)
+        for r, rl in runner.roles.items():
+            pin = torch.stack([runner_pack(obs[a]) for a in rl.agents])
+            logits, state[r] = rl.policy.forward(pin.unsqueeze(1), state[r], keep)
+            probs = torch.softmax(logits[:, 0].float(), dim=-1)
+            act = torch.multinomial(probs.view(rl.G * N, 4), 1).view(rl.G, N)
+            if r in random_roles:                       # a uniformly random opponent (not part of the reference protocol)
+                act = torch.randint(0, 4, (rl.G, N), device=runner.device)
+            actions[:, rl.indices] = act.t().to(torch.int32)
         obs, _, terms, _, infos = env.step(actions)
-        w = infos["winner"]
-        wins["cop"] += int((w == 0).sum())
-        wins["thief"] += int((w == 1).sum())
-        starts = terms[trainer.agents[0]].clone()
-        finished = wins["cop"] + wins["thief"]
-    return wins
+        done = terms[runner.agents[0]]
+        first = open_ & done
+        winner = torch.where(first, infos["winner"].to(torch.int8), winner)
+        open_ = open_ & ~done
+        starts = done.clone()
+        if not bool(open_.any()):                       # one host sync per tick, on the evaluation path only
+            break
+    w = winner[:n_episodes]
+    return float((w == 0).sum()) / n_episodes, float((w == 1).sum()) / n_episodes
 
 
-def run_self_play(map_name: str, num_envs: int, iterations: int, rollouts_per_iteration: int, out_dir: Path,
-                  num_rays: int = 64, strategy: str = "pfsp", win_rate_buffer: int = 20, eval_episodes: int = 64,
-                  seed: int = 0, device=None) -> Dict[str, float]:
+def runner_pack(obs_agent):
+    from .. import packing
+    return packing.pack_policy_input(obs_agent)
+
+
+def evaluate_agent(eval_env, evaluator: MAPPOTrainer, learned: MAPPOTrainer, learned_role: str, opponent_role: str,
+                   opponent_archive: Path, tc: TrainingConfig, rng: random.Random, log=print) -> Dict[str, bool]:
+    """``agent_learning_utils.py:233-380``: the newly trained ``learned_role`` against up to
+    ``tc.num_opponents_to_evaluate`` distinct archived ``opponent_role`` policies.  Returns {opponent file: opponent won}."""
+    results: Dict[str, bool] = {}
+    evaluator.load_state_dict(learned.state_dict(), roles=[learned_role], optimizer=False)
+    seen = set()
+    for i in range(tc.num_opponents_to_evaluate):
+        path = None
+        for strategy in (tc.policy_sample_strategy, "random"):          # 20 tries for a new one, then 20 uniformly
+            for _ in range(20):
+                cand = archive.sample_policy_from_archive(opponent_archive, opponent_role, strategy, rng=rng)
+                if cand is None:
+                    break
+                if Path(cand).name not in seen:
+                    path = cand
+                    break
+            if path is not None:
+                break
+        if path is None:
+            log(f"[self-play] no new distinct {opponent_role} opponent for evaluation round {i + 1}/{tc.num_opponents_to_evaluate}")
+            break
+        name = Path(path).name
+        seen.add(name)
+        evaluator.load_state_dict(torch.load(path, map_location=evaluator.device, weights_only=False), roles=[opponent_role],
+                                  optimizer=False)                       # copy_role_models: policy + value weights
+        cop_rate, thief_rate = evaluate_agents(eval_env, evaluator, tc.n_trial_episodes)
+        opponent_won = (thief_rate > cop_rate) if learned_role == tc.cop_role_prefix else (cop_rate > thief_rate)
+        archive.update_policy_win_rate(opponent_archive, name, opponent_won, tc.win_rate_buffer_size)
+        results[name] = opponent_won
+        log(f"[self-play]   {learned_role} vs {name}: cop {cop_rate:.2f} thief {thief_rate:.2f} -> opponent {'won' if opponent_won else 'lost'}")
+    return results
+
+
+def run_self_play(map_name: str, num_envs: int, out_dir: Path, iterations: Optional[int] = None,
+                  training: Optional[TrainingConfig] = None, trainer_cfg: Optional[TrainerConfig] = None,
+                  role_cfg: Optional[Dict[str, RoleConfig]] = None, num_rays: int = 64, n_cops: Optional[int] = None,
+                  n_thieves: Optional[int] = None, max_step_count: int = 400, eval_envs: Optional[int] = None,
+                  seed: int = 0, device=None, resume: bool = True, log=print, env_factory=None) -> Dict[str, object]:
+    """The self-play loop.  ``resume``: continue after the highest iteration found in the archives ("latest").
+    ``env_factory(num_envs, seed)``: build the envs some other way (the CPU tests pass an oracle-backed stand-in)."""
+    tc = training or TrainingConfig()
+    iterations = tc.num_self_play_iterations if iterations is None else iterations
+    trainer_cfg = trainer_cfg or TrainerConfig(timesteps=tc.training_timesteps_per_role_training)
     out_dir = Path(out_dir)
-    arch = {"cop": out_dir / "cops", "thief": out_dir / "thieves"}
-    env = VecCopsEnv(load_preset(map_name), num_envs, num_rays=num_rays, seed=seed, device=device)
-    trainer = MAPPOTrainer(env, MAPPOConfig(), seed=seed)
+    arch = {tc.cop_role_prefix: out_dir / "cops", tc.thief_role_prefix: out_dir / "thieves"}
+    for p in arch.values():
+        p.mkdir(parents=True, exist_ok=True)
+    n_eval = eval_envs or tc.n_trial_episodes
+    if env_factory is None:
+        preset = load_preset(map_name, n_cops, n_thieves)
+        env_factory = lambda n, s: VecCopsEnv(preset, n, num_rays=num_rays, max_step_count=max_step_count, seed=s, device=device)
+    env, eval_env = env_factory(num_envs, seed), env_factory(n_eval, seed + 7919)
+    role_cfg = role_cfg or {"cop": CFG_AGENT, "thief": CFG_AGENT}        # self_play_driver.py passes CFG_AGENT
+    trainer = MAPPOTrainer(env, role_cfg, trainer_cfg, seed=seed)
+    evaluator = MAPPOTrainer(eval_env, role_cfg, dataclasses.replace(trainer_cfg, graph_rollout=False, graph_update=False),
+                             seed=seed + 1)
     rng = random.Random(seed)
-    stats: Dict[str, float] = {}
-    for it in range(iterations):
-        # opponent sampling: the role trained against an archived opponent is chosen alternately
-        learner, opponent = ("cop", "thief") if it % 2 == 0 else ("thief", "cop")
-        opp_file = archive.sample_policy_from_archive(arch[opponent], opponent, strategy, rng=rng)
-        if opp_file is not None:
-            trainer.load_role_state_dict(torch.load(opp_file, map_location=trainer.device))
-            trainer.cfg.frozen_roles = (opponent,)
-        else:
-            trainer.cfg.frozen_roles = ()
-        stats = trainer.train(rollouts_per_iteration)
-        for role in ("cop", "thief"):
-            ck = out_dir / f"joint_iter_{it}_{role}.pt"
-            out_dir.mkdir(parents=True, exist_ok=True)
-            torch.save(trainer.role_state_dict(role), ck)
-            archive.add_policy_to_archive(str(ck), arch[role], it, role)
-        wins = evaluate(trainer, eval_episodes)
-        total = max(1, wins["cop"] + wins["thief"])
-        if opp_file is not None:   # PFSP bookkeeping: outcomes of the archived opponent vs the current learner
-            name = Path(opp_file).name
-            for _ in range(wins[opponent]):
-                archive.update_policy_win_rate(arch[opponent], name, True, win_rate_buffer)
-            for _ in range(wins[learner]):
-                archive.update_policy_win_rate(arch[opponent], name, False, win_rate_buffer)
-        stats.update({"iteration": it, "cop_win_rate": wins["cop"] / total})
-        print(f"[self-play] iter {it}: learner={learner} opponent={Path(opp_file).name if opp_file else None} "
-              f"cop wins {wins['cop']}/{total}")
+    start = 0
+    if resume:
+        latest = [archive.get_latest_policy_from_archive(arch[r], r) for r in arch]
+        its = [int(Path(p).stem.split("_")[-1]) for p in latest if p]
+        start = max(its) + 1 if its else 0
+    history = []
+    for it in range(start, start + iterations):
+        # ---- 1. continue from the latest archived checkpoint of each role (orchestration.py:146-211)
+        for role in arch:
+            ck = archive.sample_policy_from_archive(arch[role], role, "latest")
+            if ck:
+                trainer.load_state_dict(torch.load(ck, map_location=trainer.device, weights_only=False), roles=[role], optimizer=False)
+        trainer.reset_optimizers()
+        trainer.reset_episodes()
+        # ---- 2. simultaneous training (agent_learning_utils.py:172-197)
+        stats = trainer.train(trainer_cfg.timesteps)
+        # ---- 3. evaluation against archived opponents (:199-228)
+        cop, thief = tc.cop_role_prefix, tc.thief_role_prefix
+        ev = {cop: evaluate_agent(eval_env, evaluator, trainer, cop, thief, arch[thief], tc, rng, log),
+              thief: evaluate_agent(eval_env, evaluator, trainer, thief, cop, arch[cop], tc, rng, log)}
+        # ---- 4. joint checkpoint into both archives (orchestration.py:225-245)
+        ck = out_dir / f"joint_iter_{it}_full_agent.pt"
+        torch.save(trainer.state_dict(), ck)
+        if it % tc.archive_save_interval == 0 or it == start + iterations - 1:
+            for role in arch:
+                archive.add_policy_to_archive(str(ck), arch[role], it, role)
+        history.append({"iteration": it, "evaluations": ev, "stats": stats})
+        log(f"[self-play] iteration {it}: saved {ck.name}; evaluated {len(ev[cop])} thief and {len(ev[thief])} cop opponents")
     env.close()
-    return stats
+    eval_env.close()
+    return {"iterations": history, "archives": {r: str(p) for r, p in arch.items()}}
 
 
 def main() -> None:
@@ -91,11 +193,13 @@ def main() -> None:
     ap.add_argument("--envs", type=int, default=1024)
     ap.add_argument("--rays", type=int, default=64)
     ap.add_argument("--iterations", type=int, default=3)
-    ap.add_argument("--rollouts", type=int, default=8)
-    ap.add_argument("--out", type=Path, default=Path("selfplay_out"))
+    ap.add_argument("--timesteps", type=int, default=100_000, help="env ticks per iteration (reference: 100 000)")
+    ap.add_argument("--out", type=Path, default=Path("lstm_policy_archive_self_play_new"))
     ap.add_argument("--strategy", default="pfsp", choices=["latest", "random", "pfsp"])
+    ap.add_argument("--eval-envs", type=int, default=None)
     args = ap.parse_args()
-    run_self_play(args.map, args.envs, args.iterations, args.rollouts, args.out, num_rays=args.rays, strategy=args.strategy)
+    tc = TrainingConfig(policy_sample_strategy=args.strategy, training_timesteps_per_role_training=args.timesteps)
+    run_self_play(args.map, args.envs, args.out, iterations=args.iterations, training=tc, num_rays=args.rays, eval_envs=args.eval_envs)
 
 
 if __name__ == "__main__":

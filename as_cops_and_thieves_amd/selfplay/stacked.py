@@ -1,0 +1,278 @@
+"""Role-stacked networks: the G policy (or value) networks of one role evaluated as ONE batched network.
+
+Same architectures as ``models.LSTMPolicy`` / ``models.LSTMValue`` (reference
+``src/models/lstm_policy_net.py:28-53``, ``lstm_value_net.py:46-75``) and the same parameter names per
+agent (``agent_state_dict`` / ``load_agent_state_dict`` round-trip through the per-agent modules), but every
+weight is a ``[G, ...]`` tensor and every layer one ``baddbmm`` over the G networks: an agent more costs no
+extra kernel launch.  The G agents' parameters are rows of ONE flat fp32 buffer (``FlatParams``): gradients
+accumulate into views of one flat gradient buffer, so the gradient all-reduce, the per-agent norm clip and
+Adam are a handful of kernels per optimiser step whatever the number of layers.
+
+The LSTM recurrence over a BPTT window is one autograd node (``_LSTMSeq``): per time step a batched GEMM plus
+the fused gate kernel forward, the fused gate gradient plus a batched GEMM backward, and the weight gradient
+as ONE GEMM over all steps (fp32 accumulation), instead of autograd's per-step graph.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .models import LSTMPolicy, LSTMValue, conv_out_len
+
+HIDDEN = 128
+# the stacked parameters are rows of one flat buffer (row stride = all parameters of an agent), and their gradients are
+# views of the flat gradient buffer with the same strides: autograd's "layout contract" note about that is expected
+warnings.filterwarnings("ignore", message="grad and param do not obey the gradient layout contract")
+
+
+# ---------------------------------------------------------------------------------------------- LSTM cell
+def _cell_fwd(ig: torch.Tensor, hg: torch.Tensor, c: torch.Tensor):
+    """One LSTM cell step from the input-side and hidden-side gate pre-activations (gate order i, f, g, o, as
+    ``nn.LSTM``).  ig, hg: [G, B, 4H]; c: [G, B, H].  Returns h', c', and the activated gates [G, B, 4H]."""
+    if ig.is_cuda:   # the fused pointwise kernel nn.LSTMCell uses
+        G, B, H4 = ig.shape
+        hy, cy, ws = torch.ops.aten._thnn_fused_lstm_cell(ig.reshape(G * B, H4), hg.reshape(G * B, H4), c.reshape(G * B, H4 // 4))
+        return hy.view(G, B, -1), cy.view(G, B, -1), ws.view(G, B, H4)
+    pre = ig + hg
+    i, f, g, o = pre.chunk(4, dim=-1)
+    i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    cy = f * c + i * g
+    return o * torch.tanh(cy), cy, torch.cat([i, f, g, o], dim=-1)
+
+
+def _cell_bwd(dh: torch.Tensor, dc: Optional[torch.Tensor], c: torch.Tensor, cy: torch.Tensor, ws: torch.Tensor):
+    """Gradient of ``_cell_fwd`` w.r.t. the summed gate pre-activations and the incoming cell state."""
+    if dh.is_cuda:
+        G, B, H = c.shape
+        dg, dcx, _ = torch.ops.aten._thnn_fused_lstm_cell_backward_impl(
+            dh.reshape(G * B, H), None if dc is None else dc.reshape(G * B, H), c.reshape(G * B, H), cy.reshape(G * B, H),
+            ws.reshape(G * B, 4 * H), False)
+        return dg.view(G, B, 4 * H), dcx.view(G, B, H)
+    i, f, g, o = ws.chunk(4, dim=-1)
+    tc = torch.tanh(cy)
+    dct = dh * o * (1 - tc * tc)
+    if dc is not None:
+        dct = dct + dc
+    dg = torch.cat([dct * g * i * (1 - i), dct * c * f * (1 - f), dct * i * (1 - g * g), dh * tc * o * (1 - o)], dim=-1)
+    return dg, dct * f
+
+
+class _LSTMSeq(torch.autograd.Function):
+    """h_t, c_t = cell(xproj[t] + h_{t-1} W_hh^T, c_{t-1}) for t = 0..T-1, with the state zeroed where ``keep[t]`` is 0
+    (an episode starts at step t).  Time-major: xproj [T, G, B, 4H]; w_hh [G, 4H, H]; h0, c0 [G, B, H]; keep [T, 1, B, 1]
+    or None.  Returns out [T, G, B, H], h_T, c_T."""
+
+    @staticmethod
+    def forward(ctx, xproj, w_hh, h0, c0, keep):
+        T = xproj.shape[0]
+        w_t = w_hh.transpose(1, 2)
+        h, c = h0, c0
+        train = any(ctx.needs_input_grad)          # a rollout tick (no_grad) keeps nothing
+        hs, cs, cys, wss, outs = [], [], [], [], []
+        for t in range(T):
+            if keep is not None:
+                h, c = h * keep[t], c * keep[t]
+            hg = torch.bmm(h, w_t)
+            hy, cy, ws = _cell_fwd(xproj[t], hg, c)
+            if train:
+                hs.append(h); cs.append(c); cys.append(cy); wss.append(ws)
+            outs.append(hy)
+            h, c = hy, cy
+        out = torch.stack(outs, 0) if T > 1 else outs[0].unsqueeze(0)
+        if train:
+            ctx.save_for_backward(w_hh, torch.stack(hs, 0), torch.stack(cs, 0), torch.stack(cys, 0), torch.stack(wss, 0),
+                                  keep if keep is not None else torch.empty(0))
+        ctx.has_keep = keep is not None
+        ctx.set_materialize_grads(False)           # unused final-state gradients arrive as None, not as zero tensors
+        return out, h, c
+
+    @staticmethod
+    def backward(ctx, d_out, d_hT, d_cT):
+        w_hh, hs, cs, cys, wss, keep = ctx.saved_tensors
+        T = hs.shape[0]
+        dh, dc = d_hT, d_cT
+        dgs = [None] * T
+        for t in range(T - 1, -1, -1):
+            if d_out is None:
+                dh_t = dh if dh is not None else torch.zeros_like(hs[t])
+            else:
+                dh_t = d_out[t] if dh is None else d_out[t] + dh
+            dg, dc = _cell_bwd(dh_t, dc, cs[t], cys[t], wss[t])
+            dh = torch.bmm(dg, w_hh)
+            if ctx.has_keep:
+                dh, dc = dh * keep[t], dc * keep[t]
+            dgs[t] = dg
+        dg_all = torch.stack(dgs, 0)                                             # [T, G, B, 4H] = d xproj
+        G, H4 = dg_all.shape[1], dg_all.shape[3]
+        a = dg_all.transpose(0, 1).reshape(G, -1, H4)                             # [G, T*B, 4H]
+        b = hs.transpose(0, 1).reshape(G, -1, hs.shape[3])                        # [G, T*B, H]
+        d_w = torch.bmm(a.transpose(1, 2), b)                                     # one GEMM over all steps
+        return dg_all, d_w, dh, dc, None
+
+
+# ---------------------------------------------------------------------------------------------- flat parameters
+class FlatParams:
+    """All parameters of the G agents of a role as rows of one ``[G, P]`` fp32 buffer.  ``views[name]`` is the
+    stacked ``[G, ...]`` view of one parameter in the compute dtype with ``.grad`` pre-assigned to the matching view
+    of the flat gradient buffer, so a backward pass accumulates straight into ``grad``."""
+
+    def __init__(self, shapes: Dict[str, Tuple[int, ...]], G: int, device, compute_dtype: torch.dtype):
+        self.G, self.names = G, list(shapes)
+        self.offsets, off = {}, 0
+        for n, shp in shapes.items():
+            k = int(math.prod(shp))
+            self.offsets[n] = (off, k, tuple(shp))
+            off += (k + 7) // 8 * 8                                              # 16-byte aligned starts in bf16
+        self.P = off
+        self.master = torch.zeros(G, self.P, dtype=torch.float32, device=device)
+        self.compute_dtype = compute_dtype
+        self.lp = self.master if compute_dtype == torch.float32 else torch.zeros(G, self.P, dtype=compute_dtype, device=device)
+        self.grad = torch.zeros(G, self.P, dtype=compute_dtype, device=device)
+        self.views: Dict[str, torch.Tensor] = {}
+        for n, (o, k, shp) in self.offsets.items():
+            v = self.lp[:, o:o + k].view(G, *shp).detach().requires_grad_(True)
+            v.grad = self.grad[:, o:o + k].view(G, *shp)
+            self.views[n] = v
+
+    def master_view(self, name: str) -> torch.Tensor:
+        o, k, shp = self.offsets[name]
+        return self.master[:, o:o + k].view(self.G, *shp)
+
+    def column_mask(self, prefix: str) -> torch.Tensor:
+        """[P] fp32, 1 on the columns of the parameters whose name starts with ``prefix``."""
+        m = torch.zeros(self.P, dtype=torch.float32, device=self.master.device)
+        for n, (o, k, _) in self.offsets.items():
+            if n.startswith(prefix):
+                m[o:o + k] = 1.0
+        return m
+
+    @torch.no_grad()
+    def refresh(self) -> None:
+        """compute-dtype copy of the master weights (no-op in fp32)."""
+        if self.lp is not self.master:
+            self.lp.copy_(self.master)
+
+
+# ---------------------------------------------------------------------------------------------- the stacked net
+def _net_shapes(kind: str, R: int) -> Dict[str, Tuple[int, ...]]:
+    C, layers = (2, 1) if kind == "policy" else (4, 2)
+    L2 = conv_out_len(R)
+    s = {"trunk.features.0.weight": (64, C, 5), "trunk.features.0.bias": (64,),
+         "trunk.features.2.weight": (32, 64, 5), "trunk.features.2.bias": (32,),
+         "trunk.features.5.weight": (256, 32 * L2), "trunk.features.5.bias": (256,)}
+    for l in range(layers):
+        s[f"trunk.lstm.weight_ih_l{l}"] = (4 * HIDDEN, 256 if l == 0 else HIDDEN)
+        s[f"trunk.lstm.weight_hh_l{l}"] = (4 * HIDDEN, HIDDEN)
+        s[f"trunk.lstm.bias_ih_l{l}"] = (4 * HIDDEN,)
+        s[f"trunk.lstm.bias_hh_l{l}"] = (4 * HIDDEN,)
+    dims = [HIDDEN, 128, 64, 4] if kind == "policy" else [HIDDEN, 256, 128, 64, 1]
+    for j in range(len(dims) - 1):
+        s[f"head.{2 * j}.weight"] = (dims[j + 1], dims[j])
+        s[f"head.{2 * j}.bias"] = (dims[j + 1],)
+    return s
+
+
+def role_param_shapes(R: int) -> Dict[str, Tuple[int, ...]]:
+    """Names/shapes of one agent's parameters: ``policy.*`` then ``value.*`` (names below the prefix as in models.py)."""
+    out = {}
+    for kind in ("policy", "value"):
+        for n, shp in _net_shapes(kind, R).items():
+            out[f"{kind}.{n}"] = shp
+    return out
+
+
+def _lin(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """x [G, M, in] @ w[G, out, in]^T + b[G, out]"""
+    return torch.baddbmm(b.unsqueeze(1), x, w.transpose(1, 2))
+
+
+class StackedNet:
+    """Functional forward of the G stacked policy or value networks of a role over a FlatParams."""
+
+    def __init__(self, kind: str, R: int, fp: FlatParams):
+        assert kind in ("policy", "value")
+        self.kind, self.R, self.fp = kind, R, fp
+        self.C, self.layers = (2, 1) if kind == "policy" else (4, 2)
+        self.L1, self.L2 = (R - 5) // 2 + 1, conv_out_len(R)
+        self.n_head = 3 if kind == "policy" else 4
+
+    def w(self, name: str) -> torch.Tensor:
+        return self.fp.views[f"{self.kind}.{name}"]
+
+    def initial_state(self, B: int):
+        z = torch.zeros(self.layers, self.fp.G, B, HIDDEN, device=self.fp.master.device, dtype=self.fp.compute_dtype)
+        return z, z.clone()
+
+    def forward(self, x: torch.Tensor, state, keep: Optional[torch.Tensor]):
+        """x: [G, T, B, C*R] (time-major); state: (h, c) each [layers, G, B, H]; keep: [T, B] (1 = carry the state
+        into step t, 0 = an episode starts there) or None.  Returns (out [G, T, B, n_out], new state)."""
+        G, T, B, _ = x.shape
+        dt = self.fp.compute_dtype
+        N = T * B
+        z = x.reshape(G, N, self.C, self.R).to(dt)
+        cols = z.unfold(3, 5, 2).permute(0, 1, 3, 2, 4).reshape(G, N * self.L1, self.C * 5)     # windows, (c, k) minor
+        z = torch.relu(_lin(cols, self.w("trunk.features.0.weight").reshape(G, 64, self.C * 5), self.w("trunk.features.0.bias")))
+        z = z.view(G, N, self.L1, 64)                                                            # [.., L, C] layout
+        cols = z.unfold(2, 5, 3).reshape(G, N * self.L2, 64 * 5)                                  # [.., L2, 64, 5]
+        z = torch.relu(_lin(cols, self.w("trunk.features.2.weight").reshape(G, 32, 64 * 5), self.w("trunk.features.2.bias")))
+        z = z.view(G, N, self.L2 * 32)                                                           # (l, c) order
+        wfc = self.w("trunk.features.5.weight").view(G, 256, 32, self.L2).transpose(2, 3).reshape(G, 256, self.L2 * 32)
+        f = torch.tanh(_lin(z, wfc, self.w("trunk.features.5.bias")))                            # [G, T*B, 256]
+        h0, c0 = state
+        kp = None if keep is None else keep.to(dt).view(T, 1, B, 1)
+        inp = f
+        hs, cs = [], []
+        for l in range(self.layers):
+            bias = self.w(f"trunk.lstm.bias_ih_l{l}") + self.w(f"trunk.lstm.bias_hh_l{l}")
+            xp = _lin(inp, self.w(f"trunk.lstm.weight_ih_l{l}"), bias).view(G, T, B, 4 * HIDDEN).transpose(0, 1).contiguous()
+            out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), h0[l].to(dt), c0[l].to(dt), kp)
+            hs.append(hT); cs.append(cT)
+            inp = out.transpose(0, 1).reshape(G, N, HIDDEN)                                      # back to [G, T*B, H]
+        y = inp
+        for j in range(self.n_head):
+            y = _lin(y, self.w(f"head.{2 * j}.weight"), self.w(f"head.{2 * j}.bias"))
+            if j < self.n_head - 1:
+                y = torch.relu(y)
+        return y.view(G, T, B, -1), (torch.stack(hs, 0), torch.stack(cs, 0))
+
+
+# ---------------------------------------------------------------------------------------------- per-agent checkpoints
+def _module_for(kind: str, R: int) -> nn.Module:
+    return LSTMPolicy(R) if kind == "policy" else LSTMValue(R)
+
+
+@torch.no_grad()
+def init_from_modules(fp: FlatParams, R: int, seeds: Sequence[int]) -> None:
+    """Initialise row g of the flat buffer exactly as freshly constructed per-agent modules would be (PyTorch's
+    default initialisers, seeded per agent), so a stacked run and a per-module run start from the same weights."""
+    for g, seed in enumerate(seeds):
+        gen_state = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        for kind in ("policy", "value"):
+            sd = _module_for(kind, R).state_dict()
+            for n, v in sd.items():
+                fp.master_view(f"{kind}.{n}")[g].copy_(v)
+        torch.random.set_rng_state(gen_state)
+    fp.refresh()
+
+
+@torch.no_grad()
+def agent_state_dict(fp: FlatParams, g: int) -> Dict[str, Dict[str, torch.Tensor]]:
+    """{"policy": state_dict, "value": state_dict} of agent g, loadable by models.LSTMPolicy / LSTMValue."""
+    out = {"policy": {}, "value": {}}
+    for n in fp.names:
+        kind, name = n.split(".", 1)
+        out[kind][name] = fp.master_view(n)[g].clone()
+    return out
+
+
+@torch.no_grad()
+def load_agent_state_dict(fp: FlatParams, g: int, sd: Dict[str, Dict[str, torch.Tensor]], kinds=("policy", "value")) -> None:
+    for kind in kinds:
+        for name, v in sd[kind].items():
+            fp.master_view(f"{kind}.{name}")[g].copy_(v.to(fp.master.device, torch.float32))
+    fp.refresh()

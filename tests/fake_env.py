@@ -16,6 +16,7 @@ class OracleVecEnv:
                              max_step_count=max_step_count, seed=seed, env_id_offset=env_id_offset)
         self.sim = OracleSim(self.cfg, [cmap])
         self.num_envs, self.device = num_envs, torch.device("cpu")
+        self.max_step_count = max_step_count
         self.possible_agents = [f"cop_{i}" for i in range(cmap.n_cops)] + [f"thief_{j}" for j in range(cmap.n_thieves)]
         sp = spaces.Dict({"distance": spaces.Box(0, 400, (num_rays,), np.float16),
                           "object_type": spaces.Box(0, 4, (num_rays,), np.uint8)})
@@ -33,13 +34,19 @@ class OracleVecEnv:
         return self._obs(), {}
 
     def step(self, actions):
-        acts = np.stack([np.asarray(actions[a], dtype=np.int32) for a in self.possible_agents], axis=1)
+        if isinstance(actions, dict):
+            acts = np.stack([np.asarray(actions[a], dtype=np.int32) for a in self.possible_agents], axis=1)
+        else:                                       # [N, A] tensor, as VecCopsEnv.step also accepts
+            acts = np.ascontiguousarray(np.asarray(actions, dtype=np.int32))
         out = self.sim.step(acts)
         rew = {a: torch.from_numpy(out["reward"][:, i].copy()) for i, a in enumerate(self.possible_agents)}
         term = torch.from_numpy(out["terminated"].astype(bool)); trunc = torch.from_numpy(out["truncated"].astype(bool))
         infos = {"winner": torch.from_numpy(out["winner"].copy())}
         self.sim.reset(mask=out["terminated"].copy())
         return self._obs(), rew, {a: term for a in self.possible_agents}, {a: trunc for a in self.possible_agents}, infos
+
+    def close(self):
+        pass
 
     def state(self):
         o = self.sim.out

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Diagnostic: does the learner learn?  Cops (trained) against uniformly random thieves on a map; prints the cop win
+rate of sampled-action evaluation episodes every few updates.  Usage: python tools/learn_curve.py [map] [envs] [updates]"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from as_cops_and_thieves_amd import VecCopsEnv, load_preset
+from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, RoleConfig, TrainerConfig
+from as_cops_and_thieves_amd.selfplay.self_play import evaluate_agents
+
+name = sys.argv[1] if len(sys.argv) > 1 else "squarinth"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+U = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+lr = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-4
+msc = int(sys.argv[5]) if len(sys.argv) > 5 else 400
+rc = RoleConfig(random_timesteps=0, learning_starts=0, learning_rate=lr)
+env = VecCopsEnv(load_preset(name), num_envs=N, num_rays=64, max_step_count=msc, seed=1)
+ev = VecCopsEnv(load_preset(name), num_envs=512, num_rays=64, max_step_count=msc, seed=99)
+tc = TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0, random_action_roles=("thief",))
+tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, tc, seed=0)
+tr.set_frozen(role="thief", policy=True, value=True)
+evr = MAPPOTrainer(ev, {"cop": rc, "thief": rc}, TrainerConfig(graph_rollout=False, graph_update=False), seed=1)
+t0 = time.time()
+for u in range(U + 1):
+    if u % max(1, U // 10) == 0:
+        evr.load_state_dict(tr.state_dict(), optimizer=False)
+        c, t = evaluate_agents(ev, evr, 512, random_roles=("thief",))
+        print(f"update {u:4d} ({u * 16 * N / 1e6:6.1f} M env-steps, {time.time() - t0:5.1f} s): cop win rate {c:.3f} thief {t:.3f}  {tr.read_stats().get('cop_0/value_loss')}", flush=True)
+    tr.collect(); tr.update()

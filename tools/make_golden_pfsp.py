@@ -4,9 +4,12 @@ file path; run with python3 -B so no bytecode lands in /root/reference):
 
     python3 -B tools/make_golden_pfsp.py [/root/reference]
 
-Records, for scripted outcome sequences, the win_rates.json the reference writes, the PFSP weight
-of every archived policy, "latest", and which policy random.choices picks for fixed seeds with the
-candidates in iteration order."""
+Every recorded value is an output of the reference's own functions: the win_rates.json it writes for a
+scripted outcome sequence, "latest", the PFSP weights exactly as ``sample_policy_from_archive`` hands them to
+``random.choices`` (captured by a spy on that call), and the policy it returns after ``random.seed(s)``.
+The archive path handed to the reference is a ``Path`` whose ``glob`` yields iteration order (plain
+``Path.glob`` order is whatever the filesystem returns, so the reference's pick is not reproducible
+otherwise); this build's sampler documents the same order."""
 import contextlib
 import importlib.util
 import io
@@ -21,6 +24,16 @@ REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
 spec = importlib.util.spec_from_file_location("ref_pau", REF / "src/utils/policy_archive_utils.py")
 ref = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(ref)
+
+_CHOICES = random.choices
+
+
+class SortedGlobPath(type(Path())):
+    """glob() in iteration order (see the module docstring)."""
+
+    def glob(self, pattern):
+        return sorted(super().glob(pattern), key=lambda q: int(q.stem.split("_")[-1]))
+
 
 scenarios = []
 rng = random.Random(7)
@@ -43,27 +56,25 @@ with contextlib.redirect_stdout(io.StringIO()):
                 events.append([name, won])
                 ref.update_policy_win_rate(arch, name, won, buf)
             rates = json.loads((arch / "win_rates.json").read_text()) if (arch / "win_rates.json").exists() else {}
-            loaded = ref.load_win_rates(arch)
-            weights = {}
-            for it in iters:
-                name = f"cop_iter_{it}.pt"
-                st = loaded.get(name)
-                wr = 0.5
-                if st and st["games"] > 0:
-                    ro = st.get("recent_outcomes")
-                    wr = sum(ro) / len(ro) if ro is not None and len(ro) > 0 else st["wins"] / st["games"]
-                weights[name] = max(1e-3, 1.0 - abs(wr - 0.5) * 2.0)
-            # PFSP picks with the candidate list in iteration order (the port's documented order)
-            cands = [f"cop_iter_{it}.pt" for it in iters]
+            latest = Path(ref.get_latest_policy_from_archive(arch, "cop")).name
+            seen = {}
+
+            def spy(population, weights=None, k=1, _orig=_CHOICES):
+                seen["cands"], seen["weights"] = [Path(c).name for c in population], list(weights)
+                return _orig(population, weights=weights, k=k)
             picks = {}
             for seed in (0, 1, 2, 3, 4):
-                picks[str(seed)] = random.Random(seed).choices(cands, weights=[weights[c] for c in cands], k=1)[0]
-            # sanity: the reference's own sampler returns a member and agrees on "latest"
-            latest = Path(ref.get_latest_policy_from_archive(arch, "cop")).name
-            random.seed(0)
-            assert Path(ref.sample_policy_from_archive(arch, "cop", "pfsp")).name in cands
+                random.seed(seed)
+                ref.random.choices = spy
+                try:
+                    picks[str(seed)] = Path(ref.sample_policy_from_archive(SortedGlobPath(arch), "cop", "pfsp")).name
+                finally:
+                    ref.random.choices = _CHOICES
+            cands = [f"cop_iter_{it}.pt" for it in iters]
+            assert seen["cands"] == cands
+            weights = dict(zip(seen["cands"], seen["weights"]))
             scenarios.append({"iterations": iters, "buffer_size": buf, "events": events, "win_rates_json": rates,
                               "pfsp_weights": weights, "latest": latest, "picks_by_seed": picks})
 out = ROOT / "tests" / "golden" / "pfsp_golden.json"
-out.write_text(json.dumps({"scenarios": scenarios, "generated_by": "tools/make_golden_pfsp.py (reference policy_archive_utils.py)"}, indent=1) + "\n")
+out.write_text(json.dumps({"scenarios": scenarios, "generated_by": "tools/make_golden_pfsp.py: every value is an output of the reference's policy_archive_utils.py (weights captured from its random.choices call, picks after random.seed)"}, indent=1) + "\n")
 print(f"{len(scenarios)} scenarios -> {out}")

@@ -7,7 +7,8 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import torch
 from as_cops_and_thieves_amd import _native as nat
-nat.LIB_PATH = nat.PKG / "libcat_sim_timing.so"
+import os
+nat.LIB_PATH = Path(os.environ.get("CAT_TIMING_LIB", str(nat.PKG / "libcat_sim_timing.so"))).resolve()
 from as_cops_and_thieves_amd.config import SimConfig
 from as_cops_and_thieves_amd.maps import load_preset
 from as_cops_and_thieves_amd.sim import CatSim
@@ -31,11 +32,11 @@ L.cat_debug_phase_cycles(buf, 1)
 # a mark closes the span since the previous mark of the same wave, so with shared work units the spans also contain
 # the claim/scan steps that precede them; "tail" = everything after a wave's last unit (scan, waits, write-back)
 names = {0: "stage_map", 1: "state -> LDS", 2: "termination+actions", 4: "agent setup (cells, cones)",
-         5: "unit claim + chunk prologue + packing (gate)", 6: "dense items (hull query)", 7: "per-ray resolve", 8: "hit point + f16",
-         9: "before physics unit", 10: "physics (rest)", 11: "tail: scan, waits, write-back", 12: "phys: integrate",
+         5: "packing (gate)", 20: "unit claim + chunk prologue (row fetch)", 16: "after last unit: scan / wait for open units", 17: "write-back: rewards (LUT)", 18: "write-back: state record", 19: "write-back: shared obs + output stores", 6: "dense items (hull query)", 7: "per-ray resolve", 8: "hit point + f16",
+         9: "before physics unit", 10: "physics (rest)", 11: "kernel end", 12: "phys: integrate",
          13: "phys: wall broadphase+narrow", 14: "phys: pairs", 15: "phys: aging"}
 tot = sum(buf)
 for i in range(24):
     if buf[i]:
-        print(f"{str(names.get(i, i)):22s} {buf[i] / T / N:10.0f} cycles/wave  {100.0 * buf[i] / tot:5.1f}%")
+        print(f"{str(names.get(i, i)):46s} {buf[i] / T / N:10.0f} cycles/wave  {100.0 * buf[i] / tot:5.1f}%")
 print(f"{'total':22s} {tot / T / N:10.0f} cycles/wave")
