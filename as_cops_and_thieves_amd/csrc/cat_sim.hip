@@ -40,9 +40,10 @@ constexpr unsigned kBlobMagic = 0x31544143u;
 
 struct MapDesc {
     int S, P, A, n_regions;
-    int f64_off;   // into geo_f64: [bb 4S][planes 8P][start 2A][regions 4Rg]
+    int f64_off;   // into geo_f64: [bb 4S][planes 8P][planes32 4P][start 2A][regions 4Rg]
     int i32_off;   // into geo_i32: [first S][count S][region_off A+1]
-    int pad0, pad1;
+    float cmax;    // max over the planes of |dot(v0, n) + wall radius + ray radius| (error bound of the f32 pre-classification)
+    int pad1;
 };
 
 // Spatial-hash grids, built once per (map, ray table) on the host (build_grids):
@@ -248,6 +249,7 @@ __device__ __forceinline__ double u53(unsigned a, unsigned b)
 struct Lds {
     const double *bb;      // [S][4]            workgroup-shared
     const double *planes;  // [P][8]
+    const float *p32;      // [P][8]  f32 copy for the conservative pre-classification: n.x n.y c dtMin | dtMax v0.x v0.y -
     const int *fc;         // [S] first plane | plane count << 16
     // per env slot
     double *pos, *vel, *vb, *tc, *leaf;  // [A][2] x4, [A][4]
@@ -436,30 +438,47 @@ constexpr int kPassJ = 8;           // candidate positions per ray per pass
 // An agent's circle goes through the same code as a hull with no edges and one "corner" (its cached centre, radius
 // r = the agent radius): the lanes of a round hold walls and agents side by side, and a separate circle path would be
 // executed for the whole wave whenever one lane needs it.  cx, cy: that centre (ignored for walls).
-__device__ __forceinline__ void poly_query_feat(const Lds &L, bool wall, int sh, double r, double cx, double cy, double ax, double ay,
+__device__ __forceinline__ void poly_query_feat(const Lds &L, float cmax, bool wall, int sh, double r, double cx, double cy, double ax, double ay,
                                                 double bx, double by, double r2, double &alpha, int &feat)
 {
     const int fc = wall ? L.fc[sh] : 0, first = fc & 0xFFFF, count = fc >> 16;
     const double rsum = r + r2, rr = rsum * rsum;
-    // conservative f32 pre-test for the bevels (see poly_segment_query)
+    // Conservative f32 pre-classification of every hull edge (from the f32 copy of the plane records, which holds
+    // c = dot(v0, n) + rsum for THIS rsum = wall radius + ray radius): a face stays a candidate unless the f32 evaluation,
+    // widened by a bound on its error, excludes one of the exact conditions 0 <= d <= den and dtMin <= dt <= dtMax; a
+    // corner stays a candidate unless its centre is farther than rsum from the ray's LINE or projects outside the
+    // segment by more than rsum.  Everything the exact tests below would accept is kept, so the results are those of
+    // evaluating every edge exactly; what changes is that the exact f64 tests (a divide / a square root and a divide)
+    // mostly run for the one face or corner that is really hit.
+    const float axf = (float)ax, ayf = (float)ay;
     const float dxf = (float)(bx - ax), dyf = (float)(by - ay);
-    const float thr = ((float)rsum + 0.01f) * sqrtf(dxf * dxf + dyf * dyf) * 1.00001f + 0.25f;
+    const float len2 = dxf * dxf + dyf * dyf, len = sqrtf(len2);
+    const float e1 = 1e-6f * (fabsf(axf) + fabsf(ayf) + cmax + 512.0f);   // >= 3x the error of d and den evaluated in f32
+    const float thr = ((float)rsum + 0.01f) * len * 1.00001f + 0.25f + 64.0f * e1;
+    const float s_lo = -((float)rsum + 1.0f) * len, s_hi = len2 + ((float)rsum + 1.0f) * len;
     const bool bevels = rsum > 0.0;
     unsigned pm = 0u, vm = wall ? 0u : 1u;
     const double *pl0 = L.planes + 8 * first;
     {
-        const double *pl = pl0;
-        for (int i = 0; i < count; i++, pl += 8) {
-            const double2 n = *reinterpret_cast<const double2 *>(pl);
-            const double2 v = *reinterpret_cast<const double2 *>(pl + 2);
-            const double an = ax * n.x + ay * n.y;
-            const double d = an - pl[4] - rsum;
-            const double bn = bx * n.x + by * n.y;
-            const double den = fmax2(an - bn, DBL_MIN);
-            // !(d < 0) and !(d > den): the segment reaches the face line (d > den <=> fl(d/den) > 1)
-            pm |= (unsigned)(!(d < 0.0) && !(d > den)) << i;
-            const float ex = (float)(v.x - ax), ey = (float)(v.y - ay);
-            vm |= (unsigned)(bevels && !(fabsf(dxf * ey - dyf * ex) > thr)) << i;
+        const float *q = L.p32 + 8 * first;
+        for (int i = 0; i < count; i++, q += 8) {
+            const float4 q0 = *reinterpret_cast<const float4 *>(q);       // n.x n.y c dtMin
+            const float4 q1 = *reinterpret_cast<const float4 *>(q + 4);   // dtMax v0.x v0.y -
+            const float d = __builtin_fmaf(ayf, q0.y, axf * q0.x) - q0.z;
+            const float den = -__builtin_fmaf(dyf, q0.y, dxf * q0.x);
+            bool face = (d >= -e1) && (d <= den + e1);
+            {   // where the crossing point falls along the face (skipped for a ray almost parallel to it: ill-conditioned)
+                const float ri = __builtin_amdgcn_rcpf(fmaxf(den, 0.25f));
+                const float t = d * ri;
+                const float ptx = __builtin_fmaf(t, dxf, axf), pty = __builtin_fmaf(t, dyf, ayf);
+                const float dt = __builtin_fmaf(q0.x, pty, -(q0.y * ptx));
+                const float e2 = e1 * __builtin_fmaf(3.0f * len, ri, 4.0f);
+                face = face && ((den < 0.25f) || ((dt >= q0.w - e2) && (dt <= q1.x + e2)));
+            }
+            pm |= (unsigned)face << i;
+            const float ex = q1.y - axf, ey = q1.z - ayf;
+            const float cr = __builtin_fmaf(dxf, ey, -(dyf * ex)), sp = __builtin_fmaf(dxf, ex, dyf * ey);
+            vm |= (unsigned)(bevels && !(fabsf(cr) > thr) && (sp >= s_lo) && (sp <= s_hi)) << i;
         }
     }
     double pa = 1.0, va = 1.0;
@@ -672,7 +691,7 @@ __device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, i
 // union of L is the calling wave's.  Writes the chunk's observations to the env's output staging.
 template <class D>
 __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, int env, int lane,
-                          int S, int rew_mode, int c, PhaseClock &pc)
+                          int S, float cmax, int rew_mode, int c, PhaseClock &pc)
 {
     const int A = D::A(p), R = D::R(p);
     const double r2 = p.ray_radius;
@@ -798,7 +817,7 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
                         if (inside) { alpha = 0.0; feat = kFeatNear; }
                         else {   // an accepted circle hit at alpha == 1 could never beat the initial best of 1: "t < 1" is equivalent
                             int f;
-                            poly_query_feat(L, wall, wall ? id : 0, wall ? wall_r : rc, L.ftc[2 * j], L.ftc[2 * j + 1], ax, ay, cbx, cby, r2, alpha, f);
+                            poly_query_feat(L, cmax, wall, wall ? id : 0, wall ? wall_r : rc, L.ftc[2 * j], L.ftc[2 * j + 1], ax, ay, cbx, cby, r2, alpha, f);
                             feat = f < 0 ? 0 : f;
                         }
                     }
@@ -1292,7 +1311,8 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     const int S = md.S, P = md.P, W = p.wpb;
     L.bb = reinterpret_cast<const double *>(smem);
     L.planes = L.bb + 4 * S;
-    L.fc = reinterpret_cast<const int *>(L.planes + 8 * P);
+    L.p32 = reinterpret_cast<const float *>(L.planes + 8 * P);
+    L.fc = reinterpret_cast<const int *>(L.planes + 12 * P);
     L.rayd = reinterpret_cast<const double *>(smem + p.lds_map_bytes - 16 * D::R(p));
     L.ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
     char *w = smem + p.lds_map_bytes + 16 * W + slot * p.lds_env_bytes;
@@ -1333,7 +1353,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
 template <class D>
 __device__ __forceinline__ void stage_map(const Params &p, char *smem, const MapDesc &md)
 {
-    const int nf = 4 * md.S + 8 * md.P;
+    const int nf = 4 * md.S + 12 * md.P;
     double *dst = reinterpret_cast<double *>(smem);
     GAS const double *src = G(p.geo_f64) + md.f64_off;
     {   // 16-byte copies, four in flight per thread (every map base is 16-byte aligned, nf is even)
@@ -1471,7 +1491,7 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         const Lds Ls = carve<D>(p, smem, md, slot, wave);
         int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
         while (c <= last_unit) {
-            if (c < nchunks) fan_chunk<D>(Ls, p, la, gd, e_s, lane, S, tick, c, pc);   // entity.py:143-144, base_env.py:388-390 / :334-344
+            if (c < nchunks) fan_chunk<D>(Ls, p, la, gd, e_s, lane, S, md.cmax, tick, c, pc);   // entity.py:143-144, base_env.py:388-390 / :334-344
             else {
                 PHASE(pc, 9);
                 physics_env<D>(Ls, p, S, lane, pc);                                // base_env.py:392
@@ -1658,7 +1678,7 @@ __device__ __forceinline__ void spawn_and_reset(const Lds &L, const Params &p, c
                                                 int env, unsigned rc, int lane)
 {
     const int S = md.S, A = D::A(p);
-    GAS const double *start = G(p.geo_f64) + md.f64_off + 4 * md.S + 8 * md.P;
+    GAS const double *start = G(p.geo_f64) + md.f64_off + 4 * md.S + 12 * md.P;
     GAS const double *regions = start + 2 * md.A;
     GAS const int *region_off = G(p.geo_i32) + md.i32_off + 2 * md.S;
 
@@ -1868,7 +1888,7 @@ static LdsSizes lds_sizes(int A, int R, int maxS, int maxP)
     auto up = [](int x, int a) { return (x + a - 1) / a * a; };
     const int NP = A * (A - 1) / 2, NPs = NP > 0 ? NP : 1, maxc = A * kK + NP;
     LdsSizes z;
-    z.map = up((4 * maxS + 8 * maxP) * 8 + maxS * 4, 16) + 16 * R;
+    z.map = up((4 * maxS + 12 * maxP) * 8 + maxS * 4, 16) + 16 * R;
     const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
     const int fan_bytes = 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;
     z.uni = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 16);
@@ -1975,7 +1995,26 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
                 return CAT_ERR_BAD_MAP;
             }
         d.f64_off = (int)geo_f.size();
-        geo_f.insert(geo_f.end(), f.begin() + 2, f.end());  // drop window w,h
+        const size_t n_geo = 4 * (size_t)d.S + 8 * (size_t)d.P;
+        geo_f.insert(geo_f.end(), f.begin() + 2, f.begin() + 2 + n_geo);  // drop window w,h: [bb][planes]
+        {   // f32 copy of the plane records for the ray fan's conservative pre-classification (poly_query_feat)
+            const double rsum = cfg->wall_radius + cfg->ray_radius;
+            const double *pl = f.data() + 2 + 4 * (size_t)d.S;
+            std::vector<float> p32(8 * (size_t)d.P, 0.0f);
+            float cmax = 0.0f;
+            for (int q = 0; q < d.P; q++) {
+                const double *r = pl + 8 * (size_t)q;   // n.x n.y v0.x v0.y dot(v0,n) dtMin dtMax -
+                float *o = p32.data() + 8 * (size_t)q;
+                o[0] = (float)r[0]; o[1] = (float)r[1]; o[2] = (float)(r[4] + rsum); o[3] = (float)r[5];
+                o[4] = (float)r[6]; o[5] = (float)r[2]; o[6] = (float)r[3];
+                cmax = std::fmax(cmax, std::fabs(o[2]));
+            }
+            d.cmax = cmax;
+            const size_t at = geo_f.size();
+            geo_f.resize(at + 4 * (size_t)d.P);
+            memcpy(geo_f.data() + at, p32.data(), p32.size() * sizeof(float));
+        }
+        geo_f.insert(geo_f.end(), f.begin() + 2 + n_geo, f.end());        // [start][regions]
         d.i32_off = (int)geo_i.size();
         geo_i.insert(geo_i.end(), iv.begin(), iv.end());
         if (geo_f.size() & 1) geo_f.push_back(0.0);  // keep 16-byte alignment of each map's base
@@ -2066,7 +2105,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     std::vector<char> rec0((size_t)N * p.rec_bytes, 0);
     for (int e = 0; e < N; e++) {
         const MapDesc &d = descs[slot[e]];
-        const double *start = geo_f.data() + d.f64_off + 4 * d.S + 8 * d.P;
+        const double *start = geo_f.data() + d.f64_off + 4 * d.S + 12 * d.P;
         double *rd = reinterpret_cast<double *>(rec0.data() + (size_t)e * p.rec_bytes);
         int *ri = reinterpret_cast<int *>(rd + p.rec_doubles);
         for (int i = 0; i < A; i++) {

@@ -96,15 +96,19 @@ def _dist_ready() -> bool:
 
 
 class RoleLearner:
-    """The G agents of one role: stacked policy + value networks over one flat parameter buffer, their Adam state,
-    the role's rollout buffers and its PPO minibatch step."""
+    """G agents that share one ``RoleConfig`` -- the agents of a role, or of both roles when the roles are configured
+    alike (the reference's driver: ``CFG_AGENT`` for everyone) -- as stacked policy + value networks over one flat
+    parameter buffer, with their Adam state, rollout buffers and PPO minibatch step.  Every launch then serves all of
+    them: the update is bound by the number of kernels, not by their size."""
 
     BETA1, BETA2, EPS = 0.9, 0.999, 1e-8    # torch.optim.Adam defaults (what skrl constructs)
 
     def __init__(self, role: str, agents: List[str], indices: List[int], R: int, N: int, T: int, cfg: RoleConfig,
                  device: torch.device, compute_dtype: torch.dtype, seeds: List[int]):
         self.role, self.agents, self.indices, self.cfg = role, agents, indices, cfg
+        self.agent_roles = [a.split("_")[0] for a in agents]
         self.G, self.R, self.N, self.T, self.device = len(agents), R, N, T, device
+        self.index_t = torch.tensor(indices, dtype=torch.long, device=device)     # columns of the [N, A] action tensor
         self.fp = FlatParams(role_param_shapes(R), self.G, device, compute_dtype)
         init_from_modules(self.fp, R, seeds)
         self.policy, self.value = StackedNet("policy", R, self.fp), StackedNet("value", R, self.fp)
@@ -112,11 +116,11 @@ class RoleLearner:
         f32 = dict(dtype=torch.float32, device=device)
         self.m, self.v, self.steps = torch.zeros(G, P, **f32), torch.zeros(G, P, **f32), torch.zeros(G, P, **f32)
         self.col_policy, self.col_value = self.fp.column_mask("policy."), self.fp.column_mask("value.")
-        self.col_train = torch.ones(P, **f32)                  # 1 where the parameter is trainable right now
+        self.col_train = torch.ones(G, P, **f32)               # 1 where the parameter is trainable right now
+        self.frozen = {r: [False, False] for r in set(self.agent_roles)}   # role -> [policy frozen, value frozen]
         self.epoch_active = torch.ones(G, **f32)               # KL early stop: 0 = skip the rest of this epoch
         self.ar = torch.zeros(G, P + 1, **f32)                 # all-reduce buffer: fp32 gradients | KL
         self.stat = torch.zeros(3, G, **f32)                   # last policy loss, value loss, KL per agent
-        self.policy_frozen, self.value_frozen = False, False
         B = N // cfg.mini_batches
         self.B = B
         self.idx = torch.zeros(B, dtype=torch.long, device=device)
@@ -131,13 +135,19 @@ class RoleLearner:
         self._graphs = None
 
     # ------------------------------------------------------------------ freezing (skrl Model.freeze_parameters)
-    def set_frozen(self, policy: Optional[bool] = None, value: Optional[bool] = None) -> None:
-        if policy is not None:
-            self.policy_frozen = policy
-        if value is not None:
-            self.value_frozen = value
-        self.col_train.copy_(self.col_policy * (0.0 if self.policy_frozen else 1.0)
-                             + self.col_value * (0.0 if self.value_frozen else 1.0))
+    def set_frozen(self, role: Optional[str] = None, policy: Optional[bool] = None, value: Optional[bool] = None) -> None:
+        for r, fr in self.frozen.items():
+            if role is None or r == role:
+                if policy is not None:
+                    fr[0] = policy
+                if value is not None:
+                    fr[1] = value
+        rows = [self.col_policy * (0.0 if self.frozen[r][0] else 1.0) + self.col_value * (0.0 if self.frozen[r][1] else 1.0)
+                for r in self.agent_roles]
+        self.col_train.copy_(torch.stack(rows))
+
+    def rows(self, role: str) -> List[int]:
+        return [g for g, r in enumerate(self.agent_roles) if r == role]
 
     # ------------------------------------------------------------------ the PPO minibatch step
     def _step_forward_backward(self) -> None:
@@ -193,7 +203,9 @@ class RoleLearner:
         multi = _dist_ready()
         if use_graph and self._graphs is None:
             self._graphs = self._capture()
-        if use_graph and self._graphs:
+        import os
+        dbg = os.environ.get("CAT_DBG_GRAPH", "ab")
+        if use_graph and self._graphs and "a" in dbg:
             ga, gb = self._graphs
             ga.replay()
         else:
@@ -201,7 +213,8 @@ class RoleLearner:
         if multi:
             dist.all_reduce(self.ar, op=dist.ReduceOp.SUM)                             # RCCL over xGMI on a GPU node
             self.ar.div_(dist.get_world_size())
-        if use_graph and self._graphs:
+        if use_graph and self._graphs and "b" in dbg:
+            ga, gb = self._graphs
             gb.replay()
         else:
             self._step_apply()
@@ -272,15 +285,26 @@ class MAPPOTrainer:
         role_cfg = role_cfg or {}
         on_gpu = self.device.type == "cuda"
         dt = torch.bfloat16 if (self.tcfg.compute_bf16 and on_gpu) else torch.float32
+        # roles configured alike are stacked into ONE learner (key "cop+thief"); otherwise one learner per role
+        cfgs = {r: dataclasses.replace(role_cfg.get(r, CFG_AGENT)) for r in ("cop", "thief")
+                if any(a.startswith(r) for a in self.agents)}
+        groups: List[List[str]] = []
+        for r in cfgs:
+            for grp in groups:
+                if cfgs[grp[0]] == cfgs[r]:
+                    grp.append(r)
+                    break
+            else:
+                groups.append([r])
         self.roles: Dict[str, RoleLearner] = {}
-        for role in ("cop", "thief"):
-            names = [a for a in self.agents if a.startswith(role)]
-            if not names:
-                continue
+        for grp in groups:
+            names = [a for a in self.agents if a.split("_")[0] in grp]
             idx = [self.agents.index(a) for a in names]
-            self.roles[role] = RoleLearner(role, names, idx, self.R, self.N, self.tcfg.horizon,
-                                           dataclasses.replace(role_cfg.get(role, CFG_AGENT)), self.device, dt,
-                                           seeds=[seed * 1000 + i for i in idx])
+            self.roles["+".join(grp)] = RoleLearner("+".join(grp), names, idx, self.R, self.N, self.tcfg.horizon, cfgs[grp[0]],
+                                                    self.device, dt, seeds=[seed * 1000 + i for i in idx])
+        for rl in self.roles.values():
+            mask = [r in self.tcfg.random_action_roles for r in rl.agent_roles]
+            rl.random_rows = torch.tensor(mask, device=self.device).view(rl.G, 1) if any(mask) else None
         self._gen = torch.Generator(device="cpu").manual_seed(seed)
         torch.manual_seed(seed)
         self.timestep = 0
@@ -321,15 +345,15 @@ class MAPPOTrainer:
                 logp_all = torch.log_softmax(logits[:, 0].float(), dim=-1)                               # [G, N, 4]
                 if random_actions:
                     act = torch.randint(0, 4, (rl.G, N), generator=self._gen).to(self.device)
-                elif rl.role in self.tcfg.random_action_roles:
-                    act = torch.randint(0, 4, (rl.G, N), device=self.device)
                 else:
                     act = torch.multinomial(logp_all.exp().view(rl.G * N, 4), 1).view(rl.G, N)
+                    if rl.random_rows is not None:   # rows of the roles in TrainerConfig.random_action_roles
+                        act = torch.where(rl.random_rows, torch.randint(0, 4, (rl.G, N), device=self.device), act)
                 b = rl.buf
                 b["pin"][:, t].copy_(pin); b["vin"][:, t].copy_(vin); b["act"][:, t].copy_(act)
                 b["logp"][:, t].copy_(logp_all.gather(-1, act.unsqueeze(-1)).squeeze(-1))
                 b["val"][:, t].copy_(val[:, 0, :, 0].float())
-                self._actions[:, rl.indices] = act.t().to(torch.int32)
+                self._actions.index_copy_(1, rl.index_t, act.t().to(torch.int32))    # device index: capturable
             self._obs, rewards, terms, truncs, infos = self.env.step(self._actions)
             done = terms[self.agents[0]]
             for rl in self.roles.values():
@@ -389,9 +413,14 @@ class MAPPOTrainer:
         return out
 
     def set_frozen(self, role: Optional[str] = None, policy: Optional[bool] = None, value: Optional[bool] = None) -> None:
-        for r, rl in self.roles.items():
-            if role is None or r == role:
-                rl.set_frozen(policy, value)
+        for rl in self.roles.values():
+            rl.set_frozen(role, policy, value)
+
+    def learner_of(self, agent: str) -> Tuple[RoleLearner, int]:
+        for rl in self.roles.values():
+            if agent in rl.agents:
+                return rl, rl.agents.index(agent)
+        raise KeyError(agent)
 
     def train(self, timesteps: Optional[int] = None, freeze_policies_first: bool = True) -> Dict[str, float]:
         """One ``SequentialTrainer.train()`` of the reference's simultaneous mode (``agent_learning_utils.py:172-197``):
@@ -417,26 +446,30 @@ class MAPPOTrainer:
     # ------------------------------------------------------------------ checkpoints
     def agent_models(self, agent: str) -> Dict[str, Dict[str, torch.Tensor]]:
         """{"policy": sd, "value": sd} with the reference modules' parameter names (models.LSTMPolicy / LSTMValue)."""
-        rl = self.roles[agent.split("_")[0]]
-        return agent_state_dict(rl.fp, rl.agents.index(agent))
+        rl, g = self.learner_of(agent)
+        return agent_state_dict(rl.fp, g)
 
     def state_dict(self) -> dict:
-        """The "full agent" (reference ``MAPPO.save``: every model and optimiser) plus the trainer position."""
-        return {"format": "cat-mappo-1", "timestep": self.timestep, "num_rays": self.R,
-                "models": {a: self.agent_models(a) for a in self.agents},
-                "optimizers": {r: {"m": rl.m.clone(), "v": rl.v.clone(), "steps": rl.steps.clone()} for r, rl in self.roles.items()}}
+        """The "full agent" (reference ``MAPPO.save``: every model and optimiser) plus the trainer position.  Everything
+        is stored per agent, so a checkpoint does not depend on how the agents were stacked."""
+        opt = {}
+        for a in self.agents:
+            rl, g = self.learner_of(a)
+            opt[a] = {"m": rl.m[g].clone(), "v": rl.v[g].clone(), "steps": rl.steps[g].clone()}
+        return {"format": "cat-mappo-2", "timestep": self.timestep, "num_rays": self.R,
+                "models": {a: self.agent_models(a) for a in self.agents}, "optimizers": opt}
 
     def load_state_dict(self, sd: dict, roles: Optional[List[str]] = None, optimizer: bool = True) -> None:
         """``roles``: restrict to these roles' models (reference ``copy_role_models``, which copies policy and value
         weights only: pass ``optimizer=False`` for that)."""
-        for role, rl in self.roles.items():
-            if roles is not None and role not in roles:
+        for a in self.agents:
+            if roles is not None and a.split("_")[0] not in roles:
                 continue
-            for g, a in enumerate(rl.agents):
-                load_agent_state_dict(rl.fp, g, sd["models"][a])
-            if optimizer and "optimizers" in sd and role in sd["optimizers"]:
-                o = sd["optimizers"][role]
-                rl.m.copy_(o["m"]); rl.v.copy_(o["v"]); rl.steps.copy_(o["steps"])
+            rl, g = self.learner_of(a)
+            load_agent_state_dict(rl.fp, g, sd["models"][a])
+            if optimizer and a in sd.get("optimizers", {}):
+                o = sd["optimizers"][a]
+                rl.m[g].copy_(o["m"]); rl.v[g].copy_(o["v"]); rl.steps[g].copy_(o["steps"])
         if optimizer and roles is None:
             self.timestep = int(sd.get("timestep", 0))
 

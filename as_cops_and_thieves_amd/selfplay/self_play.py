@@ -76,9 +76,11 @@ def evaluate_agents(env, runner: MAPPOTrainer, n_episodes: int, random_roles: Tu
             logits, state[r] = rl.policy.forward(pin.unsqueeze(1), state[r], keep)
             probs = torch.softmax(logits[:, 0].float(), dim=-1)
             act = torch.multinomial(probs.view(rl.G * N, 4), 1).view(rl.G, N)
-            if r in random_roles:                       # a uniformly random opponent (not part of the reference protocol)
-                act = torch.randint(0, 4, (rl.G, N), device=runner.device)
-            actions[:, rl.indices] = act.t().to(torch.int32)
+            rnd = [ar in random_roles for ar in rl.agent_roles]
+            if any(rnd):                                # a uniformly random opponent (not part of the reference protocol)
+                rows = torch.tensor(rnd, device=runner.device).view(rl.G, 1)
+                act = torch.where(rows, torch.randint(0, 4, (rl.G, N), device=runner.device), act)
+            actions.index_copy_(1, rl.index_t, act.t().to(torch.int32))
         obs, _, terms, _, infos = env.step(actions)
         done = terms[runner.agents[0]]
         first = open_ & done

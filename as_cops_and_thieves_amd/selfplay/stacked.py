@@ -185,9 +185,32 @@ def role_param_shapes(R: int) -> Dict[str, Tuple[int, ...]]:
     return out
 
 
+class _Lin(torch.autograd.Function):
+    """y = x @ w^T + b for G stacked layers: x [G, M, in], w [G, out, in], b [G, out].  The bias gradient is a GEMM with a
+    row of ones, not a column reduction: ``at::sum`` over hundreds of thousands of rows is a multi-block reduction with
+    a semaphore buffer, and inside a replayed HIP graph of the backward pass that reduction returned garbage for
+    exactly these bias gradients (ROCm 7.2 / torch 2.10; weights and activations were right).  A GEMM has no such state
+    and accumulates in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.baddbmm(b.unsqueeze(1), x, w.transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, go):
+        x, w = ctx.saved_tensors
+        go = go.contiguous()
+        dx = torch.bmm(go, w) if ctx.needs_input_grad[0] else None
+        dw = torch.bmm(go.transpose(1, 2), x)
+        ones = torch.ones(go.shape[0], 1, go.shape[1], dtype=go.dtype, device=go.device)
+        db = torch.bmm(ones, go).squeeze(1)
+        return dx, dw, db
+
+
 def _lin(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """x [G, M, in] @ w[G, out, in]^T + b[G, out]"""
-    return torch.baddbmm(b.unsqueeze(1), x, w.transpose(1, 2))
+    return _Lin.apply(x, w, b)
 
 
 class StackedNet:

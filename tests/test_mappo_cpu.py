@@ -133,7 +133,9 @@ def test_timestep_schedule_random_phase_learning_starts_and_freeze_durations():
     rc = _rc(random_timesteps=8, learning_starts=16)
     tr = MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=8, timesteps=48, policy_freeze_duration=24,
                                                                      opponent_freeze_duration=24))
-    rl = tr.roles["cop"]
+    assert list(tr.roles) == ["cop+thief"]          # same RoleConfig for both roles: one stacked learner of 3 agents
+    rl = tr.roles["cop+thief"]
+    assert rl.agents == ["cop_0", "cop_1", "thief_0"]
     p0 = rl.fp.master.clone()
     tr.train()
     assert tr.timestep == 48
@@ -144,25 +146,25 @@ def test_timestep_schedule_random_phase_learning_starts_and_freeze_durations():
     assert float((d * rl.col_policy).abs().max()) > 0 and float((d * rl.col_value).abs().max()) > 0
     tr2 = MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=8, timesteps=24, policy_freeze_duration=1000,
                                                                       opponent_freeze_duration=1000))
-    q0 = tr2.roles["thief"].fp.master.clone()
+    rl2, g = tr2.learner_of("thief_0")
+    q0 = rl2.fp.master.clone()
     tr2.train()
-    d2 = tr2.roles["thief"].fp.master - q0
-    assert float((d2 * tr2.roles["thief"].col_policy).abs().max()) == 0.0        # frozen for the whole call
-    assert float((d2 * tr2.roles["thief"].col_value).abs().max()) > 0
+    d2 = (rl2.fp.master - q0)[g]
+    assert float((d2 * rl2.col_policy).abs().max()) == 0.0        # frozen for the whole call
+    assert float((d2 * rl2.col_value).abs().max()) > 0
 
 
 def test_masked_adam_equals_torch_adam_and_frozen_entries_do_not_move():
     """The flat masked Adam against torch.optim.Adam on the same gradients (what skrl constructs), with the policy
     half frozen for the first steps: frozen entries keep their value, their moments and their step count."""
     tr = MAPPOTrainer(_env(), {"cop": _rc(learning_rate=1e-2, grad_norm_clip=1e9), "thief": _rc()}, TrainerConfig(horizon=4))
+    assert sorted(tr.roles) == ["cop", "thief"]     # different RoleConfigs: one learner per role
     rl = tr.roles["cop"]
-    ref = rl.fp.master.clone().requires_grad_(True)
-    opt = torch.optim.Adam([ref], lr=1e-2)
     gen = torch.Generator().manual_seed(0)
     pol = rl.col_policy.bool()
     for k in range(6):
         frozen = k < 2
-        rl.set_frozen(policy=frozen, value=False)
+        rl.set_frozen("cop", policy=frozen, value=False)
         g = torch.randn(rl.G, rl.fp.P, generator=gen) * rl.fp.column_mask("")     # padding columns carry no gradient
         rl.ar[:, :-1].copy_(g); rl.ar[:, -1] = 0.0
         rl.epoch_active.fill_(1.0)
@@ -172,12 +174,10 @@ def test_masked_adam_equals_torch_adam_and_frozen_entries_do_not_move():
             assert torch.equal(rl.fp.master[:, pol], before[:, pol])
     # the value half took 6 steps of plain Adam, the policy half 4 (steps 2..5): replay both with torch.optim.Adam
     gen = torch.Generator().manual_seed(0)
-    refv = tr.roles["cop"].fp.master.clone()
-    opt_v = torch.optim.Adam([ref], lr=1e-2)
     grads = [torch.randn(rl.G, rl.fp.P, generator=gen) * rl.fp.column_mask("") for _ in range(6)]
     w_v = torch.nn.Parameter(torch.zeros(rl.G, int((~pol).sum())))
     w_p = torch.nn.Parameter(torch.zeros(rl.G, int(pol.sum())))
-    tr0 = MAPPOTrainer(_env(), {"cop": _rc(), "thief": _rc()}, TrainerConfig(horizon=4))      # same seed: same initial weights
+    tr0 = MAPPOTrainer(_env(), {"cop": _rc(learning_rate=1e-2), "thief": _rc()}, TrainerConfig(horizon=4))   # same seed: same initial weights
     w_v.data.copy_(tr0.roles["cop"].fp.master[:, ~pol]); w_p.data.copy_(tr0.roles["cop"].fp.master[:, pol])
     ov, op = torch.optim.Adam([w_v], lr=1e-2), torch.optim.Adam([w_p], lr=1e-2)
     for k, g in enumerate(grads):
@@ -216,20 +216,26 @@ def test_checkpoints_use_the_reference_module_names_and_resume_exactly(tmp_path)
     sd = tr.state_dict()
     torch.save(sd, tmp_path / "joint_iter_0_full_agent.pt")
     sd = torch.load(tmp_path / "joint_iter_0_full_agent.pt", weights_only=False)
-    assert set(sd["models"]) == {"cop_0", "cop_1", "thief_0"} and set(sd["optimizers"]) == {"cop", "thief"}
+    assert set(sd["models"]) == {"cop_0", "cop_1", "thief_0"} and set(sd["optimizers"]) == {"cop_0", "cop_1", "thief_0"}
     LSTMPolicy(16).load_state_dict(sd["models"]["cop_1"]["policy"])          # loadable by the reference-shaped modules
     LSTMValue(16).load_state_dict(sd["models"]["thief_0"]["value"])
-    tr2 = MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=4), seed=99)
+    # resume into a trainer whose agents are stacked DIFFERENTLY (one learner per role): checkpoints are per agent
+    tr2 = MAPPOTrainer(_env(), {"cop": rc, "thief": _rc(learning_rate=5e-4)}, TrainerConfig(horizon=4), seed=99)
+    assert sorted(tr2.roles) == ["cop", "thief"]
     tr2.load_state_dict(sd)
-    for r in tr.roles:
-        assert torch.equal(tr.roles[r].fp.master, tr2.roles[r].fp.master) and torch.equal(tr.roles[r].m, tr2.roles[r].m)
-        assert torch.equal(tr.roles[r].steps, tr2.roles[r].steps)
+    for a in tr.agents:
+        (l1, g1), (l2, g2) = tr.learner_of(a), tr2.learner_of(a)
+        assert torch.equal(l1.fp.master[g1], l2.fp.master[g2]) and torch.equal(l1.m[g1], l2.m[g2])
+        assert torch.equal(l1.steps[g1], l2.steps[g2])
     assert tr2.timestep == tr.timestep
     tr3 = MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=4), seed=98)
-    before = tr3.roles["thief"].fp.master.clone()
+    rl3 = tr3.roles["cop+thief"]
+    before = rl3.fp.master.clone()
     tr3.load_state_dict(sd, roles=["cop"], optimizer=False)                  # copy_role_models: one role's weights only
-    assert torch.equal(tr3.roles["cop"].fp.master, tr.roles["cop"].fp.master)
-    assert torch.equal(tr3.roles["thief"].fp.master, before) and float(tr3.roles["cop"].m.abs().max()) == 0.0
+    for a in ("cop_0", "cop_1"):
+        assert torch.equal(rl3.fp.master[rl3.agents.index(a)], tr.learner_of(a)[0].fp.master[tr.learner_of(a)[1]])
+    g = rl3.agents.index("thief_0")
+    assert torch.equal(rl3.fp.master[g], before[g]) and float(rl3.m.abs().max()) == 0.0
 
 
 def _ddp_worker(rank, world, port, q, kl):
@@ -244,7 +250,7 @@ def _ddp_worker(rank, world, port, q, kl):
     tr.train()
     flat = torch.cat([rl.fp.master.reshape(-1) for rl in tr.roles.values()])
     steps = torch.cat([rl.steps.amax(dim=1) for rl in tr.roles.values()])
-    q.put((rank, flat.numpy().copy(), steps.numpy().copy(), float(tr.roles["cop"].buf["pin"].double().sum())))
+    q.put((rank, flat.numpy().copy(), steps.numpy().copy(), float(next(iter(tr.roles.values())).buf["pin"].double().sum())))
     dist.barrier()
     dist.destroy_process_group()
 
