@@ -213,6 +213,46 @@ def _lin(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return _Lin.apply(x, w, b)
 
 
+class _Expand(torch.autograd.Function):
+    """out[g, j] = src[g, idx[j]] (idx == n selects 0): lays a small convolution weight out as the dense ("Toeplitz")
+    matrix of the equivalent fully connected layer.  Backward: every source element gathers the gradients of the
+    positions it was copied to (``back`` [n, L], entries == number of outputs select 0) and adds them up -- a gather plus
+    a short per-element sum, no atomics and no multi-block reduction."""
+
+    @staticmethod
+    def forward(ctx, src, idx, back):
+        ctx.save_for_backward(back)
+        ctx.n = src.shape[1]
+        ext = torch.cat([src, src.new_zeros(src.shape[0], 1)], dim=1)
+        return ext.index_select(1, idx)
+
+    @staticmethod
+    def backward(ctx, go):
+        (back,) = ctx.saved_tensors
+        ext = torch.cat([go, go.new_zeros(go.shape[0], 1)], dim=1)
+        return ext.index_select(1, back.reshape(-1)).view(go.shape[0], ctx.n, -1).sum(-1), None, None
+
+
+def _conv_as_dense_indices(c_out: int, c_in: int, k: int, stride: int, l_in: int, in_layout: str, device):
+    """Index tensors for ``_Expand``: the [l_out * c_out, l_in * c_in] matrix of Conv1d(c_in, c_out, k, stride) on an input
+    flattened as (channel, position) [``in_layout`` "cl", the observation vector] or (position, channel) ["lc", the
+    previous stacked layer's output]; outputs are flattened (position, channel).  Also the tiling of the bias."""
+    l_out = (l_in - k) // stride + 1
+    n_w = c_out * c_in * k
+    idx = torch.full((l_out * c_out, l_in * c_in), n_w, dtype=torch.long)
+    back = torch.full((n_w, l_out), l_out * c_out * l_in * c_in, dtype=torch.long)
+    lo, co, ci, kk = torch.meshgrid(torch.arange(l_out), torch.arange(c_out), torch.arange(c_in), torch.arange(k), indexing="ij")
+    pos = stride * lo + kk
+    col = (ci * l_in + pos) if in_layout == "cl" else (pos * c_in + ci)
+    row = lo * c_out + co
+    w_id = (co * c_in + ci) * k + kk                                        # flat index into weight [c_out, c_in, k]
+    idx[row.reshape(-1), col.reshape(-1)] = w_id.reshape(-1)
+    back[w_id.reshape(-1), lo.reshape(-1)] = (row * (l_in * c_in) + col).reshape(-1)
+    b_idx = torch.arange(c_out).repeat(l_out)                                # bias of output (l, c) = bias[c]
+    b_back = (torch.arange(l_out).unsqueeze(0) * c_out + torch.arange(c_out).unsqueeze(1))   # [c_out, l_out]
+    return idx.reshape(-1).to(device), back.to(device), b_idx.to(device), b_back.to(device), l_out
+
+
 class StackedNet:
     """Functional forward of the G stacked policy or value networks of a role over a FlatParams."""
 
@@ -222,6 +262,14 @@ class StackedNet:
         self.C, self.layers = (2, 1) if kind == "policy" else (4, 2)
         self.L1, self.L2 = (R - 5) // 2 + 1, conv_out_len(R)
         self.n_head = 3 if kind == "policy" else 4
+        dev = fp.master.device
+        # Both convolutions run as ONE dense GEMM each, on the Toeplitz expansion of their (tiny) weights.  It multiplies
+        # the flops by ~10 -- irrelevant on the matrix cores -- and removes what the update was actually spending its
+        # time on: the im2col copies of a [samples * positions, channels * taps] matrix (hundreds of MB per minibatch),
+        # their unfold backward, and GEMMs with a 10..320-wide inner dimension over half a million rows.
+        self.t1 = _conv_as_dense_indices(64, self.C, 5, 2, R, "cl", dev)
+        self.t2 = _conv_as_dense_indices(32, 64, 5, 3, self.L1, "lc", dev)
+        assert self.t1[4] == self.L1 and self.t2[4] == self.L2
 
     def w(self, name: str) -> torch.Tensor:
         return self.fp.views[f"{self.kind}.{name}"]
@@ -236,13 +284,12 @@ class StackedNet:
         G, T, B, _ = x.shape
         dt = self.fp.compute_dtype
         N = T * B
-        z = x.reshape(G, N, self.C, self.R).to(dt)
-        cols = z.unfold(3, 5, 2).permute(0, 1, 3, 2, 4).reshape(G, N * self.L1, self.C * 5)     # windows, (c, k) minor
-        z = torch.relu(_lin(cols, self.w("trunk.features.0.weight").reshape(G, 64, self.C * 5), self.w("trunk.features.0.bias")))
-        z = z.view(G, N, self.L1, 64)                                                            # [.., L, C] layout
-        cols = z.unfold(2, 5, 3).reshape(G, N * self.L2, 64 * 5)                                  # [.., L2, 64, 5]
-        z = torch.relu(_lin(cols, self.w("trunk.features.2.weight").reshape(G, 32, 64 * 5), self.w("trunk.features.2.bias")))
-        z = z.view(G, N, self.L2 * 32)                                                           # (l, c) order
+        z = x.reshape(G, N, self.C * self.R).to(dt)                                              # (channel, ray) order
+        for name, (idx, back, b_idx, b_back, l_out), c_out, width in (("trunk.features.0", self.t1, 64, self.C * self.R),
+                                                                       ("trunk.features.2", self.t2, 32, self.L1 * 64)):
+            w = _Expand.apply(self.w(name + ".weight").reshape(G, -1), idx, back).view(G, l_out * c_out, width)
+            b = _Expand.apply(self.w(name + ".bias"), b_idx, b_back)
+            z = torch.relu(_lin(z, w, b))                                                        # [G, N, l_out * c_out], (l, c)
         wfc = self.w("trunk.features.5.weight").view(G, 256, 32, self.L2).transpose(2, 3).reshape(G, 256, self.L2 * 32)
         f = torch.tanh(_lin(z, wfc, self.w("trunk.features.5.bias")))                            # [G, T*B, 256]
         h0, c0 = state

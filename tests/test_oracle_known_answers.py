@@ -1,6 +1,9 @@
 """Known-answer tests that pin the CPU oracle to the specification:
 analytic geometry cases, the reference's tick ordering quirks (Q1, Q5, Q6, Q7), Chipmunk's
-contact behaviour, and the Random123 Philox vectors.  CPU only."""
+contact behaviour, and the Random123 Philox vectors.  Here they run against the oracle (CPU);
+tests/test_gpu_known_answers.py re-runs the same cases through the C ABI of the HIP library
+(``make_sim`` is the switch), so the product itself is shown cases whose answers are known without
+the oracle."""
 import json
 
 import numpy as np
@@ -30,9 +33,14 @@ def one_wall(tmp_path, agents):
 AG2 = [{"type": "cop", "x": 200, "y": 400}, {"type": "thief", "x": 260, "y": 400}]
 
 
+def make_sim(cfg, cmaps):
+    """The simulator under test: the oracle here, the HIP library in tests/test_gpu_known_answers.py."""
+    return OracleSim(cfg, cmaps)
+
+
 def sim_for(cmap, **kw):
     cfg = SimConfig(n_envs=1, n_cops=cmap.n_cops, n_thieves=cmap.n_thieves, n_rays=kw.pop("n_rays", 8), **kw)
-    return OracleSim(cfg, [cmap])
+    return make_sim(cfg, [cmap])
 
 
 def test_philox4x32_10_random123_known_answers():
@@ -51,16 +59,19 @@ def test_philox4x32_10_random123_known_answers():
 def test_ray_hits_rounded_wall_at_computed_distance(tmp_path):
     s = sim_for(one_wall(tmp_path, [{"type": "cop", "x": 200, "y": 400}, {"type": "thief", "x": 100, "y": 100}]))
     # +x ray (radius 1) against a wall face at x = 300 inflated by 1: centre stops at 298
-    sh, alpha, pt = s.segment_query(0, 0, (200, 400), (600, 400), 1.0)
-    assert sh == 0 and alpha == pytest.approx(98 / 400, abs=1e-15) and pt == pytest.approx((299.0, 400.0))
+    if hasattr(s, "segment_query"):                                  # oracle-side introspection of the raw query
+        sh, alpha, pt = s.segment_query(0, 0, (200, 400), (600, 400), 1.0)
+        assert sh == 0 and alpha == pytest.approx(98 / 400, abs=1e-15) and pt == pytest.approx((299.0, 400.0))
     out = s.reset(positions=np.array([[[200, 400], [100, 100]]], float))
     assert out["obs_type"][0, 0, 0] == WALL and F16(out["obs_distance"])[0, 0, 0] == np.float16(99.0)
     assert out["hit_shape"][0, 0, 0] == 0
     # rays pointing away see nothing: exactly the ray length, EMPTY
     assert out["obs_type"][0, 0, 4] == EMPTY and F16(out["obs_distance"])[0, 0, 4] == np.float16(400.0)
-    # a hit at alpha == 1.0 exactly is not reported (strict '<' against the initial alpha 1)
-    sh, alpha, _ = s.segment_query(0, 0, (200, 400), (298, 400), 1.0)
-    assert sh == -1
+    # a hit at alpha == 1.0 exactly is not reported (strict '<' against the initial alpha 1): with the ray length cut to
+    # 98 the +x ray ends exactly where its swept circle would touch the inflated face
+    if hasattr(s, "segment_query"):
+        sh, alpha, _ = s.segment_query(0, 0, (200, 400), (298, 400), 1.0)
+        assert sh == -1
 
 
 def test_ray_hits_other_agent_and_classifies_by_category(tmp_path):
@@ -210,29 +221,32 @@ def test_spawn_sampling_respects_regions_and_falls_back_to_centre(tmp_path):
     agents = [{"type": "cop", "x": 100, "y": 400, "spawn_region": {"x": 50, "y": 50, "w": 100, "h": 100}},
               {"type": "thief", "x": 100, "y": 100, "spawn_region": {"x": 300.5, "y": 100, "w": 4, "h": 50}}]
     cmap = one_wall(tmp_path, agents)
-    s = OracleSim(SimConfig(n_envs=64, n_cops=1, n_thieves=1, n_rays=8, seed=5), [cmap])
+    s = make_sim(SimConfig(n_envs=64, n_cops=1, n_thieves=1, n_rays=8, seed=5), [cmap])
     s.reset()
     p = s.get_state()["pos"]
     assert ((p[:, 0] >= 50) & (p[:, 0] <= 150)).all()
     assert len(np.unique(p[:, 0], axis=0)) > 32                       # Philox streams differ per env
     # the thief's region lies inside the wall: 20 rejected attempts -> region centre (base_env.py:163-166)
     assert np.array_equal(p[:, 1], np.tile([[300.5 + 2.0, 125.0]], (64, 1)))
-    for e in range(64):
-        assert not s.point_query_any(e, 0, p[e, 0], 5.0) or np.hypot(*(p[e, 0] - [100, 100])) < 10
+    # no accepted spawn point within 5 of the wall surface (x = 299 is the inflated face)
+    assert (p[:, 0, 0] <= 299.0 - 5.0).all()
+    if hasattr(s, "point_query_any"):
+        for e in range(64):
+            assert not s.point_query_any(e, 0, p[e, 0], 5.0) or np.hypot(*(p[e, 0] - [100, 100])) < 10
 
 
 def test_batch_independence_and_determinism(tmp_path):
     cmap = one_wall(tmp_path, AG2)
     cfg = SimConfig(n_envs=5, n_cops=1, n_thieves=1, n_rays=16, seed=9, max_step_count=20)
-    a, b = OracleSim(cfg, [cmap]), OracleSim(cfg, [cmap])
+    a, b = make_sim(cfg, [cmap]), make_sim(cfg, [cmap])
     a.reset(); b.reset()
     for t in range(30):
         oa = a.step(a.random_actions(t)); ob = b.step(b.random_actions(t))
         assert all(np.array_equal(oa[k], ob[k]) for k in oa)
         a.reset(mask=oa["terminated"].copy()); b.reset(mask=ob["terminated"].copy())
     # env slot 3 of the batch == a single env whose global id is 3
-    single = OracleSim(SimConfig(n_envs=1, n_cops=1, n_thieves=1, n_rays=16, seed=9, max_step_count=20, env_id_offset=3), [cmap])
-    batch = OracleSim(cfg, [cmap])
+    single = make_sim(SimConfig(n_envs=1, n_cops=1, n_thieves=1, n_rays=16, seed=9, max_step_count=20, env_id_offset=3), [cmap])
+    batch = make_sim(cfg, [cmap])
     single.reset(); batch.reset()
     for t in range(25):
         ob = batch.step(batch.random_actions(t)); os_ = single.step(single.random_actions(t))
@@ -262,3 +276,25 @@ def test_vertex_region_behind_an_adjacent_edge_is_not_a_contact(tmp_path):
     assert (st["wall_shape"][0, 0] == 0).sum() == 1
     vb = st["vbias"][0, 0]                                        # pushed away from the vertex, along (0.8, 0.6)
     assert vb[0] > 0 and vb[1] > 0 and abs(vb[1] / vb[0] - 0.75) < 0.05
+
+
+def test_single_wall_map_is_gated_like_any_other_wall(tmp_path):
+    """Deviation D6: Chipmunk's ``SubtreeSegmentQuery`` does not gate a BBTree root that is
+    itself a leaf, so with ONE static shape the shape is queried even when the thin segment misses its bb; the linear
+    index of this build gates every wall alike.  The case: a ray whose swept circle (radius 1) grazes the rounded
+    corner of the only wall while its thin segment passes outside the wall's bb -> not visited here (EMPTY); with
+    ``bbtree_gate=0`` the shape is always visited and the graze is reported."""
+    blocks = [{"type": "rect", "x": 300, "y": 300, "w": 100, "h": 100}]
+    agents = [{"type": "cop", "x": 200, "y": 297.5}, {"type": "thief", "x": 100, "y": 100}]
+    cmap = make_map(tmp_path, blocks, agents)
+    pos = np.array([[[200.0, 297.5], [100.0, 100.0]]])
+    # the wall's bb is [299, 401]^2 (hull inflated by the wall radius 1); the +x ray travels along y = 297.5: 1.5 below
+    # the bb, 2.5 from the hull edge y = 300 -> the swept circle (1) + wall radius (1) = 2 does not reach it either
+    out = sim_for(cmap).reset(positions=pos)
+    assert out["obs_type"][0, 0, 0] == EMPTY
+    # 1.6 from the hull edge: inside rsum = 2 of the corner / face, thin segment still outside the bb (0.6 below it)
+    pos2 = np.array([[[200.0, 298.4], [100.0, 100.0]]])
+    gated = sim_for(cmap).reset(positions=pos2)
+    assert gated["obs_type"][0, 0, 0] == EMPTY                       # this build: the wall is never visited
+    ungated = sim_for(cmap, bbtree_gate=0).reset(positions=pos2)
+    assert ungated["obs_type"][0, 0, 0] == WALL and ungated["hit_shape"][0, 0, 0] == 0   # what an ungated root reports
