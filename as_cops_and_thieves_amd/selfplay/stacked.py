@@ -73,9 +73,11 @@ class _LSTMSeq(torch.autograd.Function):
         h, c = h0, c0
         train = any(ctx.needs_input_grad)          # a rollout tick (no_grad) keeps nothing
         hs, cs, cys, wss, outs = [], [], [], [], []
+        # the mask at full shape, once: h and c are then masked by ONE multi-tensor kernel per step
+        kf = None if keep is None else keep.expand(T, *h0.shape).contiguous()
         for t in range(T):
-            if keep is not None:
-                h, c = h * keep[t], c * keep[t]
+            if kf is not None:
+                h, c = torch._foreach_mul((h, c), (kf[t], kf[t]))
             hg = torch.bmm(h, w_t)
             hy, cy, ws = _cell_fwd(xproj[t], hg, c)
             if train:
@@ -85,8 +87,8 @@ class _LSTMSeq(torch.autograd.Function):
         out = torch.stack(outs, 0) if T > 1 else outs[0].unsqueeze(0)
         if train:
             ctx.save_for_backward(w_hh, torch.stack(hs, 0), torch.stack(cs, 0), torch.stack(cys, 0), torch.stack(wss, 0),
-                                  keep if keep is not None else torch.empty(0))
-        ctx.has_keep = keep is not None
+                                  kf if kf is not None else torch.empty(0))
+        ctx.has_keep = kf is not None
         ctx.set_materialize_grads(False)           # unused final-state gradients arrive as None, not as zero tensors
         return out, h, c
 
@@ -104,7 +106,7 @@ class _LSTMSeq(torch.autograd.Function):
             dg, dc = _cell_bwd(dh_t, dc, cs[t], cys[t], wss[t])
             dh = torch.bmm(dg, w_hh)
             if ctx.has_keep:
-                dh, dc = dh * keep[t], dc * keep[t]
+                dh, dc = torch._foreach_mul((dh, dc), (keep[t], keep[t]))
             dgs[t] = dg
         dg_all = torch.stack(dgs, 0)                                             # [T, G, B, 4H] = d xproj
         G, H4 = dg_all.shape[1], dg_all.shape[3]

@@ -2,11 +2,12 @@
 """Headline benchmark: env-steps/sec of the batched Cops-and-Thieves env core on MI355X.
 
 One "step" = one tick of the whole env batch on every GPU: cat_step_fused = synthetic Philox actions
-generated in the step kernel + the full BaseEnv.step pipeline, then cat_reset_done (auto-reset of
-finished episodes on the device-side done mask).  Workload =
+generated in the step kernel + the full BaseEnv.step pipeline + the auto-reset of the episodes that end
+with the tick, ONE tick_kernel launch.  Workload =
 BASELINE.json configs[1]: 2 cops vs 1 thief, labyrinth map, 4096 envs per GPU, 64 rays/agent.
 Env slots shard across GPUs with no data-path collective (weak scaling); only the timing uses a
-barrier + MAX all-reduce.  Prints ONE JSON line on rank 0.
+barrier + MAX all-reduce.  Prints ONE JSON line on rank 0; at N = 1 it also carries `extra`: the other
+BASELINE shapes measured in the same run (kernel_ms each), the headline stays configs[1].
 """
 from __future__ import annotations
 
@@ -98,6 +99,53 @@ class HipEvents:
         return float(ms.value)
 
 
+EXTRA_WORKLOADS = (   # the other BASELINE.json shapes, measured in the same run beside the headline (N = 1 only)
+    ("agh-map 2v1 x4096 (configs[2] per-GPU shard)", dict(map="agh-map", cops=2, thieves=1, envs=4096)),
+    ("grandbyrinth 3v2 x8192 (configs[3])", dict(map="grandbyrinth", cops=3, thieves=2, envs=8192)),
+    ("five maps mixed 2v1 x16384 (configs[4])", dict(map="mixed", cops=2, thieves=1, envs=16384)),
+    ("labyrinth 2v1 x4096, every agent spawned inside the maze", dict(map="labyrinth-inside", cops=2, thieves=1, envs=4096)),
+)
+
+
+def build_sim(map_name: str, cops: int, thieves: int, envs: int, rays: int, rank: int, dev):
+    """CatSim for one bench workload: a preset map, or "mixed" = all five maps interleaved across env slots."""
+    import numpy as np
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.maps import load_preset
+    from as_cops_and_thieves_amd.sim import CatSim
+    if map_name == "mixed":   # BASELINE configs[4]
+        names = ["agh-map", "grandbyrinth", "labyrinth", "lbirinth", "squarinth"]
+        cmaps = [load_preset(n, cops, thieves).compile() for n in names]
+        slot = (np.arange(envs) % len(cmaps)).astype(np.int32)
+        cmap = cmaps[2]
+    else:
+        cmaps, slot = [load_preset(map_name, cops, thieves).compile()], None
+        cmap = cmaps[0]
+    cfg = SimConfig(n_envs=envs, n_cops=cops, n_thieves=thieves, n_rays=rays, max_step_count=400, seed=0,
+                    env_id_offset=rank * envs)
+    return CatSim(cfg, cmaps, slot, device=dev), cfg, cmap
+
+
+def timed_steps(sim, steps: int, warmup: int, fence, hip: "HipEvents"):
+    """W untimed + K timed rollout steps (cat_step_fused: in-kernel Philox actions + tick + auto-reset, ONE launch per
+    step).  Every EVENT_EVERY-th tick_kernel launch of the timed region carries a pair of HIP events attached to the
+    dispatch itself (hipExtLaunchKernelGGL start/stop events, on the stream the kernel is launched on), so kernel_ms is
+    the kernel's own duration, as in a rocprofv3 kernel trace; events recorded AROUND the call would add the
+    inter-kernel dispatch gap (~5 us here).  Returns (seconds of the timed region on this rank, mean kernel ms, launches timed)."""
+    for t in range(warmup):
+        sim.step_fused(None, tick=t, auto_reset=True)
+    ev = {k: (hip.create(), hip.create()) for k in range(0, steps, EVENT_EVERY)}
+    fence()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        if k in ev:
+            sim.arm_kernel_timing(*ev[k])
+        sim.step_fused(None, tick=warmup + k, auto_reset=True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    return elapsed, sum(hip.elapsed_ms(a, b) for a, b in ev.values()) / len(ev), len(ev)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,13 +157,11 @@ def main() -> None:
     ap.add_argument("--cops", type=int, default=2)
     ap.add_argument("--thieves", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE shapes (the `extra` object)")
     args = ap.parse_args()
 
     import torch
-    from as_cops_and_thieves_amd.config import SimConfig
-    from as_cops_and_thieves_amd.maps import load_preset
     from as_cops_and_thieves_amd.sharding import max_over_ranks
-    from as_cops_and_thieves_amd.sim import CatSim
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -125,6 +171,7 @@ def main() -> None:
                  f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ... "
                  f"(WORLD_SIZE is {world})")
     rehearse = os.environ.get("CAT_BENCH_REHEARSE") == "1"   # flow check on a 1-GPU box: gloo, ranks share the GPU
+    timing_backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -132,6 +179,7 @@ def main() -> None:
             local_rank %= torch.cuda.device_count()
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
+            timing_backend = "gloo (CAT_BENCH_REHEARSE=1: ranks share one GPU)"
         else:
             torch.cuda.set_device(local_rank)
             try:
@@ -139,61 +187,35 @@ def main() -> None:
                 probe = torch.zeros(1, device=torch.device("cuda", local_rank))
                 dist.all_reduce(probe)                                                        # fails here if RCCL cannot start
                 torch.cuda.synchronize()
+                timing_backend = "nccl (RCCL)"
             except Exception as exc:   # the simulator needs no collective: only the timing barrier / MAX does
                 print(f"[bench] RCCL unavailable ({exc!r}); timing reductions over gloo", file=sys.stderr, flush=True)
                 if dist.is_initialized():
                     dist.destroy_process_group()
                 dist.init_process_group("gloo")
                 rehearse = True   # CPU tensors for the reductions
+                timing_backend = f"gloo (RCCL could not start: {type(exc).__name__})"
     else:
         torch.cuda.set_device(0)
         local_rank = 0
     dev = torch.device("cuda", local_rank)
-
-    if args.map == "mixed":   # BASELINE configs[4]: all five maps interleaved across env slots
-        import numpy as np
-        names = ["agh-map", "grandbyrinth", "labyrinth", "lbirinth", "squarinth"]
-        cmaps = [load_preset(n, args.cops, args.thieves).compile() for n in names]
-        slot = (np.arange(args.envs) % len(cmaps)).astype(np.int32)
-        cmap = cmaps[2]
-    else:
-        cmaps, slot = [load_preset(args.map, args.cops, args.thieves).compile()], None
-        cmap = cmaps[0]
-    cfg = SimConfig(n_envs=args.envs, n_cops=args.cops, n_thieves=args.thieves, n_rays=args.rays,
-                    max_step_count=400, seed=0, env_id_offset=rank * args.envs)
-    sim = CatSim(cfg, cmaps, slot, device=dev)
-    sim.reset()
-    acts = torch.empty((cfg.n_envs, cfg.n_agents), dtype=torch.int32, device=dev)
-
-    def one_step(t: int) -> None:   # synthetic Philox actions are generated inside the step kernel
-        sim.step_fused(None, tick=t, auto_reset=True)
-
-    for t in range(args.warmup):
-        one_step(t)
 
     def fence() -> None:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # HIP events time every EVENT_EVERY-th tick_kernel launch of the timed region.  They are attached to the
-    # dispatch itself (hipExtLaunchKernelGGL start/stop events, on the stream the kernel is launched on), so the
-    # figure is the kernel's own duration, as in a rocprofv3 kernel trace; events recorded AROUND the call would
-    # add the inter-kernel dispatch gap (~5 us here).
     hip = HipEvents()
-    ev = {k: (hip.create(), hip.create()) for k in range(0, args.steps, EVENT_EVERY)}
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        t = args.warmup + k
-        if k in ev:
-            sim.arm_kernel_timing(*ev[k])
-        sim.step_fused(None, tick=t, auto_reset=True)   # tick_kernel (actions: in-kernel Philox) + reset_kernel on the done mask
-    fence()
-    elapsed = time.perf_counter() - t0
+    sim, cfg, cmap = build_sim(args.map, args.cops, args.thieves, args.envs, args.rays, rank, dev)
+    sim.reset()
+    elapsed, tick_ms, n_timed = timed_steps(sim, args.steps, args.warmup, fence, hip)
     elapsed = max_over_ranks(elapsed, device=None if rehearse else dev)   # the slowest rank bounds the whole-job rate
-    tick_ms = sum(hip.elapsed_ms(a, b) for a, b in ev.values()) / len(ev)
     episodes = int(sim.get_state()["reset_count"].sum().item())
+    sim.close()
+    offsets = [cfg.env_id_offset]
+    if world > 1:   # which global env ids each rank simulated (disjoint contiguous shards)
+        offsets = [None] * world
+        dist.all_gather_object(offsets, int(cfg.env_id_offset))
 
     copy_gbs = None
     if rank == 0 and world == 1:   # the HBM peak as a stream copy measures it on this box (read + write bytes)
@@ -206,15 +228,32 @@ def main() -> None:
         c1.record(); torch.cuda.synchronize(dev)
         copy_gbs = 10 * 2 * a.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del a, b
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extras:   # the other BASELINE shapes, same process, same box
+        extra = {}
+        for label, w in EXTRA_WORKLOADS:
+            s2, c2, m2 = build_sim(w["map"], w["cops"], w["thieves"], w["envs"], args.rays, 0, dev)
+            s2.reset()
+            k_steps = min(args.steps, 400)
+            e2, k2, _ = timed_steps(s2, k_steps, min(args.warmup, 100), fence, hip)
+            bytes2 = algorithmic_bytes_per_env_step(c2.n_agents, c2.n_rays) * c2.n_envs
+            extra[label] = {"value": c2.n_envs * k_steps / e2, "unit": "env-steps/s", "steps": k_steps,
+                            "ms_per_step": 1e3 * e2 / k_steps, "kernel_ms": k2,
+                            "roofline_frac": bytes2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            s2.close()
     if rank == 0:
         A, R = cfg.n_agents, cfg.n_rays
         bytes_launch = algorithmic_bytes_per_env_step(A, R) * cfg.n_envs
         achieved = bytes_launch / (tick_ms * 1e-3) / 1e9
-        traffic = valu = None   # HBM bytes per launch / VALU figures from the committed PMC passes of this exact workload, if any
-        tfile = ROOT / "profiles" / "r01_traffic.json"
-        if tfile.exists() and (args.map, cfg.n_envs, R, args.cops, args.thieves) == ("labyrinth", 4096, 64, 2, 1):
-            prof = json.loads(tfile.read_text())
-            traffic, valu = prof["hbm_bytes_per_launch"], prof.get("valu")
+        # HBM bytes per launch / VALU figures: NOT measured in this run (PMC counters need rocprofv3 passes of their own);
+        # replayed from the committed PMC summary of this exact workload and labelled as such
+        traffic = valu = traffic_source = None
+        for tfile in sorted((ROOT / "profiles").glob("r*_traffic.json"), reverse=True):
+            if (args.map, cfg.n_envs, R, args.cops, args.thieves) == ("labyrinth", 4096, 64, 2, 1):
+                prof = json.loads(tfile.read_text())
+                traffic, valu = prof["hbm_bytes_per_launch"], prof.get("valu")
+                traffic_source = f"profiles/{tfile.name} (committed rocprofv3 --pmc passes of this command; replayed, not measured in this run)"
+            break
         line = {
             "metric": "env-steps/sec (whole node) at 4096 parallel envs, 2v1 agents, 64-ray sensors",
             "value": world * cfg.n_envs * args.steps / elapsed,
@@ -228,22 +267,25 @@ def main() -> None:
                                    f"{R} rays/agent, dt=1/60, max_step_count=400, Philox random actions, auto-reset",
                        "envs_per_gpu": cfg.n_envs, "rays": R, "agents": A, "map": args.map,
                        "parallelism": f"env-sharded x{world}, no data-path collective",
-                       "episodes_reset_per_gpu": episodes},
+                       "episodes_reset_per_gpu": episodes, "env_id_offsets": offsets},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "tick_kernel", "kernel_ms": tick_ms, "kernel_launches_timed": len(ev),
-                         "algorithmic_bytes_per_launch": bytes_launch, "valu": valu,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "tick_kernel", "kernel_ms": tick_ms, "kernel_launches_timed": n_timed,
+                         "algorithmic_bytes_per_launch": bytes_launch, "valu": valu, "valu_source": traffic_source,
                          "hbm_stream_copy_GBs": copy_gbs,
                          "frac_of_stream_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "note": "path is FP64-VALU/LDS bound, not HBM bound (SURVEY 8d); fraction reported as contracted"},
         }
+        if timing_backend:
+            line["config"]["timing_reductions"] = timing_backend
+        if extra is not None:
+            line["extra"] = extra
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(cfg, cmap)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    sim.close()
 
 
 if __name__ == "__main__":

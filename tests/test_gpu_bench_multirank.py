@@ -1,0 +1,45 @@
+"""GPU: bench.py's N > 1 branch without an 8-GPU node.  Two fresh rank processes are started by
+torch.distributed.run (the launcher runs before anything touches the GPU) with CAT_BENCH_REHEARSE=1: both ranks use
+the one GPU of the box and the timing reductions go over gloo.  What is checked is the flow the driver's N = 2, 4, 8
+runs take: env shards keyed by disjoint env_id_offsets, barrier + MAX-over-ranks timing, ONE JSON line from rank 0
+whose value is the whole-job aggregate."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_two_rank_bench_prints_one_aggregate_line():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CAT_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    envs, steps = 1024, 60
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "10",
+           "--envs", str(envs)]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == steps and d["scaling"] == "weak"
+    assert d["config"]["env_id_offsets"] == [0, envs]               # disjoint contiguous shards of the global env ids
+    assert "gloo" in d["config"]["timing_reductions"]
+    assert "cpu_baseline" not in d and "extra" not in d             # N = 1 only
+    # whole-job aggregate: both ranks' env-steps over the slowest rank's time
+    assert d["value"] == pytest.approx(2 * envs * steps / (d["ms_per_step"] * 1e-3 * steps), rel=1e-9)
+    assert d["roofline"]["kernel_ms"] > 0 and d["value"] > 1e6
+
+
+def test_bench_refuses_a_rank_count_mismatch():
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                         env=dict(os.environ, WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "needs 2 ranks" in (res.stderr + res.stdout)

@@ -98,7 +98,8 @@ def test_trainer_schedule_and_stats_on_gpu():
     before = {r: rl.fp.master.clone() for r, rl in tr.roles.items()}
     stats = tr.train()
     assert tr.timestep == 96 and all(v == v for v in stats.values())          # no NaNs
-    rl = tr.roles["cop"]
+    assert list(tr.roles) == ["cop+thief"]          # same config for both roles: one stacked learner
+    rl = tr.roles["cop+thief"]
     assert float((rl.steps * rl.col_value).max()) == 5 * 4 and float((rl.steps * rl.col_policy).max()) == 2 * 4
     assert rl.fp.lp.dtype == torch.bfloat16 and rl.fp.master.device.type == "cuda"
     assert any(not torch.equal(before[r], rl.fp.master) for r, rl in tr.roles.items())
@@ -147,8 +148,8 @@ def test_self_play_protocol_on_baseline_config_3(tmp_path):
     assert sorted(p.name for p in (tmp_path / "cops").glob("cop_iter_*.pt")) == [f"cop_iter_{i}.pt" for i in range(4)]
     assert sorted(p.name for p in (tmp_path / "thieves").glob("thief_iter_*.pt")) == [f"thief_iter_{i}.pt" for i in range(4)]
     sd = torch.load(tmp_path / "joint_iter_3_full_agent.pt", weights_only=False)
-    assert set(sd["models"]) == {"cop_0", "cop_1", "cop_2", "thief_0", "thief_1"} and set(sd["optimizers"]) == {"cop", "thief"}
-    assert float(sd["optimizers"]["cop"]["steps"].max()) > 0
+    assert set(sd["models"]) == {"cop_0", "cop_1", "cop_2", "thief_0", "thief_1"} and set(sd["optimizers"]) == set(sd["models"])
+    assert float(sd["optimizers"]["cop_0"]["steps"].max()) > 0
     ev = res["iterations"][0]["evaluations"]
     assert len(ev["cop"]) == 3 and len(ev["thief"]) == 3               # every archived opponent once: 3 distinct ones exist
     for role in ("cops", "thieves"):
