@@ -22,6 +22,7 @@ OUT_FIELDS = ("obs_distance", "obs_type", "hit_shape", "shared_distance", "share
 STATE_FIELDS = ("pos", "vel", "vbias", "tc", "leaf_bb", "wall_shape", "wall_age", "wall_jn",
                 "pair_age", "pair_jn", "step_count", "reset_count")
 WALL_CACHE = 8
+DEVERR_BAD_ACTION, DEVERR_CONTACT_DROPPED = 1, 2
 
 ERRORS = {-1: "CAT_ERR_BAD_CONFIG", -2: "CAT_ERR_BAD_MAP", -3: "CAT_ERR_BAD_SLOT_MAP",
           -4: "CAT_ERR_NO_DEVICE", -5: "CAT_ERR_HIP", -6: "CAT_ERR_BAD_ARG"}
@@ -97,6 +98,7 @@ def lib() -> C.CDLL:
     L.cat_set_state.argtypes = [vp, vp, vp]
     L.cat_random_actions.argtypes = [vp, u64, vp, vp]
     L.cat_set_seed.argtypes = [vp, u64, vp]
+    L.cat_device_errors.argtypes = [vp, vp, i32, vp]
     L.cat_arm_kernel_timing.argtypes = [vp, vp, vp]
     L.cat_num_agents.argtypes = [vp]
     L.cat_num_shapes.argtypes = [vp, i32]
@@ -111,7 +113,7 @@ def lib() -> C.CDLL:
     L.cat_grid_free_host.argtypes = [vp]
     L.cat_grid_free_host.restype = None
     for name in ("cat_create", "cat_destroy", "cat_reset", "cat_reset_done", "cat_step", "cat_step_fused", "cat_get_state",
-                 "cat_set_state", "cat_random_actions", "cat_set_seed", "cat_arm_kernel_timing", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup"):
+                 "cat_set_state", "cat_random_actions", "cat_set_seed", "cat_device_errors", "cat_arm_kernel_timing", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup"):
         getattr(L, name).restype = i32
     _lib = L
     return L
@@ -119,5 +121,5 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = ("cat_abi_version", "cat_last_error", "cat_create", "cat_destroy", "cat_reset",
                     "cat_reset_done", "cat_step", "cat_step_fused", "cat_get_state", "cat_set_state", "cat_random_actions",
-                    "cat_set_seed", "cat_arm_kernel_timing", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup",
+                    "cat_set_seed", "cat_device_errors", "cat_arm_kernel_timing", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup",
                     "cat_grid_build_host", "cat_grid_lookup_host", "cat_grid_bytes_host", "cat_grid_free_host")

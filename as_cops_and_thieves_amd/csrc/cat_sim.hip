@@ -76,6 +76,7 @@ struct Params {
     const int *grid_off, *cgrid_off;
     const unsigned char *grid_ent, *cgrid_ent;
     const unsigned long long *cgrid_rows;   // per cell: count | first 7 contact-candidate wall ids (longer lists: the CSR arrays)
+    unsigned *err_word;     // device-side error flags (CAT_DEVERR_*), read back by cat_device_errors
     const int *work_env;    // [n_blocks*wpb] env slot or -1
     const int *block_map;   // [n_blocks]
     // Env state: one contiguous record per env slot (so a wave moves it with 16-byte lanes):
@@ -1152,7 +1153,10 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
                             const int ag = uni(L.wag[i * kK + k]);
                             if (!((seen_w >> (i * kK + k)) & 1ull) && ag > oldage) { oldest = k; oldage = ag; }
                         }
-                        if (oldest < 0) continue;
+                        if (oldest < 0) {   // all CAT_WALL_CACHE slots hold contacts of THIS step: the contact gets no constraint
+                            if (lane == 0) atomicOr(p.err_word, CAT_DEVERR_CONTACT_DROPPED);
+                            continue;
+                        }
                         slot = oldest;
                     }
                     L.wsh[i * kK + slot] = sh; L.wjn[i * kK + slot] = 0.0; L.wag[i * kK + slot] = 0;
@@ -1589,6 +1593,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
             int act;
             if (la.actions) act = la.actions[(size_t)env * A + i];
             else { unsigned rnd[4]; philox_env(p, env, (unsigned)la.synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
+            if ((unsigned)act > 3u) atomicOr(p.err_word, CAT_DEVERR_BAD_ACTION);   // applied as "no impulse", and flagged
             double jx = 0.0, jy = 0.0;
             if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
             else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
@@ -2148,6 +2153,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.cgrid_ent), s->grid.cent.size(), s->grid.cent.data()));
         TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.cgrid_rows), s->grid.crows.size(), s->grid.crows.data()));
     }
+    TRY_ALLOC(dev_alloc(s, &p.err_word, 1, nullptr));
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.work_env), work.size(), work.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.block_map), block_map.size(), block_map.data()));
     TRY_ALLOC(dev_alloc(s, &p.state, rec0.size(), rec0.data()));
@@ -2281,6 +2287,20 @@ extern "C" int cat_random_actions(cat_sim *s, uint64_t tick, int32_t *actions, v
     hipLaunchKernelGGL(random_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                        s->dev_p, (unsigned long long)tick, actions);
     HIP_TRY(s, hipGetLastError());
+    return CAT_OK;
+}
+
+extern "C" int cat_device_errors(cat_sim *s, uint32_t *flags, int clear, void *stream)
+{
+    if (!s || !flags) return CAT_ERR_BAD_ARG;
+    HIP_TRY(s, hipSetDevice(s->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(s, hipMemcpyAsync(flags, s->p.err_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (clear) HIP_TRY(s, hipMemsetAsync(s->p.err_word, 0, sizeof(uint32_t), st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+    if (*flags) snprintf(s->err, sizeof s->err, "device-side error flags 0x%x:%s%s", *flags,
+                         (*flags & CAT_DEVERR_BAD_ACTION) ? " an action outside 0..3 (applied as no impulse)" : "",
+                         (*flags & CAT_DEVERR_CONTACT_DROPPED) ? " a wall contact was dropped (more than CAT_WALL_CACHE simultaneous wall contacts of one agent)" : "");
     return CAT_OK;
 }
 

@@ -8,9 +8,9 @@ computed by the HIP kernels behind ``libcat_sim.so`` instead of Pymunk.  ``VecCo
 batched form of the same surface: same keys, values are torch tensors with a leading ``num_envs``
 axis, finished episodes auto-reset on device.
 
-pettingzoo itself is not imported (not installable here); the classes are duck-typed to the
-attributes its wrappers use.  There is no CPU path: constructing an env without the built
-extension or without a GPU raises.
+``BaseEnv`` subclasses ``pettingzoo.ParallelEnv`` when pettingzoo is importable (it is not installable in the build
+container, where the class is duck-typed to the attributes its wrappers use; ``tests/test_gpu_boundary_double.py``
+drives exactly those).  There is no CPU path: constructing an env without the built extension or without a GPU raises.
 """
 from __future__ import annotations
 
@@ -32,6 +32,13 @@ from .sim import CatSim
 
 WINNER_NAMES = {-1: None, 0: "cop", 1: "thief"}
 
+try:  # pragma: no cover - depends on the installation
+    from pettingzoo import ParallelEnv as _ParallelEnvBase  # type: ignore
+    HAVE_PETTINGZOO = True
+except ModuleNotFoundError:
+    _ParallelEnvBase = object
+    HAVE_PETTINGZOO = False
+
 
 def _physical_from_cwd() -> PhysicalParams:
     """The reference reads ``pyproject.toml [tool.physical-params]`` from the CWD
@@ -45,8 +52,8 @@ def _physical_from_cwd() -> PhysicalParams:
     return load_physical_params(None)
 
 
-class BaseEnv:
-    """Single-env PettingZoo-style surface (reference ``BaseEnv``, base_env.py:30-554)."""
+class BaseEnv(_ParallelEnvBase):
+    """Single-env PettingZoo ``ParallelEnv`` surface (reference ``BaseEnv(ParallelEnv)``, base_env.py:30-554)."""
 
     metadata = {"render_modes": ["human", "rgb_array"], "name": "cops_and_thieves_amd"}
 
@@ -354,6 +361,12 @@ class VecCopsEnv:
 
     def random_actions(self, tick: int) -> torch.Tensor:
         return self._sim.random_actions(tick, out=self._actions)
+
+    def check_errors(self) -> None:
+        """The step launches are asynchronous and cannot raise; this synchronises and raises ``ValueError`` if any
+        action since the last check was outside ``Discrete(4)`` (the reference raises at once), ``CatSimError`` if a
+        wall contact had to be dropped."""
+        self._sim.check_errors()
 
     def get_env_state(self) -> Dict[str, torch.Tensor]:
         """Full simulator state (bodies, caches, counters) for checkpointing."""

@@ -138,7 +138,7 @@ def run_self_play(map_name: str, num_envs: int, out_dir: Path, iterations: Optio
                   n_thieves: Optional[int] = None, max_step_count: int = 400, eval_envs: Optional[int] = None,
                   seed: int = 0, device=None, resume: bool = True, log=print, env_factory=None) -> Dict[str, object]:
     """The self-play loop.  ``resume``: continue after the highest iteration found in the archives ("latest").
-    ``env_factory(num_envs, seed)``: build the envs some other way (the CPU tests pass an oracle-backed stand-in)."""
+    ``env_factory(num_envs, seed)``: build the envs some other way (the CPU tests pass a stand-in env with the same surface)."""
     tc = training or TrainingConfig()
     iterations = tc.num_self_play_iterations if iterations is None else iterations
     trainer_cfg = trainer_cfg or TrainerConfig(timesteps=tc.training_timesteps_per_role_training)

@@ -147,6 +147,21 @@ class CatSim:
         """Attach two raw ``hipEvent_t`` handles to the NEXT step's tick-kernel dispatch (its own begin/end)."""
         self._check(self._L.cat_arm_kernel_timing(self._h, start_event, stop_event), "cat_arm_kernel_timing")
 
+    def device_errors(self, clear: bool = True) -> int:
+        """Device-side error flags raised by the kernels since the last clear (``_native.DEVERR_*``); synchronises."""
+        flags = C.c_uint32(0)
+        self._check(self._L.cat_device_errors(self._h, C.byref(flags), int(clear), self._stream()), "cat_device_errors")
+        return int(flags.value)
+
+    def check_errors(self) -> None:
+        """Raise for what the asynchronous launches could not report: an action outside 0..3 (the reference raises on
+        it) or a dropped wall contact."""
+        flags = self.device_errors()
+        if flags & nat.DEVERR_BAD_ACTION:
+            raise ValueError("an action outside 0..3 was passed to the step kernel (it was applied as 'no impulse')")
+        if flags & nat.DEVERR_CONTACT_DROPPED:
+            raise CatSimError("a wall contact was dropped: an agent touched more than WALL_CACHE walls in one step")
+
     def set_seed(self, seed: int) -> None:
         self.cfg.seed = int(seed) & (2**64 - 1)
         self._check(self._L.cat_set_seed(self._h, self.cfg.seed, self._stream()), "cat_set_seed")

@@ -135,8 +135,17 @@ int cat_reset_done(cat_sim *sim, const cat_outputs *out, void *stream);
    Entity.step/_perform_action/get_observation/_query_body (entity.py:126-241), Cop.reward /
    Thief.reward (cop.py:49-75, thief.py:48-69), get_shared_observations
    (src/environments/observation_spaces.py:67-131) and pymunk Space.step (call site :392).
-   actions: DEVICE [N,A] int32 in {0,1,2,3}. */
+   actions: DEVICE [N,A] int32 in {0,1,2,3}.  The launch is asynchronous, so an action outside 0..3 (the reference
+   raises on it: entity.py:126-134 indexes its impulse table) cannot fail the call: it is applied as "no impulse" and
+   raises CAT_DEVERR_BAD_ACTION in the handle's device-side error word -- read it with cat_device_errors. */
 int cat_step(cat_sim *sim, const int32_t *actions, const cat_outputs *out, void *stream);
+
+/* Device-side error flags raised by the kernels since the last clear (synchronises `stream`); flags != 0 also sets
+   cat_last_error.  CAT_DEVERR_CONTACT_DROPPED: an agent touched more than CAT_WALL_CACHE walls in one step and a
+   contact got no constraint (Chipmunk's arbiter hash has no such limit). */
+#define CAT_DEVERR_BAD_ACTION 1u
+#define CAT_DEVERR_CONTACT_DROPPED 2u
+int cat_device_errors(cat_sim *sim, uint32_t *flags, int clear, void *stream);
 
 /* One-LAUNCH form of the rollout tick: cat_step, the auto-reset of cat_reset_done (auto_reset != 0) and,
    when actions == NULL, the synthetic Philox actions of cat_random_actions for tick `synth_tick`, all inside
