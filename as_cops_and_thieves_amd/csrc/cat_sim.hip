@@ -79,11 +79,13 @@ struct Params {
     unsigned *err_word;     // device-side error flags (CAT_DEVERR_*), read back by cat_device_errors
     const int *work_env;    // [n_blocks*wpb] env slot or -1
     const int *block_map;   // [n_blocks]
-    // Env state: one contiguous record per env slot (so a wave moves it with 16-byte lanes):
-    //   f64  pos[2A] vel[2A] vbias[2A] tc[2A] leaf[4A] wall_jn[8A] pair_jn[NPs]
-    //   i32  wall_shape[8A] wall_age[8A] pair_age[NPs] step_count reset_count done pad
+    // Env state: one contiguous record per env slot (so a wave moves it with 16-byte lanes), in two parts:
+    //   HOT  (always moved)   f64  pos[2A] vel[2A] vbias[2A] tc[2A] leaf[4A]   i32  step_count reset_count done cache_live
+    //   COLD (arbiter caches) f64  wall_jn[8A] pair_jn[NPs]                    i32  wall_shape[8A] wall_age[8A] pair_age[NPs]
+    // The cold part is only read when cache_live says it holds something, and only written while it does: an agent
+    // in free space has no cached arbiter, and its slot then moves 96 A + 16 bytes per tick instead of the whole record.
     char *state;
-    int rec_bytes, rec_doubles;
+    int rec_bytes, hot_bytes;
     int maxE, ang_ok, row_words;
     float ang0, inv_step;
     // LDS carve (bytes)
@@ -101,18 +103,19 @@ struct DynDims {
     static __device__ __forceinline__ int NP(const Params &p) { return p.NP; }
     static __device__ __forceinline__ int maxc(const Params &p) { return p.maxc; }
     static __device__ __forceinline__ int rec_bytes(const Params &p) { return p.rec_bytes; }
-    static __device__ __forceinline__ int rec_doubles(const Params &p) { return p.rec_doubles; }
+    static __device__ __forceinline__ int hot_bytes(const Params &p) { return p.hot_bytes; }
 };
 template <int TA, int TR, int TC> struct FixDims {
     static constexpr int kNP = TA * (TA - 1) / 2, kNPs = kNP > 0 ? kNP : 1;
-    static constexpr int kRecDoubles = 12 * TA + TA * CAT_WALL_CACHE + kNPs;
+    static constexpr int kHotBytes = 96 * TA + 16;
+    static constexpr int kColdBytes = ((TA * CAT_WALL_CACHE + kNPs) * 8 + (2 * TA * CAT_WALL_CACHE + kNPs) * 4 + 15) / 16 * 16;
     static __device__ __forceinline__ constexpr int A(const Params &) { return TA; }
     static __device__ __forceinline__ constexpr int R(const Params &) { return TR; }
     static __device__ __forceinline__ constexpr int n_cops(const Params &) { return TC; }
     static __device__ __forceinline__ constexpr int NP(const Params &) { return kNP; }
     static __device__ __forceinline__ constexpr int maxc(const Params &) { return TA * CAT_WALL_CACHE + kNP; }
-    static __device__ __forceinline__ constexpr int rec_bytes(const Params &) { return (kRecDoubles * 8 + (2 * TA * CAT_WALL_CACHE + kNPs + 4) * 4 + 15) / 16 * 16; }
-    static __device__ __forceinline__ constexpr int rec_doubles(const Params &) { return kRecDoubles; }
+    static __device__ __forceinline__ constexpr int rec_bytes(const Params &) { return kHotBytes + kColdBytes; }
+    static __device__ __forceinline__ constexpr int hot_bytes(const Params &) { return kHotBytes; }
 };
 
 // Diagnostic build only (-DCAT_PHASE_TIMING): per-phase shader-clock totals, summed over waves
@@ -169,6 +172,17 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 
 __device__ __forceinline__ double fmax2(double a, double b) { return (a > b) ? a : b; }  // [CP cpfmax]
 __device__ __forceinline__ double fmin2(double a, double b) { return (a < b) ? a : b; }  // [CP cpfmin]
+
+#ifndef CAT_HW_MINMAX
+#define CAT_HW_MINMAX 1
+#endif
+#if CAT_HW_MINMAX
+#define CAT_FMAX(a, b) __builtin_fmax((a), (b))
+#define CAT_FMIN(a, b) __builtin_fmin((a), (b))
+#else
+#define CAT_FMAX(a, b) fmax2((a), (b))
+#define CAT_FMIN(a, b) fmin2((a), (b))
+#endif
 
 // wave-local ordering of LDS traffic between lanes (one wave owns its scratch; no s_barrier)
 __device__ __forceinline__ void wave_sync()
@@ -289,6 +303,9 @@ template <class T> __device__ __forceinline__ T launder(T v) { asm volatile("" :
 __device__ __forceinline__ double bb_segment_query(const double *bb, double ax, double ay, double dx,
                                                    double dy, double idx, double idy)
 {
+    // [CP cpfmax / cpfmin] as v_max_f64 / v_min_f64 here: the operands are never NaN (a zero delta takes the other
+    // branch, every other delta is at least an ulp of a coordinate, so 1/delta is finite) and the sign of a zero result
+    // is immaterial -- the value is only ever compared.  One instruction instead of a compare and two selects.
     const double2 lo = *reinterpret_cast<const double2 *>(bb);
     const double2 hi = *reinterpret_cast<const double2 *>(bb + 2);
     double tmin = -INFINITY, tmax = INFINITY;
@@ -296,17 +313,17 @@ __device__ __forceinline__ double bb_segment_query(const double *bb, double ax, 
         if (ax < lo.x || hi.x < ax) return INFINITY;
     } else {
         double t1 = (lo.x - ax) * idx, t2 = (hi.x - ax) * idx;
-        tmin = fmax2(tmin, fmin2(t1, t2));
-        tmax = fmin2(tmax, fmax2(t1, t2));
+        tmin = CAT_FMAX(tmin, CAT_FMIN(t1, t2));
+        tmax = CAT_FMIN(tmax, CAT_FMAX(t1, t2));
     }
     if (dy == 0.0) {
         if (ay < lo.y || hi.y < ay) return INFINITY;
     } else {
         double t1 = (lo.y - ay) * idy, t2 = (hi.y - ay) * idy;
-        tmin = fmax2(tmin, fmin2(t1, t2));
-        tmax = fmin2(tmax, fmax2(t1, t2));
+        tmin = CAT_FMAX(tmin, CAT_FMIN(t1, t2));
+        tmax = CAT_FMIN(tmax, CAT_FMAX(t1, t2));
     }
-    if (tmin <= tmax && 0.0 <= tmax && tmin <= 1.0) return fmax2(tmin, 0.0);
+    if (tmin <= tmax && 0.0 <= tmax && tmin <= 1.0) return CAT_FMAX(tmin, 0.0);
     return INFINITY;
 }
 
@@ -1324,10 +1341,13 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.rec = w;
     double *d = reinterpret_cast<double *>(w);
     L.pos = d; d += 2 * A; L.vel = d; d += 2 * A; L.vb = d; d += 2 * A; L.tc = d; d += 2 * A;
-    L.leaf = d; d += 4 * A; L.wjn = d; d += A * kK; L.pjn = d; d += NPs;
+    L.leaf = d; d += 4 * A;
+    L.cnt = reinterpret_cast<int *>(d);                       // step_count reset_count done cache_live: end of the hot part
+    d = reinterpret_cast<double *>(w + D::hot_bytes(p));      // the cold part: arbiter caches
+    L.wjn = d; d += A * kK; L.pjn = d; d += NPs;
     {
         int *ri = reinterpret_cast<int *>(d);
-        L.wsh = ri; ri += A * kK; L.wag = ri; ri += A * kK; L.pag = ri; ri += NPs; L.cnt = ri;
+        L.wsh = ri; ri += A * kK; L.wag = ri; ri += A * kK; L.pag = ri;
     }
     d = reinterpret_cast<double *>(w + D::rec_bytes(p));
     L.spawn = d; L.fpos = d; L.ftc = d + 2 * A; L.fleaf = d + 4 * A; d += 8 * A;
@@ -1384,43 +1404,73 @@ __device__ __forceinline__ void stage_map(const Params &p, char *smem, const Map
     __syncthreads();
 }
 
+// The cold part of a slot's record (the arbiter caches): fetched from HBM when the hot part says it holds something,
+// else set to "no cached arbiter" in LDS.  Called once the hot part is in LDS.
+template <class D>
+__device__ __forceinline__ void load_cold(const Lds &L, const Params &p, int env, int lane)
+{
+    const int A = D::A(p), NPs = D::NP(p) > 0 ? D::NP(p) : 1;
+    const int hot16 = D::hot_bytes(p) / 16, cold16 = (D::rec_bytes(p) - D::hot_bytes(p)) / 16;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(L.rec) + hot16;
+    if (uni(L.cnt[3]) != 0) {
+        GAS const u32x4 *src = (GAS const u32x4 *)(G(p.state) + (size_t)env * D::rec_bytes(p)) + hot16;
+        for (int o = lane; o < cold16; o += kLanes) dst[o] = src[o];
+    } else {
+        const int nd2 = 2 * (A * kK + NPs);   // dwords of the f64 fields; then wall_shape (-1), wall_age (0), pair_age (-1)
+        for (int o = lane; o < cold16; o += kLanes) {
+            u32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int j = 4 * o + q - nd2;
+                v[q] = (j >= 0 && (j < A * kK || (j >= 2 * A * kK && j < 2 * A * kK + NPs))) ? 0xFFFFFFFFu : 0u;
+            }
+            dst[o] = v;
+        }
+    }
+    wave_sync();
+}
+
 template <class D>
 __device__ __forceinline__ void load_state(const Lds &L, const Params &p, int env, int lane)
 {
     GAS const u32x4 *src = (GAS const u32x4 *)(G(p.state) + (size_t)env * D::rec_bytes(p));
     u32x4 *dst = reinterpret_cast<u32x4 *>(L.rec);
-    for (int o = lane; o < D::rec_bytes(p) / 16; o += kLanes) dst[o] = src[o];
+    for (int o = lane; o < D::hot_bytes(p) / 16; o += kLanes) dst[o] = src[o];
     wave_sync();
+    load_cold<D>(L, p, env, lane);
 }
 
-// The same copy in two halves, so that the HBM round trip overlaps the map staging: fetch into registers
+// The hot part in two halves, so that the HBM round trip overlaps the map staging: fetch into registers
 // before stage_map (whose barrier keeps the loads in front of it), write to LDS after it.
-struct StateRegs { u32x4 v[3]; };   // 3 x 64 lanes x 16 B = 3 KB >= the largest record (A = 8: 2.1 KB)
+struct StateRegs { u32x4 v; };   // 64 lanes x 16 B = 1 KB >= the largest hot part (A = 8: 784 B)
 template <class D>
 __device__ __forceinline__ void fetch_state(StateRegs &r, const Params &p, int env, int lane)
 {
     GAS const u32x4 *src = (GAS const u32x4 *)(G(p.state) + (size_t)(env < 0 ? 0 : env) * D::rec_bytes(p));
-#pragma unroll
-    for (int q = 0; q < 3; q++)
-        if (lane + q * kLanes < D::rec_bytes(p) / 16) r.v[q] = src[lane + q * kLanes];
+    if (lane < D::hot_bytes(p) / 16) r.v = src[lane];
 }
 template <class D>
 __device__ __forceinline__ void commit_state(const Lds &L, const StateRegs &r, const Params &p, int lane)
 {
     u32x4 *dst = reinterpret_cast<u32x4 *>(L.rec);
-#pragma unroll
-    for (int q = 0; q < 3; q++)
-        if (lane + q * kLanes < D::rec_bytes(p) / 16) dst[lane + q * kLanes] = r.v[q];
+    if (lane < D::hot_bytes(p) / 16) dst[lane] = r.v;
     wave_sync();
 }
 
+// LDS -> HBM.  cache_live (cnt[3]) is recomputed: the cold part goes out only while some arbiter is cached.
 template <class D>
 __device__ __forceinline__ void store_state(const Lds &L, const Params &p, int env, int lane)
 {
     wave_sync();
+    const int A = D::A(p);
+    const bool mine = (lane < A * kK && L.wsh[lane] >= 0) || (lane < D::NP(p) && L.pag[lane] >= 0);
+    const bool live = __ballot(mine) != 0ull;
+    if (lane == 0) L.cnt[3] = live ? 1 : 0;
+    wave_sync();
     GAS u32x4 *dst = (GAS u32x4 *)(G(p.state) + (size_t)env * D::rec_bytes(p));
     const u32x4 *src = reinterpret_cast<const u32x4 *>(L.rec);
-    for (int o = lane; o < D::rec_bytes(p) / 16; o += kLanes) dst[o] = src[o];
+    const int n16 = (live ? D::rec_bytes(p) : D::hot_bytes(p)) / 16;
+    for (int o = lane; o < n16; o += kLanes) dst[o] = src[o];
 }
 
 #ifdef CAT_WAVE_SPREAD
@@ -1578,6 +1628,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
     int captured = 0, timeout = 0, step = 0;
     if (has) {
         commit_state<D>(L, sregs, p, lane);
+        load_cold<D>(L, p, env, lane);
         PHASE(pc, 1);
         step = uni(L.cnt[0]) + 1;                                 // :372
         captured = termination_captured<D>(L, p, S, lane);           // :378
@@ -1646,7 +1697,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void reset_kernel(const Params *
     bool need = env >= 0;
     if (need) {
         if (la.use_done_mask)
-            need = ((GAS const int *)(G(p.state) + (size_t)env * D::rec_bytes(p) + 8 * D::rec_doubles(p)))[2 * D::A(p) * kK + (D::NP(p) > 0 ? D::NP(p) : 1) + 2] != 0;
+            need = ((GAS const int *)(G(p.state) + (size_t)env * D::rec_bytes(p) + 96 * D::A(p)))[2] != 0;   // the hot part's `done`
         else if (la.mask) need = la.mask[env] != 0;
     }
     if (!__syncthreads_or(need ? 1 : 0)) return;  // nothing to reset in this workgroup: skip the map staging
@@ -1745,6 +1796,26 @@ __global__ void random_actions_kernel(const Params *__restrict__ pp, unsigned lo
     unsigned rnd[4];
     philox_env(p, env, (unsigned)tick, (unsigned)i, 0xAC710u, rnd);
     actions[idx] = (int)(rnd[0] & 3u);
+}
+
+// cat_get_state / cat_set_state see the records field by field (strided copies); the cold part of a slot whose
+// cache_live flag is 0 holds stale bytes.  mode 0 (before a read-out): such slots get the "no cached arbiter" pattern;
+// mode 1 (after cold fields were written from outside): every slot's flag is raised, so the kernels read what was set.
+__global__ void cold_fixup_kernel(const Params *__restrict__ pp, int mode)
+{
+    const Params &p = *pp;
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.N) return;
+    char *rec = p.state + (size_t)env * p.rec_bytes;
+    int *cnt = reinterpret_cast<int *>(rec + 96 * p.A);
+    if (mode == 1) { cnt[3] = 1; return; }
+    if (cnt[3] != 0) return;
+    const int A = p.A, NPs = p.NP > 0 ? p.NP : 1;
+    double *cd = reinterpret_cast<double *>(rec + p.hot_bytes);
+    for (int q = 0; q < A * kK + NPs; q++) cd[q] = 0.0;
+    int *ci = reinterpret_cast<int *>(cd + A * kK + NPs);
+    for (int q = 0; q < A * kK; q++) { ci[q] = -1; ci[A * kK + q] = 0; }
+    for (int q = 0; q < NPs; q++) ci[2 * A * kK + q] = -1;
 }
 
 __global__ void selftest_kernel(int op, const double *a, const double *b, double *out, int n)
@@ -1897,8 +1968,7 @@ static LdsSizes lds_sizes(int A, int R, int maxS, int maxP)
     const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
     const int fan_bytes = 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;
     z.uni = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 16);
-    const int rec_doubles = 12 * A + A * kK + NPs, ni = 2 * A * kK + NPs + 4;
-    const int rec_bytes = (rec_doubles * 8 + ni * 4 + 15) / 16 * 16;
+    const int rec_bytes = 96 * A + 16 + ((A * kK + NPs) * 8 + (2 * A * kK + NPs) * 4 + 15) / 16 * 16;
     int eb = rec_bytes + 8 * A * 8;                                // record, spawn/snapshot
     eb += (3 * A + 2 * A * A + A + 4) * 4;                         // acell, anear, dk0, dcnt, dmin, flags
     eb = up(eb, 16) + up(A * R * 2, 16) + up(A * R, 16) + up(2 * R * 2, 16) + up(2 * R, 16);   // output staging
@@ -2098,13 +2168,10 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     auto fail = [&](int code) { strncpy(g_create_err, s->err, sizeof g_create_err - 1); cat_destroy(s); return code; };
     // ---- env state records (layout documented at Params::state)
     const int NPs_rec = p.NP > 0 ? p.NP : 1;
-    p.rec_doubles = 12 * A + A * kK + NPs_rec;
-    {
-        const int ni = 2 * A * kK + NPs_rec + 4;
-        p.rec_bytes = (p.rec_doubles * 8 + ni * 4 + 15) / 16 * 16;
-    }
-    if (p.rec_bytes > 3 * kLanes * 16) {   // StateRegs
-        snprintf(s->err, sizeof s->err, "state record of %d bytes exceeds the kernels' register staging", p.rec_bytes);
+    p.hot_bytes = 96 * A + 16;
+    p.rec_bytes = p.hot_bytes + ((A * kK + NPs_rec) * 8 + (2 * A * kK + NPs_rec) * 4 + 15) / 16 * 16;
+    if (p.hot_bytes > kLanes * 16) {   // StateRegs
+        snprintf(s->err, sizeof s->err, "state record of %d bytes exceeds the kernels' register staging", p.hot_bytes);
         return fail(CAT_ERR_BAD_CONFIG);
     }
     std::vector<char> rec0((size_t)N * p.rec_bytes, 0);
@@ -2112,7 +2179,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         const MapDesc &d = descs[slot[e]];
         const double *start = geo_f.data() + d.f64_off + 4 * d.S + 12 * d.P;
         double *rd = reinterpret_cast<double *>(rec0.data() + (size_t)e * p.rec_bytes);
-        int *ri = reinterpret_cast<int *>(rd + p.rec_doubles);
+        int *ri = reinterpret_cast<int *>(rec0.data() + (size_t)e * p.rec_bytes + p.hot_bytes + (A * kK + NPs_rec) * 8);   // cold ints
         for (int i = 0; i < A; i++) {
             // Entity.__init__ + space.add: caches and BBTree leaf at the start position, v = 0
             const double x = start[2 * i], y = start[2 * i + 1], r = cfg->agent_radius;
@@ -2329,19 +2396,25 @@ static int copy_state(cat_sim *s, const cat_state *v, bool get, void *stream)
         return get ? hipMemcpy2DAsync(user, width, recp, (size_t)p.rec_bytes, width, (size_t)p.N, hipMemcpyDeviceToDevice, st)
                    : hipMemcpy2DAsync(recp, (size_t)p.rec_bytes, user, width, width, (size_t)p.N, hipMemcpyDeviceToDevice, st);
     };
-    const size_t D = 8, I = 4, ib = (size_t)p.rec_doubles * 8;
+    const size_t D = 8, I = 4, hot = (size_t)p.hot_bytes, ci = hot + ((size_t)A * kK + NPs) * D;   // cold f64 at `hot`, cold i32 at `ci`
+    const bool cold_touched = v->wall_jn || v->pair_jn || v->wall_shape || v->wall_age || v->pair_age;
+    // a slot whose cache_live flag is 0 keeps STALE bytes in the cold part of its record: make them say "empty" before
+    // they are read out, and raise the flag of every slot after cold fields were written from outside
+    if (get) hipLaunchKernelGGL(cold_fixup_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, s->dev_p, 0);
     HIP_TRY(s, cp(v->pos, 0, 2 * A * D));
     HIP_TRY(s, cp(v->vel, 2 * A * D, 2 * A * D));
     HIP_TRY(s, cp(v->vbias, 4 * A * D, 2 * A * D));
     HIP_TRY(s, cp(v->tc, 6 * A * D, 2 * A * D));
     HIP_TRY(s, cp(v->leaf_bb, 8 * A * D, 4 * A * D));
-    HIP_TRY(s, cp(v->wall_jn, 12 * A * D, (size_t)A * kK * D));
-    if (p.NP > 0) HIP_TRY(s, cp(v->pair_jn, (12 * A + (size_t)A * kK) * D, (size_t)p.NP * D));
-    HIP_TRY(s, cp(v->wall_shape, ib, (size_t)A * kK * I));
-    HIP_TRY(s, cp(v->wall_age, ib + (size_t)A * kK * I, (size_t)A * kK * I));
-    if (p.NP > 0) HIP_TRY(s, cp(v->pair_age, ib + 2 * (size_t)A * kK * I, (size_t)p.NP * I));
-    HIP_TRY(s, cp(v->step_count, ib + (2 * (size_t)A * kK + NPs) * I, I));
-    HIP_TRY(s, cp(v->reset_count, ib + (2 * (size_t)A * kK + NPs + 1) * I, I));
+    HIP_TRY(s, cp(v->step_count, 12 * A * D, I));
+    HIP_TRY(s, cp(v->reset_count, 12 * A * D + I, I));
+    HIP_TRY(s, cp(v->wall_jn, hot, (size_t)A * kK * D));
+    if (p.NP > 0) HIP_TRY(s, cp(v->pair_jn, hot + (size_t)A * kK * D, (size_t)p.NP * D));
+    HIP_TRY(s, cp(v->wall_shape, ci, (size_t)A * kK * I));
+    HIP_TRY(s, cp(v->wall_age, ci + (size_t)A * kK * I, (size_t)A * kK * I));
+    if (p.NP > 0) HIP_TRY(s, cp(v->pair_age, ci + 2 * (size_t)A * kK * I, (size_t)p.NP * I));
+    if (!get && cold_touched) hipLaunchKernelGGL(cold_fixup_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, s->dev_p, 1);
+    HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
 

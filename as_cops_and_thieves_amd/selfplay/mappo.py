@@ -71,6 +71,9 @@ class TrainerConfig:
     graph_update: bool = True              # capture the minibatch step (forward, losses, backward / clip, Adam)
     reference_q11: bool = False            # True: every critic sees the alphabetically first agent's channels (quirk Q11)
     random_action_roles: Tuple[str, ...] = ()   # roles that act uniformly at random throughout (a fixed random opponent)
+    normalize_inputs: bool = False         # False = the reference: raw distances (0..400) and type codes (0..4) go into the
+                                           # convolutions (skrl's state_preprocessor is None).  True (build-side option):
+                                           # distances / ray length, types / 4 -- see tools/learn_curve.py
 
 
 def compute_gae(rewards: torch.Tensor, values: torch.Tensor, dones: torch.Tensor, last_values: torch.Tensor,
@@ -314,6 +317,9 @@ class MAPPOTrainer:
         for rl in self.roles.values():
             mask = [r in self.tcfg.random_action_roles for r in rl.agent_roles]
             rl.random_rows = torch.tensor(mask, device=self.device).view(rl.G, 1) if any(mask) else None
+        R, d, t = self.R, 1.0 / 400.0, 0.25          # ray length (entity.py:176 default sensor), number of type codes - 1
+        self._pin_scale = torch.tensor([d] * R + [t] * R, device=self.device)
+        self._vin_scale = torch.tensor(([d] * R + [t] * R) * 2, device=self.device)
         self._gen = torch.Generator(device="cpu").manual_seed(seed)
         torch.manual_seed(seed)
         self.timestep = 0
@@ -334,6 +340,8 @@ class MAPPOTrainer:
         first = sorted(state)[0]
         vin = torch.stack([packing.pack_agent_state(state[first if self.tcfg.reference_q11 else a])[:, :4 * self.R]
                            for a in rl.agents])                                                         # [G, N, 4R]
+        if self.tcfg.normalize_inputs:   # channel layouts: [distance | type] and [distance_shared | type_shared | own distance | own type]
+            pin, vin = pin * self._pin_scale, vin * self._vin_scale
         return pin, vin
 
     # ------------------------------------------------------------------ rollout

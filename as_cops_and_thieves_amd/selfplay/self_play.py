@@ -73,6 +73,8 @@ def evaluate_agents(env, runner: MAPPOTrainer, n_episodes: int, random_roles: Tu
         keep = (~starts).view(1, N)
         for r, rl in runner.roles.items():
             pin = torch.stack([runner_pack(obs[a]) for a in rl.agents])
+            if runner.tcfg.normalize_inputs:
+                pin = pin * runner._pin_scale
             logits, state[r] = rl.policy.forward(pin.unsqueeze(1), state[r], keep)
             probs = torch.softmax(logits[:, 0].float(), dim=-1)
             act = torch.multinomial(probs.view(rl.G * N, 4), 1).view(rl.G, N)

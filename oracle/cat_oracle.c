@@ -15,6 +15,11 @@
  *   D3  bb slab test multiplies by 1/delta instead of dividing (gate decision only).
  *   D4  centre-inside-hull contacts use least-penetration instead of EPA (unreachable in
  *       play: needs > 5 px penetration).
+ *   D5  spawn sampling draws from Philox4x32-10 counter streams.
+ *   D6  Chipmunk's SubtreeSegmentQuery does not gate a BBTree root that is itself a leaf: with ONE
+ *       static shape in the space that shape is queried even when the thin segment misses its bb.
+ *       The linear index here gates every wall alike (bb_gate below).  None of the five maps has a
+ *       single wall; tests/test_oracle_known_answers.py::test_single_wall_map_... shows the case.
  */
 #include "cat_oracle.h"
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: does the learner learn?  Cops (trained) against uniformly random thieves on a map; prints the cop win
-rate of sampled-action evaluation episodes every few updates.  Usage: python tools/learn_curve.py [map] [envs] [updates]"""
+rate of sampled-action evaluation episodes every few updates.  Usage: python tools/learn_curve.py [map] [envs] [updates] [lr] [max_step_count] [entropy_scale] [norm|raw]"""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -14,17 +14,21 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 U = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 lr = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-4
 msc = int(sys.argv[5]) if len(sys.argv) > 5 else 400
-rc = RoleConfig(random_timesteps=0, learning_starts=0, learning_rate=lr)
+ent = float(sys.argv[6]) if len(sys.argv) > 6 else 0.02
+norm = (sys.argv[7] == "norm") if len(sys.argv) > 7 else False
+rc = RoleConfig(random_timesteps=0, learning_starts=0, learning_rate=lr, entropy_loss_scale=ent)
 env = VecCopsEnv(load_preset(name), num_envs=N, num_rays=64, max_step_count=msc, seed=1)
 ev = VecCopsEnv(load_preset(name), num_envs=512, num_rays=64, max_step_count=msc, seed=99)
-tc = TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0, random_action_roles=("thief",))
+tc = TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0, random_action_roles=("thief",), normalize_inputs=norm)
 tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, tc, seed=0)
 tr.set_frozen(role="thief", policy=True, value=True)
-evr = MAPPOTrainer(ev, {"cop": rc, "thief": rc}, TrainerConfig(graph_rollout=False, graph_update=False), seed=1)
+evr = MAPPOTrainer(ev, {"cop": rc, "thief": rc}, TrainerConfig(graph_rollout=False, graph_update=False, normalize_inputs=norm), seed=1)
 t0 = time.time()
 for u in range(U + 1):
     if u % max(1, U // 10) == 0:
         evr.load_state_dict(tr.state_dict(), optimizer=False)
         c, t = evaluate_agents(ev, evr, 512, random_roles=("thief",))
-        print(f"update {u:4d} ({u * 16 * N / 1e6:6.1f} M env-steps, {time.time() - t0:5.1f} s): cop win rate {c:.3f} thief {t:.3f}  {tr.read_stats().get('cop_0/value_loss')}", flush=True)
+        rl, g = tr.learner_of("cop_0")
+        print(f"update {u:4d} ({u * 16 * N / 1e6:6.1f} M env-steps, {time.time() - t0:5.1f} s): cop win rate {c:.3f} thief {t:.3f}  "
+              f"mean cop_0 reward/tick {float(rl.buf['rew'][g].mean()):+.4f}  value_loss {tr.read_stats().get('cop_0/value_loss')}", flush=True)
     tr.collect(); tr.update()

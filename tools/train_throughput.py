@@ -2,7 +2,8 @@
 """Diagnostic: env-steps/s of the MAPPO trainer on the device env -- rollout collection (env tick +
 the stacked policies and critics per tick, one HIP graph) and the PPO update (HIP-graph minibatch steps) -- beside the
 bare env rate of bench.py.  Usage: python tools/train_throughput.py [envs] [rollouts] [map]"""
-import sys, time
+import sys, time, faulthandler
+faulthandler.dump_traceback_later(100, exit=True)    # a hang shows where
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
@@ -16,6 +17,7 @@ env = VecCopsEnv(load_preset(name), num_envs=N, num_rays=64, max_step_count=400)
 tr = MAPPOTrainer(env, None, TrainerConfig(), seed=0)      # CFG_AGENT for both roles, as the reference's driver
 for _ in range(3):                                         # eager warm-up, then the graph captures
     tr.collect(); tr.update()
+    torch.cuda.synchronize(); print('warm-up pass done', flush=True)
 torch.cuda.synchronize()
 tc = tu = 0.0
 for _ in range(K):
