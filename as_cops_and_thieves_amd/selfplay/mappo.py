@@ -136,7 +136,6 @@ class RoleLearner:
         self.p0 = tuple(s.clone() for s in self.p_state)       # recurrent state at the start of the stored rollout
         self.v0 = tuple(s.clone() for s in self.v_state)
         self._graphs = None
-        self._side = None
 
     # ------------------------------------------------------------------ freezing (skrl Model.freeze_parameters)
     def set_frozen(self, role: Optional[str] = None, policy: Optional[bool] = None, value: Optional[bool] = None) -> None:
@@ -162,20 +161,8 @@ class RoleLearner:
         sel = lambda x: x.index_select(2, idx)
         keep = (~self.start.index_select(1, idx)).to(torch.float32)                    # [T, B]
         st = lambda s: s.index_select(2, idx)
-        if self.device.type == "cuda":
-            # the critics' chain on a second stream: the two chains share nothing, their kernels are small (the update is
-            # bound by their number), and autograd runs each backward on the stream of its forward -- fork / join in the graph
-            cur = torch.cuda.current_stream(self.device)
-            if self._side is None:
-                self._side = torch.cuda.Stream(self.device)
-            self._side.wait_stream(cur)
-            with torch.cuda.stream(self._side):
-                values, _ = self.value.forward(sel(b["vin"]), (st(self.v0[0]), st(self.v0[1])), keep)
-            logits, _ = self.policy.forward(sel(b["pin"]), (st(self.p0[0]), st(self.p0[1])), keep)
-            cur.wait_stream(self._side)
-        else:
-            logits, _ = self.policy.forward(sel(b["pin"]), (st(self.p0[0]), st(self.p0[1])), keep)
-            values, _ = self.value.forward(sel(b["vin"]), (st(self.v0[0]), st(self.v0[1])), keep)
+        logits, _ = self.policy.forward(sel(b["pin"]), (st(self.p0[0]), st(self.p0[1])), keep)
+        values, _ = self.value.forward(sel(b["vin"]), (st(self.v0[0]), st(self.v0[1])), keep)
         logp_all = torch.log_softmax(logits.float(), dim=-1)                            # [G, T, B, 4]
         logp = logp_all.gather(-1, sel(b["act"]).unsqueeze(-1)).squeeze(-1)
         old = sel(b["logp"])

@@ -73,11 +73,10 @@ class _LSTMSeq(torch.autograd.Function):
         h, c = h0, c0
         train = any(ctx.needs_input_grad)          # a rollout tick (no_grad) keeps nothing
         hs, cs, cys, wss, outs = [], [], [], [], []
-        # the mask at full shape, once: h and c are then masked by ONE multi-tensor kernel per step
-        kf = None if keep is None else keep.expand(T, *h0.shape).contiguous()
+        kf = keep
         for t in range(T):
             if kf is not None:
-                h, c = torch._foreach_mul((h, c), (kf[t], kf[t]))
+                h, c = h * kf[t], c * kf[t]
             hg = torch.bmm(h, w_t)
             hy, cy, ws = _cell_fwd(xproj[t], hg, c)
             if train:
@@ -106,7 +105,7 @@ class _LSTMSeq(torch.autograd.Function):
             dg, dc = _cell_bwd(dh_t, dc, cs[t], cys[t], wss[t])
             dh = torch.bmm(dg, w_hh)
             if ctx.has_keep:
-                dh, dc = torch._foreach_mul((dh, dc), (keep[t], keep[t]))
+                dh, dc = dh * keep[t], dc * keep[t]
             dgs[t] = dg
         dg_all = torch.stack(dgs, 0)                                             # [T, G, B, 4H] = d xproj
         G, H4 = dg_all.shape[1], dg_all.shape[3]

@@ -17,8 +17,21 @@ msc = int(sys.argv[5]) if len(sys.argv) > 5 else 400
 ent = float(sys.argv[6]) if len(sys.argv) > 6 else 0.02
 norm = (sys.argv[7] == "norm") if len(sys.argv) > 7 else False
 rc = RoleConfig(random_timesteps=0, learning_starts=0, learning_rate=lr, entropy_loss_scale=ent)
-env = VecCopsEnv(load_preset(name), num_envs=N, num_rays=64, max_step_count=msc, seed=1)
-ev = VecCopsEnv(load_preset(name), num_envs=512, num_rays=64, max_step_count=msc, seed=99)
+if name == "arena":   # an open 600 x 600 arena with one small block: cops and thieves spawn 50..200 px apart, so the
+    import json, tempfile                       # cops' shaping reward (1.5 exp(-d/50) while a thief is in sight) is dense
+    from as_cops_and_thieves_amd.maps import Map
+    reg = {"x": 150, "y": 150, "w": 300, "h": 300}
+    data = {"window": {"w_px": 600, "h_px": 600}, "canvas": {"w": 600, "h": 600},
+            "objects": {"blocks": [{"type": "rect", "x": 20, "y": 20, "w": 30, "h": 30}]},
+            "agents": [{"type": "cop", "x": 250, "y": 300, "spawn_region": reg}, {"type": "cop", "x": 350, "y": 300, "spawn_region": reg},
+                       {"type": "thief", "x": 300, "y": 200, "spawn_region": reg}]}
+    f = Path(tempfile.mkdtemp()) / "arena.json"
+    f.write_text(json.dumps(data))
+    the_map = Map(f)
+else:
+    the_map = load_preset(name)
+env = VecCopsEnv(the_map, num_envs=N, num_rays=64, max_step_count=msc, seed=1)
+ev = VecCopsEnv(the_map, num_envs=512, num_rays=64, max_step_count=msc, seed=99)
 tc = TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0, random_action_roles=("thief",), normalize_inputs=norm)
 tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, tc, seed=0)
 tr.set_frozen(role="thief", policy=True, value=True)
