@@ -95,6 +95,37 @@ def evaluate_agents(env, runner: MAPPOTrainer, n_episodes: int, random_roles: Tu
     return float((w == 0).sum()) / n_episodes, float((w == 1).sum()) / n_episodes
 
 
+@torch.no_grad()
+def mean_reward_per_tick(env, runner: MAPPOTrainer, ticks: int, random_roles: Tuple[str, ...] = ()) -> Dict[str, float]:
+    """Diagnostic (not part of the reference protocol): reset ``env``, act for ``ticks`` ticks with sampled actions
+    (``random_roles`` uniformly at random) and return every agent's mean reward per tick -- the quantity PPO maximises,
+    measured from the same starting conditions whenever it is called."""
+    N = env.num_envs
+    assert N == runner.N
+    obs, _ = env.reset()
+    starts = torch.ones(N, dtype=torch.bool, device=runner.device)
+    state = {r: rl.policy.initial_state(N) for r, rl in runner.roles.items()}
+    actions = torch.zeros(N, len(runner.agents), dtype=torch.int32, device=runner.device)
+    total = {a: torch.zeros((), device=runner.device) for a in runner.agents}
+    for _ in range(ticks):
+        keep = (~starts).view(1, N)
+        for r, rl in runner.roles.items():
+            pin = torch.stack([runner_pack(obs[a]) for a in rl.agents])
+            if runner.tcfg.normalize_inputs:
+                pin = pin * runner._pin_scale
+            logits, state[r] = rl.policy.forward(pin.unsqueeze(1), state[r], keep)
+            act = torch.multinomial(torch.softmax(logits[:, 0].float(), dim=-1).view(rl.G * N, 4), 1).view(rl.G, N)
+            rnd = [ar in random_roles for ar in rl.agent_roles]
+            if any(rnd):
+                act = torch.where(torch.tensor(rnd, device=runner.device).view(rl.G, 1), torch.randint(0, 4, (rl.G, N), device=runner.device), act)
+            actions.index_copy_(1, rl.index_t, act.t().to(torch.int32))
+        obs, rewards, terms, _, _ = env.step(actions)
+        for a in runner.agents:
+            total[a] += rewards[a].float().mean()
+        starts = terms[runner.agents[0]].clone()
+    return {a: float(v) / ticks for a, v in total.items()}
+
+
 def runner_pack(obs_agent):
     from .. import packing
     return packing.pack_policy_input(obs_agent)

@@ -7,7 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from as_cops_and_thieves_amd import VecCopsEnv, load_preset
 from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, RoleConfig, TrainerConfig
-from as_cops_and_thieves_amd.selfplay.self_play import evaluate_agents
+from as_cops_and_thieves_amd.selfplay.self_play import evaluate_agents, mean_reward_per_tick
 
 name = sys.argv[1] if len(sys.argv) > 1 else "squarinth"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
@@ -41,7 +41,7 @@ for u in range(U + 1):
     if u % max(1, U // 10) == 0:
         evr.load_state_dict(tr.state_dict(), optimizer=False)
         c, t = evaluate_agents(ev, evr, 512, random_roles=("thief",))
-        rl, g = tr.learner_of("cop_0")
+        r = mean_reward_per_tick(ev, evr, msc, random_roles=("thief",))
         print(f"update {u:4d} ({u * 16 * N / 1e6:6.1f} M env-steps, {time.time() - t0:5.1f} s): cop win rate {c:.3f} thief {t:.3f}  "
-              f"mean cop_0 reward/tick {float(rl.buf['rew'][g].mean()):+.4f}  value_loss {tr.read_stats().get('cop_0/value_loss')}", flush=True)
+              f"mean cop reward/tick over full evaluation episodes {0.5 * (r['cop_0'] + r['cop_1']):+.4f}  value_loss {tr.read_stats().get('cop_0/value_loss')}", flush=True)
     tr.collect(); tr.update()
