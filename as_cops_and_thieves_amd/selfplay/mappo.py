@@ -93,6 +93,27 @@ def compute_gae(rewards: torch.Tensor, values: torch.Tensor, dones: torch.Tensor
     return adv, adv + values
 
 
+def _rowsum(x: torch.Tensor) -> torch.Tensor:
+    """x [G, ...] -> [G]: the sum over everything but the first axis, as a GEMM with a vector of ones.  Inside a captured
+    HIP graph this replaces ``x.sum(dim=...)``: ``at::sum`` over more than a few tens of thousands of elements is a
+    multi-block reduction with a semaphore buffer, and replayed from a graph it returned garbage on this stack (ROCm 7.2 /
+    torch 2.10) -- first for the bias gradients of the backward pass, then, at 8192 envs, for the validity check inside
+    ``torch.multinomial`` (a spurious device-side assert).  Matrix products carry no such state."""
+    G = x.shape[0]
+    flat = x.reshape(G, 1, -1)
+    ones = torch.ones(G, flat.shape[2], 1, dtype=flat.dtype, device=flat.device)
+    return torch.bmm(flat, ones).view(G)
+
+
+def _sample(logp_all: torch.Tensor) -> torch.Tensor:
+    """Categorical sample from log-probabilities [..., K] by inverse CDF on one uniform draw per row (elementwise ops and a
+    K-term sum only; ``torch.multinomial``'s input validation is a large reduction, see ``_rowsum``)."""
+    p = logp_all.exp()
+    u = torch.rand(p.shape[:-1] + (1,), device=p.device, dtype=p.dtype)
+    cdf = torch.cumsum(p, dim=-1)[..., :-1]
+    return (u >= cdf).sum(dim=-1)
+
+
 def _dist_ready() -> bool:
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -167,13 +188,14 @@ class RoleLearner:
         logp = logp_all.gather(-1, sel(b["act"]).unsqueeze(-1)).squeeze(-1)
         old = sel(b["logp"])
         ratio = torch.exp(logp - old)
+        M = float(logp.shape[1] * logp.shape[2])                                         # samples per agent in the minibatch
         with torch.no_grad():
-            kl = ((ratio - 1) - (logp - old)).mean(dim=(1, 2))                          # [G]
+            kl = _rowsum((ratio - 1) - (logp - old)) / M                                # [G]
         adv = sel(b["adv"])
         surr = torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.ratio_clip, 1 + cfg.ratio_clip))
-        policy_loss = -surr.mean(dim=(1, 2))
-        entropy = -(logp_all.exp() * logp_all).sum(-1).mean(dim=(1, 2))
-        value_loss = cfg.value_loss_scale * ((values.float().squeeze(-1) - sel(b["ret"])) ** 2).mean(dim=(1, 2))
+        policy_loss = -_rowsum(surr) / M
+        entropy = -_rowsum((logp_all.exp() * logp_all).sum(-1)) / M
+        value_loss = cfg.value_loss_scale * _rowsum((values.float().squeeze(-1) - sel(b["ret"])) ** 2) / M
         (policy_loss - cfg.entropy_loss_scale * entropy + value_loss).sum().backward()   # agents share no parameter
         with torch.no_grad():
             self.ar[:, :-1].copy_(self.fp.grad)
@@ -189,7 +211,7 @@ class RoleLearner:
         if cfg.kl_threshold:
             self.epoch_active.mul_((kl <= cfg.kl_threshold).to(torch.float32))
         g = self.ar[:, :-1] * self.col_train                                           # frozen parameters: no gradient
-        norm = g.norm(dim=1, keepdim=True)
+        norm = _rowsum(g * g).sqrt().unsqueeze(1)
         g = g * torch.clamp(cfg.grad_norm_clip / (norm + 1e-6), max=1.0)                 # torch.nn.utils.clip_grad_norm_
         gate = self.epoch_active.unsqueeze(1) * self.col_train                         # [G, P]: 1 = this entry steps
         self.steps.add_(gate)
@@ -350,7 +372,7 @@ class MAPPOTrainer:
                 if random_actions:
                     act = torch.randint(0, 4, (rl.G, N), generator=self._gen).to(self.device)
                 else:
-                    act = torch.multinomial(logp_all.exp().view(rl.G * N, 4), 1).view(rl.G, N)
+                    act = _sample(logp_all)
                     if rl.random_rows is not None:   # rows of the roles in TrainerConfig.random_action_roles
                         act = torch.where(rl.random_rows, torch.randint(0, 4, (rl.G, N), device=self.device), act)
                 b = rl.buf
@@ -374,11 +396,11 @@ class MAPPOTrainer:
         use_graph = self.tcfg.graph_rollout and self.use_graphs and not random_actions
         if not use_graph:
             self._rollout_ticks(random_actions)
-            self._eager_rollouts += 1
+            self._eager_rollouts += 0 if random_actions else 1
         else:
             if self._graph is None:
-                if self._eager_rollouts == 0:       # the first rollout runs eagerly: warms allocator and libraries up
-                    self._rollout_ticks(False)
+                if self._eager_rollouts == 0:       # the first policy-driven rollout runs eagerly: every op of the tick
+                    self._rollout_ticks(False)      # (sampling included) has then run once before it is captured
                     self._eager_rollouts += 1
                     self.timestep += self.tcfg.horizon
                     return

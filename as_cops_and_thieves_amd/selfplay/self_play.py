@@ -36,7 +36,7 @@ import torch
 from ..environments import VecCopsEnv
 from ..maps import load_preset
 from . import archive
-from .mappo import CFG_AGENT, MAPPOTrainer, RoleConfig, TrainerConfig
+from .mappo import CFG_AGENT, MAPPOTrainer, RoleConfig, TrainerConfig, _sample
 
 
 @dataclasses.dataclass
@@ -76,8 +76,7 @@ def evaluate_agents(env, runner: MAPPOTrainer, n_episodes: int, random_roles: Tu
             if runner.tcfg.normalize_inputs:
                 pin = pin * runner._pin_scale
             logits, state[r] = rl.policy.forward(pin.unsqueeze(1), state[r], keep)
-            probs = torch.softmax(logits[:, 0].float(), dim=-1)
-            act = torch.multinomial(probs.view(rl.G * N, 4), 1).view(rl.G, N)
+            act = _sample(torch.log_softmax(logits[:, 0].float(), dim=-1))
             rnd = [ar in random_roles for ar in rl.agent_roles]
             if any(rnd):                                # a uniformly random opponent (not part of the reference protocol)
                 rows = torch.tensor(rnd, device=runner.device).view(rl.G, 1)
@@ -114,7 +113,7 @@ def mean_reward_per_tick(env, runner: MAPPOTrainer, ticks: int, random_roles: Tu
             if runner.tcfg.normalize_inputs:
                 pin = pin * runner._pin_scale
             logits, state[r] = rl.policy.forward(pin.unsqueeze(1), state[r], keep)
-            act = torch.multinomial(torch.softmax(logits[:, 0].float(), dim=-1).view(rl.G * N, 4), 1).view(rl.G, N)
+            act = _sample(torch.log_softmax(logits[:, 0].float(), dim=-1))
             rnd = [ar in random_roles for ar in rl.agent_roles]
             if any(rnd):
                 act = torch.where(torch.tensor(rnd, device=runner.device).view(rl.G, 1), torch.randint(0, 4, (rl.G, N), device=runner.device), act)
