@@ -65,7 +65,11 @@ class TrainerConfig:
     timesteps: int = 100_000               # TrainingConfig.training_timesteps_per_role_training
     opponent_freeze_duration: int = 15_000
     policy_freeze_duration: int = 15_000
-    horizon: int = 16                      # ticks per rollout = BPTT window (reference LSTM sequence_length)
+    horizon: int = 16                      # ticks per rollout; a multiple of ``bptt``
+    bptt: int = 16                         # BPTT window (reference LSTM sequence_length).  A rollout of W = horizon / bptt
+                                           # windows trains on W * num_envs sequences per update: the same number of
+                                           # optimiser steps over W times the data (the update's cost is dominated by
+                                           # its kernel COUNT, which does not grow with W)
     compute_bf16: bool = True              # bf16 compute copy of the weights on a GPU (fp32 master + fp32 Adam)
     graph_rollout: bool = True             # capture the T-tick rollout (env ticks + all networks) in one HIP graph
     graph_update: bool = True              # capture the minibatch step (forward, losses, backward / clip, Adam)
@@ -94,15 +98,19 @@ def compute_gae(rewards: torch.Tensor, values: torch.Tensor, dones: torch.Tensor
 
 
 def _rowsum(x: torch.Tensor) -> torch.Tensor:
-    """x [G, ...] -> [G]: the sum over everything but the first axis, as a GEMM with a vector of ones.  Inside a captured
-    HIP graph this replaces ``x.sum(dim=...)``: ``at::sum`` over more than a few tens of thousands of elements is a
-    multi-block reduction with a semaphore buffer, and replayed from a graph it returned garbage on this stack (ROCm 7.2 /
-    torch 2.10) -- first for the bias gradients of the backward pass, then, at 8192 envs, for the validity check inside
-    ``torch.multinomial`` (a spurious device-side assert).  Matrix products carry no such state."""
-    G = x.shape[0]
-    flat = x.reshape(G, 1, -1)
-    ones = torch.ones(G, flat.shape[2], 1, dtype=flat.dtype, device=flat.device)
-    return torch.bmm(flat, ones).view(G)
+    """x [G, ...] -> [G]: the sum over everything but the first axis, in stages of 256 so that every stage is a short
+    inner-dimension reduction with many outputs.  Inside a captured HIP graph this replaces ``x.sum(dim=...)``: ``at::sum``
+    of hundreds of thousands of elements into a few outputs is a MULTI-BLOCK reduction with a semaphore buffer, and
+    replayed from a graph it returned garbage on this stack (ROCm 7.2 / torch 2.10) -- first for the bias gradients of the
+    backward pass, then, at 8192 envs, for the validity check inside ``torch.multinomial`` (a spurious device-side
+    assert).  Short reductions are done by one block per output and carry no such state."""
+    flat = x.reshape(x.shape[0], -1)
+    while flat.shape[1] > 2048:
+        r = (-flat.shape[1]) % 256
+        if r:
+            flat = torch.nn.functional.pad(flat, (0, r))
+        flat = flat.view(flat.shape[0], -1, 256).sum(-1)
+    return flat.sum(-1)
 
 
 def _sample(logp_all: torch.Tensor) -> torch.Tensor:
@@ -128,10 +136,13 @@ class RoleLearner:
     BETA1, BETA2, EPS = 0.9, 0.999, 1e-8    # torch.optim.Adam defaults (what skrl constructs)
 
     def __init__(self, role: str, agents: List[str], indices: List[int], R: int, N: int, T: int, cfg: RoleConfig,
-                 device: torch.device, compute_dtype: torch.dtype, seeds: List[int]):
+                 device: torch.device, compute_dtype: torch.dtype, seeds: List[int], bptt: Optional[int] = None):
         self.role, self.agents, self.indices, self.cfg = role, agents, indices, cfg
         self.agent_roles = [a.split("_")[0] for a in agents]
         self.G, self.R, self.N, self.T, self.device = len(agents), R, N, T, device
+        self.bptt = bptt or T
+        assert T % self.bptt == 0, "horizon must be a multiple of the BPTT window"
+        self.W = T // self.bptt                                # windows per rollout; training sequences = W * N
         self.index_t = torch.tensor(indices, dtype=torch.long, device=device)     # columns of the [N, A] action tensor
         self.fp = FlatParams(role_param_shapes(R), self.G, device, compute_dtype)
         init_from_modules(self.fp, R, seeds)
@@ -145,7 +156,8 @@ class RoleLearner:
         self.epoch_active = torch.ones(G, **f32)               # KL early stop: 0 = skip the rest of this epoch
         self.ar = torch.zeros(G, P + 1, **f32)                 # all-reduce buffer: fp32 gradients | KL
         self.stat = torch.zeros(3, G, **f32)                   # last policy loss, value loss, KL per agent
-        B = N // cfg.mini_batches
+        W, S = self.W, self.W * N
+        B = S // cfg.mini_batches
         self.B = B
         self.idx = torch.zeros(B, dtype=torch.long, device=device)
         self.buf = {"pin": torch.zeros(G, T, N, 2 * R, **f32), "vin": torch.zeros(G, T, N, 4 * R, **f32),
@@ -154,8 +166,20 @@ class RoleLearner:
                     "adv": torch.zeros(G, T, N, **f32), "ret": torch.zeros(G, T, N, **f32)}
         self.p_state = self.policy.initial_state(N)            # carried across rollouts
         self.v_state = self.value.initial_state(N)
-        self.p0 = tuple(s.clone() for s in self.p_state)       # recurrent state at the start of the stored rollout
-        self.v0 = tuple(s.clone() for s in self.v_state)
+        # recurrent states at the start of every window of the stored rollout: [W, layers, G, N, H]
+        self.p0w = tuple(s.unsqueeze(0).repeat(W, 1, 1, 1, 1) for s in self.p_state)
+        self.v0w = tuple(s.unsqueeze(0).repeat(W, 1, 1, 1, 1) for s in self.v_state)
+        # what the minibatch step gathers from: [G, bptt, W * N, ...] (the rollout buffers themselves when W == 1)
+        if W == 1:
+            self.tb = self.buf
+            self.p0, self.v0 = tuple(s[0] for s in self.p0w), tuple(s[0] for s in self.v0w)
+            self.start = None                                  # set by update(): the trainer's [T, N] start flags
+        else:
+            self.tb = {k: torch.zeros((G, self.bptt, S) + tuple(v.shape[3:]), dtype=v.dtype, device=device)
+                       for k, v in self.buf.items() if k not in ("val", "rew")}
+            self.p0 = tuple(torch.zeros(s.shape[1], G, S, s.shape[4], dtype=s.dtype, device=device) for s in self.p0w)
+            self.v0 = tuple(torch.zeros(s.shape[1], G, S, s.shape[4], dtype=s.dtype, device=device) for s in self.v0w)
+            self.start = torch.zeros(self.bptt, S, dtype=torch.bool, device=device)
         self._graphs = None
 
     # ------------------------------------------------------------------ freezing (skrl Model.freeze_parameters)
@@ -177,7 +201,7 @@ class RoleLearner:
     def _step_forward_backward(self) -> None:
         """zero grads, gather the minibatch ``self.idx`` (sequences = env slots), forward, losses, backward; leaves the
         fp32 gradients and the per-agent KL in ``self.ar``."""
-        cfg, b, idx = self.cfg, self.buf, self.idx
+        cfg, b, idx = self.cfg, self.tb, self.idx
         self.fp.grad.zero_()
         sel = lambda x: x.index_select(2, idx)
         keep = (~self.start.index_select(1, idx)).to(torch.float32)                    # [T, B]
@@ -284,10 +308,19 @@ class RoleLearner:
         std = adv.std(dim=(1, 2), keepdim=True)
         b["adv"].copy_((adv - mean) / (std + 1e-8))                                     # skrl: per agent, whole memory
         b["ret"].copy_(ret)
-        self.start = starts
+        if self.W == 1:
+            self.start = starts
+        else:   # the rollout as W * N training sequences of ``bptt`` ticks: [G, W * bptt, N, ..] -> [G, bptt, W * N, ..]
+            G, W, L, N = self.G, self.W, self.bptt, self.N
+            for k, dst in self.tb.items():
+                src = b[k]
+                dst.copy_(src.view((G, W, L, N) + tuple(src.shape[3:])).transpose(1, 2).reshape(dst.shape))
+            self.start.copy_(starts.view(W, L, N).transpose(0, 1).reshape(L, W * N))
+            for dst, src in zip(self.p0 + self.v0, self.p0w + self.v0w):            # [W, layers, G, N, H] -> [layers, G, W * N, H]
+                dst.copy_(src.permute(1, 2, 0, 3, 4).reshape(dst.shape))
         for _ in range(cfg.learning_epochs):
             self.epoch_active.fill_(1.0)
-            perm = torch.randperm(self.N, generator=gen).to(self.device)
+            perm = torch.randperm(self.W * self.N, generator=gen).to(self.device)
             for k in range(cfg.mini_batches):
                 self.idx.copy_(perm[k * self.B:(k + 1) * self.B])
                 self.minibatch_step(use_graph)
@@ -322,7 +355,8 @@ class MAPPOTrainer:
             names = [a for a in self.agents if a.split("_")[0] in grp]
             idx = [self.agents.index(a) for a in names]
             self.roles["+".join(grp)] = RoleLearner("+".join(grp), names, idx, self.R, self.N, self.tcfg.horizon, cfgs[grp[0]],
-                                                    self.device, dt, seeds=[seed * 1000 + i for i in idx])
+                                                    self.device, dt, seeds=[seed * 1000 + i for i in idx],
+                                                    bptt=min(self.tcfg.bptt, self.tcfg.horizon))
         for rl in self.roles.values():
             mask = [r in self.tcfg.random_action_roles for r in rl.agent_roles]
             rl.random_rows = torch.tensor(mask, device=self.device).view(rl.G, 1) if any(mask) else None
@@ -363,6 +397,9 @@ class MAPPOTrainer:
             keep = (~self._starts).view(1, N)
             self._start_buf[t].copy_(self._starts)
             for rl in self.roles.values():
+                if t % rl.bptt == 0:                # the recurrent state at the start of a BPTT window is kept
+                    for dst, src in zip(rl.p0w + rl.v0w, rl.p_state + rl.v_state):
+                        dst[t // rl.bptt].copy_(src)
                 pin, vin = self._inputs(rl, self._obs, state)
                 logits, p_new = rl.policy.forward(pin.unsqueeze(1), rl.p_state, keep)
                 val, v_new = rl.value.forward(vin.unsqueeze(1), rl.v_state, keep)
@@ -389,10 +426,7 @@ class MAPPOTrainer:
 
     @torch.no_grad()
     def collect(self, random_actions: bool = False) -> None:
-        """One rollout of ``horizon`` ticks into the role buffers (the recurrent state at its start is kept for BPTT)."""
-        for rl in self.roles.values():
-            for dst, src in zip(rl.p0 + rl.v0, rl.p_state + rl.v_state):
-                dst.copy_(src)
+        """One rollout of ``horizon`` ticks into the role buffers."""
         use_graph = self.tcfg.graph_rollout and self.use_graphs and not random_actions
         if not use_graph:
             self._rollout_ticks(random_actions)

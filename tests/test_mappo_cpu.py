@@ -279,3 +279,25 @@ def test_two_rank_training_keeps_replicas_identical(kl):
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
     if kl:
         assert got[0][1].max() < 3 * 2 * 2                          # some minibatches were skipped, identically on both ranks
+
+
+def test_rollout_of_several_bptt_windows_trains_on_window_sequences():
+    """horizon = W x bptt: the rollout is cut into W * N training sequences of ``bptt`` ticks, each with the recurrent state
+    it started from; the number of optimiser steps per update does not change."""
+    rc = _rc(learning_epochs=1, mini_batches=2)
+    tr = MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=8, bptt=4, policy_freeze_duration=0,
+                                                                     opponent_freeze_duration=0), seed=1)
+    rl = tr.roles["cop+thief"]
+    assert (rl.W, rl.bptt, rl.B) == (2, 4, 8) and rl.tb["pin"].shape[:3] == (3, 4, 16)
+    tr.collect(); tr.collect()
+    h_at_window_1 = tuple(s.clone() for s in rl.p0w)                 # [W, layers, G, N, H]
+    assert float(h_at_window_1[0][1].abs().max()) > 0                # window 1 starts from a non-zero state
+    tr.update()
+    N = rl.N
+    for w in range(2):
+        sl = slice(w * N, (w + 1) * N)
+        assert torch.equal(rl.tb["pin"][:, :, sl], rl.buf["pin"][:, w * 4:(w + 1) * 4])
+        assert torch.equal(rl.tb["act"][:, :, sl], rl.buf["act"][:, w * 4:(w + 1) * 4])
+        assert torch.equal(rl.start[:, sl], tr._start_buf[w * 4:(w + 1) * 4])
+        assert torch.equal(rl.p0[0][:, :, sl], h_at_window_1[0][w]) and torch.equal(rl.v0[1][:, :, sl], rl.v0w[1][w])
+    assert float(rl.steps.max()) == 2                                # 1 epoch x 2 minibatches
