@@ -30,10 +30,10 @@ out = {
         "valu_insts_per_wave": val["SQ_INSTS_VALU"] / waves, "salu_insts_per_wave": val["SQ_INSTS_SALU"] / waves,
         "lds_insts_per_wave": val["SQ_INSTS_LDS"] / waves,
         "lane_utilisation": val["SQ_THREAD_CYCLES_VALU"] / (64 * val["SQ_ACTIVE_INST_VALU"]),
-        "valu_issue_busy_frac": val["SQ_ACTIVE_INST_VALU"] / 1024 / (val["SQ_BUSY_CYCLES"] / 32),
+        "valu_issue_busy_frac": 4 * val["SQ_ACTIVE_INST_VALU"] / 1024 / (val["SQ_BUSY_CYCLES"] / 32),
         "lds_bank_conflict_per_active_cycle": val["SQ_LDS_BANK_CONFLICT"] / val["SQ_ACTIVE_INST_LDS"],
-        "note": "valu_issue_busy_frac = SQ_ACTIVE_INST_VALU (per-SIMD issue slots of 4 cycles, 1024 SIMDs) / SQ_BUSY_CYCLES (per shader "
-                "engine, 32 of them); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)"},
+        "note": "valu_issue_busy_frac = 4 x SQ_ACTIVE_INST_VALU (issue slots of 4 cycles, summed over 1024 SIMDs) / 1024 / (SQ_BUSY_CYCLES / 32: "
+                "per shader engine, 32 of them); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)"},
 }
 (root / "profiles" / f"{tag}_traffic.json").write_text(json.dumps(out, indent=1) + "\n")
 print(json.dumps(out, indent=1))
