@@ -58,6 +58,7 @@ def _run(cfg, maps, slot, ticks, rng, spread=None, check_every=1, auto_reset=Fal
                 assert_outputs_equal(to_np(gpu.out), cpu.out, keys=("obs_distance", "obs_type", "hit_shape",
                                      "shared_distance", "shared_type", "team_positions"), ctx=f"auto-reset {t}")
                 assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"auto-reset {t}")
+    assert gpu.device_errors() == 0          # no wall contact dropped for want of a cache slot, no bad action
     gpu.close()
     return dict(contacts=n_contacts, captured=n_captured, done=n_done)
 
@@ -367,4 +368,5 @@ def test_long_rollout_soak_single_launch_step():
             assert_outputs_equal(to_np(g), {**cpu.out, **keep}, keys=obs_keys + tuple(keep), ctx=f"tick {t}")
             assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"tick {t}")
     assert done >= n * 10
+    assert gpu.device_errors() == 0          # no wall contact was dropped for want of a cache slot, no bad action flagged
     gpu.close()
