@@ -234,8 +234,8 @@ def main() -> None:
         for label, w in EXTRA_WORKLOADS:
             s2, c2, m2 = build_sim(w["map"], w["cops"], w["thieves"], w["envs"], args.rays, 0, dev)
             s2.reset()
-            k_steps = min(args.steps, 400)
-            e2, k2, _ = timed_steps(s2, k_steps, min(args.warmup, 100), fence, hip)
+            k_steps = 300                                   # own step counts: the driver's --steps 20 --warmup 5 would only
+            e2, k2, _ = timed_steps(s2, k_steps, 100, fence, hip)   # see the first ticks after the reset
             bytes2 = algorithmic_bytes_per_env_step(c2.n_agents, c2.n_rays) * c2.n_envs
             extra[label] = {"value": c2.n_envs * k_steps / e2, "unit": "env-steps/s", "steps": k_steps,
                             "ms_per_step": 1e3 * e2 / k_steps, "kernel_ms": k2,
