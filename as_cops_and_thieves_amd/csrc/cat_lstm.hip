@@ -1,0 +1,297 @@
+// cat_lstm.hip -- libcat_lstm.so: the LSTM recurrence of the role-stacked self-play learner on MI355X (gfx950).
+//
+// What it replaces (include/cat_lstm.h): per BPTT step a batched GEMM + the fused gate kernel + the episode-start
+// masks forward, the gate gradient + a batched GEMM + masks backward -- about forty ~5 us launches per step and
+// layer.  Here the window of one layer is ONE launch per direction:
+//
+//   * a workgroup = 16 sequences of one network, 4 waves; wave w owns hidden units [32w, 32w+32) with all four gates;
+//   * the products are computed TRANSPOSED on v_mfma_f32_16x16x32_bf16: gates^T [4H x 16] = W_hh [4H x H] * h^T, so the
+//     A operand is rows of W_hh (register resident for the whole window: 32 fragments = 128 VGPRs per lane), the lanes
+//     of an accumulator are sequences, and the four registers of a lane are four CONSECUTIVE hidden units: every
+//     global access of the recurrence is an 8-byte (4 x bf16) access, the cell arithmetic happens in the accumulator
+//     registers in fp32, and the cell state c never leaves the registers during the window;
+//   * the only exchange between the waves is h_t (forward) / the gate gradients (backward), through a double-buffered
+//     padded LDS tile: one barrier per step;
+//   * what backward needs (activated gates, c entering the step, tanh c leaving it) is written in the accumulator's own
+//     lane order -- fully coalesced, read back by the same lanes.
+//
+// Backward: d h_{t-1}^T [H x 16] = W_hh^T [H x 4H] * d gates^T; the A operand is W_hh^T gathered once per launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "cat_lstm.h"
+
+namespace {
+
+constexpr int H = CAT_LSTM_HIDDEN, H4 = 4 * H, BM = CAT_LSTM_ROWS_PER_BLOCK, NW = 4, LANES = 64;
+constexpr int HPAD = H + 8, GPAD = H4 + 8;          // LDS row strides (bf16): 272 B / 1040 B -> 16 rows hit 64 distinct banks
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f32x4 widen(bf16x4 v) { return __builtin_convertvector(v, f32x4); }
+__device__ __forceinline__ bf16x4 narrow(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+__device__ __forceinline__ bf16x4 zero4() { return narrow(f32x4{0.f, 0.f, 0.f, 0.f}); }
+
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+// index (in bf16 elements) of a lane's 4-vector inside the saved buffers
+__device__ __forceinline__ size_t acts_index(int t, int g, int G, int nblk, int blk, int w, int tile, int lane)
+{
+    return ((((size_t)(t * G + g) * nblk + blk) * NW + w) * 8 + tile) * (LANES * 4) + lane * 4;
+}
+__device__ __forceinline__ size_t cell_index(int t, int g, int G, int nblk, int blk, int w, int which, int hh, int lane)
+{
+    return (((((size_t)(t * G + g) * nblk + blk) * NW + w) * 2 + which) * 2 + hh) * (LANES * 4) + lane * 4;
+}
+
+__global__ __launch_bounds__(NW *LANES) void lstm_seq_fwd_kernel(const cat_lstm_fwd a)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 hbuf[2][BM][HPAD];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, r = l & 15;
+    const int g = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x, G = a.d.G, T = a.d.T, B = a.d.B;
+    const int b = blk * BM + r;
+    const bool row_ok = b < B;
+    const int hid0 = 32 * w + 4 * q;                       // + 16 * hh: this lane's four hidden units of half hh
+
+    // W_hh fragments: A[row = gate column n0 + r][k = 32 ks + 8 q + j]
+    bf16x8 wf[4][2][4];
+    {
+        const __bf16 *wg = (const __bf16 *)a.w_hh + (size_t)g * a.sw_g;
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    wf[gt][hh][ks] = *(const bf16x8 *)(wg + (size_t)(gt * H + 32 * w + 16 * hh + r) * H + 32 * ks + 8 * q);
+    }
+    const __bf16 *xg = (const __bf16 *)a.xproj + (size_t)g * a.sx_g + (size_t)b * a.sx_b;
+    __bf16 *og = (__bf16 *)a.out + (size_t)g * a.so_g + (size_t)b * a.so_b;
+    const size_t state_row = ((size_t)g * B + b) * H;
+    const bool save = a.saved_acts != nullptr;
+
+    f32x4 c[2];
+    {
+        const float k0 = (a.keep && row_ok) ? a.keep[b] : 1.0f;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int hid = hid0 + 16 * hh;
+            f32x4 h = widen(row_ok ? *(const bf16x4 *)((const __bf16 *)a.h0 + state_row + hid) : zero4()) * k0;
+            c[hh] = widen(row_ok ? *(const bf16x4 *)((const __bf16 *)a.c0 + state_row + hid) : zero4()) * k0;
+            const bf16x4 hb = narrow(h);
+            *(bf16x4 *)&hbuf[0][r][hid] = hb;
+            if (a.h_in && row_ok) *(bf16x4 *)((__bf16 *)a.h_in + (((size_t)g * T + 0) * B + b) * H + hid) = hb;
+        }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                acc[gt][hh] = widen(row_ok ? *(const bf16x4 *)(xg + (size_t)t * a.sx_t + gt * H + hid0 + 16 * hh) : zero4());
+        const float kn = (a.keep && row_ok && t + 1 < T) ? a.keep[(size_t)(t + 1) * B + b] : 1.0f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 hb = *(const bf16x8 *)&hbuf[cur][r][32 * ks + 8 * q];
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    acc[gt][hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[gt][hh][ks], hb, acc[gt][hh], 0, 0, 0);
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int hid = hid0 + 16 * hh;
+            f32x4 gi, gf, gg, go, cy, tc, hy;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                gi[i] = sigmoidf(acc[0][hh][i]);
+                gf[i] = sigmoidf(acc[1][hh][i]);
+                gg[i] = tanh_fast(acc[2][hh][i]);
+                go[i] = sigmoidf(acc[3][hh][i]);
+                cy[i] = gf[i] * c[hh][i] + gi[i] * gg[i];
+                tc[i] = tanh_fast(cy[i]);
+                hy[i] = go[i] * tc[i];
+            }
+            if (save) {
+                __bf16 *sa = (__bf16 *)a.saved_acts, *sc = (__bf16 *)a.saved_cell;
+                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 0 + hh, l)) = narrow(gi);
+                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 2 + hh, l)) = narrow(gf);
+                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 4 + hh, l)) = narrow(gg);
+                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 6 + hh, l)) = narrow(go);
+                *(bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 0, hh, l)) = narrow(c[hh]);
+                *(bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 1, hh, l)) = narrow(tc);
+            }
+            if (row_ok) *(bf16x4 *)(og + (size_t)t * a.so_t + hid) = narrow(hy);
+            if (t + 1 < T) {
+                const bf16x4 hb = narrow(hy * kn);
+                *(bf16x4 *)&hbuf[cur ^ 1][r][hid] = hb;
+                if (a.h_in && row_ok) *(bf16x4 *)((__bf16 *)a.h_in + (((size_t)g * T + t + 1) * B + b) * H + hid) = hb;
+                c[hh] = cy * kn;
+            } else if (row_ok) {
+                *(bf16x4 *)((__bf16 *)a.h_last + state_row + hid) = narrow(hy);
+                *(bf16x4 *)((__bf16 *)a.c_last + state_row + hid) = narrow(cy);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_bwd a)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 dgbuf[2][BM][GPAD];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, r = l & 15;
+    const int g = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x, G = a.d.G, T = a.d.T, B = a.d.B;
+    const int b = blk * BM + r;
+    const bool row_ok = b < B;
+    const int hid0 = 32 * w + 4 * q;
+
+    // W_hh^T fragments: A[row = hidden m0 + r][k = gate column 32 ks + 8 q + j] = W_hh[k][m0 + r]
+    bf16x8 wt[2][16];
+    {
+        const __bf16 *wg = (const __bf16 *)a.w_hh + (size_t)g * a.sw_g;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    wt[hh][ks][j] = wg[(size_t)(32 * ks + 8 * q + j) * H + 32 * w + 16 * hh + r];
+    }
+    const __bf16 *og = a.d_out ? (const __bf16 *)a.d_out + (size_t)g * a.so_g + (size_t)b * a.so_b : nullptr;
+    __bf16 *xg = (__bf16 *)a.d_xproj + (size_t)g * a.sx_g + (size_t)b * a.sx_b;
+    const size_t state_row = ((size_t)g * B + b) * H;
+    const __bf16 *sa = (const __bf16 *)a.saved_acts, *sc = (const __bf16 *)a.saved_cell;
+
+    f32x4 dh[2], dc[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int hid = hid0 + 16 * hh;
+        dh[hh] = widen((a.d_h_last && row_ok) ? *(const bf16x4 *)((const __bf16 *)a.d_h_last + state_row + hid) : zero4());
+        dc[hh] = widen((a.d_c_last && row_ok) ? *(const bf16x4 *)((const __bf16 *)a.d_c_last + state_row + hid) : zero4());
+    }
+
+    for (int t = T - 1; t >= 0; --t) {
+        const int buf = t & 1;
+        const float kt = (a.keep && row_ok) ? a.keep[(size_t)t * B + b] : 1.0f;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int hid = hid0 + 16 * hh;
+            f32x4 d = dh[hh];
+            if (og && row_ok) d += widen(*(const bf16x4 *)(og + (size_t)t * a.so_t + hid));
+            const f32x4 gi = widen(*(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 0 + hh, l)));
+            const f32x4 gf = widen(*(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 2 + hh, l)));
+            const f32x4 gg = widen(*(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 4 + hh, l)));
+            const f32x4 go = widen(*(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 6 + hh, l)));
+            const f32x4 cin = widen(*(const bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 0, hh, l)));
+            const f32x4 tc = widen(*(const bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 1, hh, l)));
+            f32x4 di, df, dg, d_o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dct = d[i] * go[i] * (1.0f - tc[i] * tc[i]) + dc[hh][i];
+                d_o[i] = d[i] * tc[i] * go[i] * (1.0f - go[i]);
+                di[i] = dct * gg[i] * gi[i] * (1.0f - gi[i]);
+                df[i] = dct * cin[i] * gf[i] * (1.0f - gf[i]);
+                dg[i] = dct * gi[i] * (1.0f - gg[i] * gg[i]);
+                dc[hh][i] = dct * gf[i] * kt;
+            }
+            const bf16x4 v0 = narrow(di), v1 = narrow(df), v2 = narrow(dg), v3 = narrow(d_o);
+            *(bf16x4 *)&dgbuf[buf][r][0 * H + hid] = v0;
+            *(bf16x4 *)&dgbuf[buf][r][1 * H + hid] = v1;
+            *(bf16x4 *)&dgbuf[buf][r][2 * H + hid] = v2;
+            *(bf16x4 *)&dgbuf[buf][r][3 * H + hid] = v3;
+            if (row_ok) {
+                __bf16 *x = xg + (size_t)t * a.sx_t + hid;
+                *(bf16x4 *)(x + 0 * H) = v0;
+                *(bf16x4 *)(x + 1 * H) = v1;
+                *(bf16x4 *)(x + 2 * H) = v2;
+                *(bf16x4 *)(x + 3 * H) = v3;
+            }
+        }
+        __syncthreads();
+        if (t > 0 || a.d_h0) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const bf16x8 db = *(const bf16x8 *)&dgbuf[buf][r][32 * ks + 8 * q];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    acc[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[hh][ks], db, acc[hh], 0, 0, 0);
+            }
+            dh[0] = acc[0] * kt;
+            dh[1] = acc[1] * kt;
+        }
+    }
+    if (row_ok) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int hid = hid0 + 16 * hh;
+            if (a.d_h0) *(bf16x4 *)((__bf16 *)a.d_h0 + state_row + hid) = narrow(dh[hh]);
+            if (a.d_c0) *(bf16x4 *)((__bf16 *)a.d_c0 + state_row + hid) = narrow(dc[hh]);
+        }
+    }
+}
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+
+bool dims_ok(const cat_lstm_dims &d) { return d.G > 0 && d.G <= 65535 && d.T > 0 && d.T <= CAT_LSTM_MAX_T && d.B > 0; }
+bool aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
+int blocks_of(const cat_lstm_dims &d) { return (d.B + BM - 1) / BM; }
+
+}   // namespace
+
+extern "C" int cat_lstm_abi_version(void) { return CAT_LSTM_ABI_VERSION; }
+extern "C" const char *cat_lstm_last_error(void) { return g_err; }
+
+extern "C" size_t cat_lstm_saved_acts_bytes(const cat_lstm_dims *d)
+{
+    return d && dims_ok(*d) ? (size_t)d->T * d->G * blocks_of(*d) * NW * 8 * LANES * 4 * 2 : 0;
+}
+extern "C" size_t cat_lstm_saved_cell_bytes(const cat_lstm_dims *d)
+{
+    return d && dims_ok(*d) ? (size_t)d->T * d->G * blocks_of(*d) * NW * 4 * LANES * 4 * 2 : 0;
+}
+
+extern "C" int cat_lstm_seq_forward(const cat_lstm_fwd *a, void *stream)
+{
+    if (!a || !dims_ok(a->d)) return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_forward: bad dimensions");
+    if (!a->xproj || !a->w_hh || !a->h0 || !a->c0 || !a->out || !a->h_last || !a->c_last)
+        return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_forward: a required buffer is NULL");
+    if ((a->saved_acts == nullptr) != (a->saved_cell == nullptr))
+        return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_forward: saved_acts and saved_cell go together");
+    if (!aligned(a->w_hh, 16) || (a->sw_g % 8) || !aligned(a->xproj, 8) || (a->sx_g % 4) || (a->sx_t % 4) || (a->sx_b % 4) ||
+        !aligned(a->out, 8) || (a->so_g % 4) || (a->so_t % 4) || (a->so_b % 4) || !aligned(a->h0, 8) || !aligned(a->c0, 8) ||
+        !aligned(a->h_last, 8) || !aligned(a->c_last, 8) || !aligned(a->h_in, 8) || !aligned(a->saved_acts, 8) || !aligned(a->saved_cell, 8))
+        return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_forward: misaligned buffer or stride");
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(blocks_of(a->d), a->d.G), dim3(NW * LANES), 0, (hipStream_t)stream, *a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_LSTM_OK : fail(CAT_LSTM_ERR_HIP, hipGetErrorString(e));
+}
+
+extern "C" int cat_lstm_seq_backward(const cat_lstm_bwd *a, void *stream)
+{
+    if (!a || !dims_ok(a->d)) return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_backward: bad dimensions");
+    if (!a->w_hh || !a->saved_acts || !a->saved_cell || !a->d_xproj)
+        return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_backward: a required buffer is NULL");
+    if (!aligned(a->w_hh, 2) || !aligned(a->d_xproj, 8) || (a->sx_g % 4) || (a->sx_t % 4) || (a->sx_b % 4) || !aligned(a->d_out, 8) ||
+        (a->d_out && ((a->so_g % 4) || (a->so_t % 4) || (a->so_b % 4))) || !aligned(a->d_h_last, 8) || !aligned(a->d_c_last, 8) ||
+        !aligned(a->d_h0, 8) || !aligned(a->d_c0, 8) || !aligned(a->saved_acts, 8) || !aligned(a->saved_cell, 8))
+        return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_backward: misaligned buffer or stride");
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(blocks_of(a->d), a->d.G), dim3(NW * LANES), 0, (hipStream_t)stream, *a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_LSTM_OK : fail(CAT_LSTM_ERR_HIP, hipGetErrorString(e));
+}

@@ -8,9 +8,9 @@ extra kernel launch.  The G agents' parameters are rows of ONE flat fp32 buffer 
 accumulate into views of one flat gradient buffer, so the gradient all-reduce, the per-agent norm clip and
 Adam are a handful of kernels per optimiser step whatever the number of layers.
 
-The LSTM recurrence over a BPTT window is one autograd node (``_LSTMSeq``): per time step a batched GEMM plus
-the fused gate kernel forward, the fused gate gradient plus a batched GEMM backward, and the weight gradient
-as ONE GEMM over all steps (fp32 accumulation), instead of autograd's per-step graph.
+The LSTM recurrence over a BPTT window is one autograd node (``_LSTMSeq``): in bf16 on the GPU one launch of
+``libcat_lstm.so`` forward and one backward for the whole window of a layer (``csrc/cat_lstm.hip``), the weight
+gradient ONE GEMM over all steps (fp32 accumulation); in fp32 / on the CPU the same recurrence step by step.
 """
 from __future__ import annotations
 
@@ -21,6 +21,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 import torch.nn as nn
 
+from .. import _lstm_native
 from .models import LSTMPolicy, LSTMValue, conv_out_len
 
 HIDDEN = 128
@@ -62,56 +63,72 @@ def _cell_bwd(dh: torch.Tensor, dc: Optional[torch.Tensor], c: torch.Tensor, cy:
 
 
 class _LSTMSeq(torch.autograd.Function):
-    """h_t, c_t = cell(xproj[t] + h_{t-1} W_hh^T, c_{t-1}) for t = 0..T-1, with the state zeroed where ``keep[t]`` is 0
-    (an episode starts at step t).  Time-major: xproj [T, G, B, 4H]; w_hh [G, 4H, H]; h0, c0 [G, B, H]; keep [T, 1, B, 1]
-    or None.  Returns out [T, G, B, H], h_T, c_T."""
+    """h_t, c_t = cell(xproj[:, t] + h_{t-1} W_hh^T, c_{t-1}) for t = 0..T-1, with the state zeroed where ``keep[t]`` is 0
+    (an episode starts at step t).  xproj [G, T, B, 4H]; w_hh [G, 4H, H]; h0, c0 [G, B, H]; keep fp32 [T, B] or None.
+    Returns out [G, T, B, H], h_T, c_T.
+
+    bf16 on a GPU: the whole window is ONE launch of ``libcat_lstm.so`` per direction (``csrc/cat_lstm.hip``: W_hh
+    resident in registers, the products on the matrix cores, the cell in fp32) -- no other path exists there.  fp32 /
+    CPU (the parity tests, ``compute_bf16=False``): the same recurrence step by step in torch."""
 
     @staticmethod
     def forward(ctx, xproj, w_hh, h0, c0, keep):
-        T = xproj.shape[0]
+        G, T, B, _ = xproj.shape
+        train = any(ctx.needs_input_grad)          # a rollout tick (no_grad) keeps nothing
+        ctx.has_keep = keep is not None
+        ctx.set_materialize_grads(False)           # unused final-state gradients arrive as None, not as zero tensors
+        ctx.native = xproj.is_cuda and xproj.dtype == torch.bfloat16
+        if ctx.native:
+            out, hT, cT, (h_in, acts, cell) = _lstm_native.seq_forward(xproj, w_hh, h0, c0, keep, save=train)
+            if train:
+                ctx.save_for_backward(w_hh, h_in, acts, cell, keep if keep is not None else torch.empty(0))
+                ctx.dims = (G, T, B)
+            return out, hT, cT
         w_t = w_hh.transpose(1, 2)
         h, c = h0, c0
-        train = any(ctx.needs_input_grad)          # a rollout tick (no_grad) keeps nothing
         hs, cs, cys, wss, outs = [], [], [], [], []
-        kf = keep
+        kf = None if keep is None else keep.to(xproj.dtype).view(T, 1, B, 1)
         for t in range(T):
             if kf is not None:
                 h, c = h * kf[t], c * kf[t]
             hg = torch.bmm(h, w_t)
-            hy, cy, ws = _cell_fwd(xproj[t], hg, c)
+            hy, cy, ws = _cell_fwd(xproj[:, t], hg, c)
             if train:
                 hs.append(h); cs.append(c); cys.append(cy); wss.append(ws)
             outs.append(hy)
             h, c = hy, cy
-        out = torch.stack(outs, 0) if T > 1 else outs[0].unsqueeze(0)
+        out = torch.stack(outs, 1)
         if train:
-            ctx.save_for_backward(w_hh, torch.stack(hs, 0), torch.stack(cs, 0), torch.stack(cys, 0), torch.stack(wss, 0),
+            ctx.save_for_backward(w_hh, torch.stack(hs, 1), torch.stack(cs, 0), torch.stack(cys, 0), torch.stack(wss, 0),
                                   kf if kf is not None else torch.empty(0))
-        ctx.has_keep = kf is not None
-        ctx.set_materialize_grads(False)           # unused final-state gradients arrive as None, not as zero tensors
         return out, h, c
 
     @staticmethod
     def backward(ctx, d_out, d_hT, d_cT):
-        w_hh, hs, cs, cys, wss, keep = ctx.saved_tensors
-        T = hs.shape[0]
-        dh, dc = d_hT, d_cT
-        dgs = [None] * T
-        for t in range(T - 1, -1, -1):
-            if d_out is None:
-                dh_t = dh if dh is not None else torch.zeros_like(hs[t])
-            else:
-                dh_t = d_out[t] if dh is None else d_out[t] + dh
-            dg, dc = _cell_bwd(dh_t, dc, cs[t], cys[t], wss[t])
-            dh = torch.bmm(dg, w_hh)
-            if ctx.has_keep:
-                dh, dc = dh * keep[t], dc * keep[t]
-            dgs[t] = dg
-        dg_all = torch.stack(dgs, 0)                                             # [T, G, B, 4H] = d xproj
-        G, H4 = dg_all.shape[1], dg_all.shape[3]
-        a = dg_all.transpose(0, 1).reshape(G, -1, H4)                             # [G, T*B, 4H]
-        b = hs.transpose(0, 1).reshape(G, -1, hs.shape[3])                        # [G, T*B, H]
-        d_w = torch.bmm(a.transpose(1, 2), b)                                     # one GEMM over all steps
+        if ctx.native:
+            w_hh, h_in, acts, cell, keep = ctx.saved_tensors
+            G, T, B = ctx.dims
+            want_state = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+            dg_all, dh, dc = _lstm_native.seq_backward(d_out, d_hT, d_cT, w_hh, keep if ctx.has_keep else None, acts, cell,
+                                                       ctx.dims, want_state)
+        else:
+            w_hh, h_in, cs, cys, wss, keep = ctx.saved_tensors
+            G, T, B = h_in.shape[:3]
+            dh, dc = d_hT, d_cT
+            dgs = [None] * T
+            for t in range(T - 1, -1, -1):
+                if d_out is None:
+                    dh_t = dh if dh is not None else torch.zeros_like(cs[t])
+                else:
+                    dh_t = d_out[:, t] if dh is None else d_out[:, t] + dh
+                dg, dc = _cell_bwd(dh_t, dc, cs[t], cys[t], wss[t])
+                dh = torch.bmm(dg, w_hh)
+                if ctx.has_keep:
+                    dh, dc = dh * keep[t], dc * keep[t]
+                dgs[t] = dg
+            dg_all = torch.stack(dgs, 1)                                          # [G, T, B, 4H] = d xproj
+        a = dg_all.reshape(G, T * B, dg_all.shape[3])
+        d_w = torch.bmm(a.transpose(1, 2), h_in.reshape(G, T * B, h_in.shape[3]))   # one GEMM over all steps
         return dg_all, d_w, dh, dc, None
 
 
@@ -294,15 +311,15 @@ class StackedNet:
         wfc = self.w("trunk.features.5.weight").view(G, 256, 32, self.L2).transpose(2, 3).reshape(G, 256, self.L2 * 32)
         f = torch.tanh(_lin(z, wfc, self.w("trunk.features.5.bias")))                            # [G, T*B, 256]
         h0, c0 = state
-        kp = None if keep is None else keep.to(dt).view(T, 1, B, 1)
+        kp = None if keep is None else keep.to(torch.float32).contiguous()
         inp = f
         hs, cs = [], []
         for l in range(self.layers):
             bias = self.w(f"trunk.lstm.bias_ih_l{l}") + self.w(f"trunk.lstm.bias_hh_l{l}")
-            xp = _lin(inp, self.w(f"trunk.lstm.weight_ih_l{l}"), bias).view(G, T, B, 4 * HIDDEN).transpose(0, 1).contiguous()
+            xp = _lin(inp, self.w(f"trunk.lstm.weight_ih_l{l}"), bias).view(G, T, B, 4 * HIDDEN)
             out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), h0[l].to(dt), c0[l].to(dt), kp)
             hs.append(hT); cs.append(cT)
-            inp = out.transpose(0, 1).reshape(G, N, HIDDEN)                                      # back to [G, T*B, H]
+            inp = out.reshape(G, N, HIDDEN)
         y = inp
         for j in range(self.n_head):
             y = _lin(y, self.w(f"head.{2 * j}.weight"), self.w(f"head.{2 * j}.bias"))

@@ -28,6 +28,26 @@ def test_library_exports_every_declared_symbol():
     assert L.cat_abi_version() == 1
 
 
+def test_lstm_library_exports_every_declared_symbol_and_struct_layouts_match():
+    """include/cat_lstm.h <-> libcat_lstm.so <-> the ctypes mirror (no compute call: no GPU here)."""
+    from as_cops_and_thieves_amd import _lstm_native as ln
+    ln.build()
+    L = ln.lib()
+    text = (ROOT / "include" / "cat_lstm.h").read_text()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(cat_lstm_[a-z_0-9]+)\s*\(", code)))
+    assert set(declared) == set(ln.EXPORTED_SYMBOLS) and all(hasattr(L, s) for s in declared)
+    for struct, cls in (("cat_lstm_dims", ln.Dims), ("cat_lstm_fwd", ln.FwdArgs), ("cat_lstm_bwd", ln.BwdArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), code, re.S).group(1)
+        names = [n for decl in body.split(";") for n in re.findall(r"\b([A-Za-z_0-9]+)\s*(?=,|$)", decl.strip())]
+        assert names == [f[0] for f in cls._fields_], (struct, names)
+    d = ln.Dims(3, 16, 100, 0)                                   # 7 blocks of 16 sequences
+    assert L.cat_lstm_saved_acts_bytes(C.byref(d)) == 16 * 3 * 7 * 16 * 512 * 2
+    assert L.cat_lstm_saved_cell_bytes(C.byref(d)) == 16 * 3 * 7 * 16 * 256 * 2
+    bad = ln.FwdArgs()                                           # argument checks come before any device call
+    assert L.cat_lstm_seq_forward(C.byref(bad), None) == -1 and b"dimensions" in L.cat_lstm_last_error()
+
+
 def test_struct_layouts_match_header_field_order():
     from as_cops_and_thieves_amd import _native
     text = (ROOT / "include" / "cat_sim.h").read_text()
