@@ -1,5 +1,6 @@
-"""ctypes binding of libcat_lstm.so (include/cat_lstm.h): the LSTM recurrence of the self-play learner as one launch
-per direction.  No CPU fallback inside: callers on a CUDA/HIP device in bf16 get these kernels or an exception."""
+"""ctypes binding of libcat_learn.so (include/cat_lstm.h, include/cat_trunk.h): the LSTM recurrence and the
+convolutional trunk of the self-play learner's networks, one launch per direction each.  No CPU fallback inside: callers
+on a CUDA/HIP device in bf16 get these kernels or an exception."""
 from __future__ import annotations
 
 import ctypes as C
@@ -9,12 +10,15 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-LIB_PATH = PKG / "libcat_lstm.so"
-SRC = PKG / "csrc" / "cat_lstm.hip"
+LIB_PATH = PKG / "libcat_learn.so"
+SOURCES = (PKG / "csrc" / "cat_lstm.hip", PKG / "csrc" / "cat_trunk.hip")
+HEADERS = (ROOT / "include" / "cat_lstm.h", ROOT / "include" / "cat_trunk.h")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared"]
 HIDDEN = 128
 EXPORTED_SYMBOLS = ("cat_lstm_abi_version", "cat_lstm_last_error", "cat_lstm_saved_acts_bytes", "cat_lstm_saved_cell_bytes",
                     "cat_lstm_seq_forward", "cat_lstm_seq_backward")
+TRUNK_SYMBOLS = ("cat_trunk_abi_version", "cat_trunk_last_error", "cat_trunk_out_positions", "cat_trunk_supported",
+                 "cat_trunk_backward_blocks", "cat_trunk_forward", "cat_trunk_backward")
 
 
 class Dims(C.Structure):
@@ -37,24 +41,43 @@ class BwdArgs(C.Structure):
                 ("d_h0", C.c_void_p), ("d_c0", C.c_void_p)]
 
 
+class TrunkDims(C.Structure):
+    _fields_ = [("G", C.c_int32), ("N", C.c_int32), ("C", C.c_int32), ("R", C.c_int32)]
+
+
+class TrunkParams(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("sw1_g", C.c_int64), ("sb1_g", C.c_int64), ("sw2_g", C.c_int64), ("sb2_g", C.c_int64)]
+
+
+class TrunkFwd(C.Structure):
+    _fields_ = [("d", TrunkDims), ("p", TrunkParams), ("x", C.c_void_p), ("sx_g", C.c_int64), ("sx_n", C.c_int64),
+                ("out", C.c_void_p), ("so_g", C.c_int64), ("so_n", C.c_int64)]
+
+
+class TrunkBwd(C.Structure):
+    _fields_ = [("d", TrunkDims), ("p", TrunkParams), ("x", C.c_void_p), ("sx_g", C.c_int64), ("sx_n", C.c_int64),
+                ("out", C.c_void_p), ("d_out", C.c_void_p), ("so_g", C.c_int64), ("so_n", C.c_int64),
+                ("part_dw1", C.c_void_p), ("part_db1", C.c_void_p), ("part_dw2", C.c_void_p), ("part_db2", C.c_void_p)]
+
+
 class NativeLibraryMissing(RuntimeError):
     pass
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the kernels in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    hdr = ROOT / "include" / "cat_lstm.h"
-    stale = (not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < SRC.stat().st_mtime
-             or LIB_PATH.stat().st_mtime < hdr.stat().st_mtime)
+    newest = max(f.stat().st_mtime for f in SOURCES + HEADERS)
+    stale = not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < newest
     if force or stale:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", "-o", str(LIB_PATH), str(SRC)]
+        cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", "-o", str(LIB_PATH), *map(str, SOURCES)]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if verbose or res.returncode != 0:
             print(" ".join(cmd))
             print(res.stdout, res.stderr)
         if res.returncode != 0:
-            raise RuntimeError("hipcc failed building libcat_lstm.so")
+            raise RuntimeError("hipcc failed building libcat_learn.so")
     return LIB_PATH
 
 
@@ -79,13 +102,23 @@ def lib() -> C.CDLL:
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
         assert L.cat_lstm_abi_version() == 1
+        L.cat_trunk_abi_version.restype = C.c_int
+        L.cat_trunk_last_error.restype = C.c_char_p
+        for n in ("cat_trunk_out_positions", "cat_trunk_supported", "cat_trunk_backward_blocks"):
+            getattr(L, n).restype = C.c_int
+            getattr(L, n).argtypes = [C.c_void_p]
+        for n in ("cat_trunk_forward", "cat_trunk_backward"):
+            getattr(L, n).restype = C.c_int
+            getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
+        assert L.cat_trunk_abi_version() == 1
         _lib = L
     return _lib
 
 
 def _check(rc: int, what: str) -> None:
     if rc != 0:
-        raise RuntimeError(f"{what} failed ({rc}): {lib().cat_lstm_last_error().decode()}")
+        err = lib().cat_trunk_last_error() if "trunk" in what else lib().cat_lstm_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {err.decode()}")
 
 
 def _ptr(t) -> int:
@@ -150,3 +183,52 @@ def seq_backward(d_out, d_hT, d_cT, w_hh, keep, acts, cell, dims, want_state_gra
                 _ptr(d_h0), _ptr(d_c0))
     _check(lib().cat_lstm_seq_backward(C.byref(a), _stream()), "cat_lstm_seq_backward")
     return d_x, d_h0, d_c0
+
+
+# ---------------------------------------------------------------------------------------------- convolutional trunk
+def trunk_supported(G: int, N: int, C_in: int, R: int) -> bool:
+    d = TrunkDims(G, N, C_in, R)
+    return bool(lib().cat_trunk_supported(C.byref(d)))
+
+
+def _trunk_params(w1, b1, w2, b2, G: int, C_in: int) -> TrunkParams:
+    import torch
+    assert w1.shape == (G, 64, C_in, 5) and w1[0].is_contiguous() and b1.shape == (G, 64) and b1.stride(1) == 1
+    assert w2.shape == (G, 32, 64, 5) and w2[0].is_contiguous() and b2.shape == (G, 32) and b2.stride(1) == 1
+    assert all(t.dtype == torch.bfloat16 for t in (w1, b1, w2, b2))
+    return TrunkParams(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w1.stride(0), b1.stride(0), w2.stride(0), b2.stride(0))
+
+
+def trunk_forward(x, w1, b1, w2, b2, R: int):
+    """x bf16 [G, N, C * R] in (channel, ray) order -> bf16 [G, N, L2 * 32] in (position, channel) order."""
+    import torch
+    G, N, CR = x.shape
+    C_in = CR // R
+    assert x.dtype == torch.bfloat16 and x.stride(2) == 1 and C_in * R == CR
+    d = TrunkDims(G, N, C_in, R)
+    L2 = lib().cat_trunk_out_positions(C.byref(d))
+    out = torch.empty(G, N, L2 * 32, dtype=torch.bfloat16, device=x.device)
+    a = TrunkFwd(d, _trunk_params(w1, b1, w2, b2, G, C_in), x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(), out.stride(0), out.stride(1))
+    _check(lib().cat_trunk_forward(C.byref(a), _stream()), "cat_trunk_forward")
+    return out
+
+
+def trunk_backward(x, w1, b1, w2, b2, out, d_out, R: int):
+    """fp32 per-workgroup partial sums [G, B, 64, 32], [G, B, 64], [G, B, 32, 320], [G, B, 32] of the parameter gradients
+    (columns kk * C + c and kk * 64 + c_in): the caller adds the B slabs up."""
+    import torch
+    G, N, CR = x.shape
+    C_in = CR // R
+    d = TrunkDims(G, N, C_in, R)
+    d_out = d_out.contiguous()
+    assert out.is_contiguous() and d_out.shape == out.shape and d_out.dtype == torch.bfloat16
+    nb = lib().cat_trunk_backward_blocks(C.byref(d))
+    dev = x.device
+    pw1 = torch.empty(G, nb, 64, 32, dtype=torch.float32, device=dev)
+    pb1 = torch.empty(G, nb, 64, dtype=torch.float32, device=dev)
+    pw2 = torch.empty(G, nb, 32, 320, dtype=torch.float32, device=dev)
+    pb2 = torch.empty(G, nb, 32, dtype=torch.float32, device=dev)
+    a = TrunkBwd(d, _trunk_params(w1, b1, w2, b2, G, C_in), x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(), d_out.data_ptr(),
+                 out.stride(0), out.stride(1), pw1.data_ptr(), pb1.data_ptr(), pw2.data_ptr(), pb2.data_ptr())
+    _check(lib().cat_trunk_backward(C.byref(a), _stream()), "cat_trunk_backward")
+    return pw1, pb1, pw2, pb2

@@ -1,4 +1,4 @@
-// cat_lstm.hip -- libcat_lstm.so: the LSTM recurrence of the role-stacked self-play learner on MI355X (gfx950).
+// cat_lstm.hip -- libcat_learn.so: the LSTM recurrence of the role-stacked self-play learner on MI355X (gfx950).
 //
 // What it replaces (include/cat_lstm.h): per BPTT step a batched GEMM + the fused gate kernel + the episode-start
 // masks forward, the gate gradient + a batched GEMM + masks backward -- about forty ~5 us launches per step and

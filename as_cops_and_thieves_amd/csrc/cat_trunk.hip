@@ -1,0 +1,384 @@
+// cat_trunk.hip -- libcat_learn.so, part 2: Conv1d(C,64,5,s2) -> ReLU -> Conv1d(64,32,5,s3) -> ReLU of the learner's
+// role-stacked networks, forward and backward, on MI355X (gfx950).  include/cat_trunk.h has the interface.
+//
+// Why a kernel: as library GEMMs the two convolutions are either im2col copies of hundreds of MB or dense GEMMs on the
+// Toeplitz expansion of the weights (6-13x the flops), and either way the 1920-wide intermediate of every sample
+// crosses HBM about ten times per training step (GEMM out, bias, ReLU, GEMM in; mask, dgrad out, wgrad in, bias grad).
+// Here a workgroup takes 16 samples at a time and the intermediate exists in LDS only:
+//
+//   * every product is computed TRANSPOSED on v_mfma_f32_16x16x32_bf16 with the weights as the A operand, held in
+//     registers for the life of the (persistent) workgroup, and the 16 samples on the accumulator's lanes, so a lane's
+//     four accumulator registers are four consecutive channels of one sample;
+//   * with the input re-laid (ray, channel) and the intermediate (position, channel), the window of either convolution
+//     is a CONTIGUOUS run of the row: the B operand of a window is plain 8/16-byte LDS reads, no im2col;
+//   * backward recomputes the intermediate (cheaper than a 1920-wide round trip), computes its gradient per POSITION
+//     (each position collects the one or two (output position, tap) pairs that cover it, so nothing is scattered), and
+//     forms the weight gradients as products whose inner index is (sample, position): the operands it needs sample-
+//     contiguous are written to LDS in [column][sample] order by the passes that produce them.  Weight and bias
+//     gradients accumulate in registers over all tiles of the workgroup and leave as one fp32 slab per workgroup.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "cat_trunk.h"
+
+namespace {
+
+constexpr int C1 = CAT_TRUNK_C1, C2 = CAT_TRUNK_C2, KW = 5, TS = CAT_TRUNK_TILE, NW = 4, LANES = 64;
+constexpr int WIN2 = KW * C1;                 // 320: the second convolution's window in the (position, channel) row
+constexpr int LDS_LIMIT = 160 * 1024;
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ bf16x4 narrow(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+__device__ __forceinline__ f32x4 relu4(f32x4 v)
+{
+    return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+}
+__device__ __forceinline__ bf16x8 ld8(const __bf16 *p)   // 8-byte aligned
+{
+    const bf16x4 a = *(const bf16x4 *)p, b = *(const bf16x4 *)(p + 4);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ bf16x8 splat8(float v)
+{
+    const __bf16 b = (__bf16)v;
+    return bf16x8{b, b, b, b, b, b, b, b};
+}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+struct Geo {
+    int C, R, CR, L1, L2, XS, A1S, D2, D2S;
+    __device__ __host__ explicit Geo(const cat_trunk_dims &d)
+    {
+        C = d.C; R = d.R; CR = C * R;
+        L1 = (R - KW) / 2 + 1; L2 = (L1 - KW) / 3 + 1;
+        XS = CR + 40;                 // input row (ray, channel) + zeroed tail: the last windows read up to 31 past 5 C
+        A1S = L1 * C1 + 8;            // forward's intermediate row (position, channel), 16-byte aligned, bank-skewed
+        D2 = L2 * C2; D2S = D2 + 8;
+    }
+    __device__ __host__ size_t fwd_lds() const { return 2 * ((size_t)TS * XS + (size_t)TS * A1S); }
+    __device__ __host__ size_t bwd_lds() const
+    {
+        return 2 * ((size_t)TS * XS * 2 + (size_t)L1 * C1 * TS * 2 + (size_t)TS * D2S + (size_t)D2 * TS);
+    }
+};
+
+// A fragments of the first convolution: A[row = channel 16 mt + r][k = kk * C + c] = w1[channel][c][kk], 0 for k >= 5 C
+__device__ __forceinline__ void load_w1(const cat_trunk_params &p, int g, int C, int q, int r, bf16x8 (&w1f)[4], f32x4 (&bias1)[4])
+{
+    const __bf16 *w1 = (const __bf16 *)p.w1 + (size_t)g * p.sw1_g, *b1 = (const __bf16 *)p.b1 + (size_t)g * p.sb1_g;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * q + j, kk = k / C, c = k % C;
+            w1f[mt][j] = (k < KW * C) ? w1[((16 * mt + r) * C + c) * KW + kk] : (__bf16)0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias1[mt][e] = (float)b1[16 * mt + 4 * q + e];
+    }
+}
+
+// input tile -> LDS in (ray, channel) order (and optionally [column][sample]); rows past N and the row tails are zero
+__device__ __forceinline__ void stage_x(const __bf16 *xg, int64_t sx_n, int n0, int N, const Geo &ge, __bf16 *xs, __bf16 *xT)
+{
+    for (int e = threadIdx.x; e < TS * ge.XS; e += NW * LANES) {
+        const int s = e / ge.XS, j = e - s * ge.XS;
+        __bf16 v = (__bf16)0.0f;
+        if (j < ge.CR && n0 + s < N) {
+            const int ray = j / ge.C, c = j - ray * ge.C;
+            v = xg[(size_t)(n0 + s) * sx_n + c * ge.R + ray];
+        }
+        xs[e] = v;
+        if (xT) xT[j * TS + s] = v;
+    }
+}
+
+__global__ __launch_bounds__(NW *LANES) void trunk_fwd_kernel(const cat_trunk_fwd a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo ge(a.d);
+    __bf16 *xs = (__bf16 *)smem, *a1 = xs + TS * ge.XS;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, r = l & 15;
+    const int g = blockIdx.y, N = a.d.N, ntiles = (N + TS - 1) / TS;
+
+    bf16x8 w1f[4], w2f[2][10];
+    f32x4 bias1[4], bias2[2];
+    load_w1(a.p, g, ge.C, q, r, w1f, bias1);
+    {   // A[row = out channel 16 mt + r][k = kk * 64 + ci] = w2[out][ci][kk]
+        const __bf16 *w2 = (const __bf16 *)a.p.w2 + (size_t)g * a.p.sw2_g, *b2 = (const __bf16 *)a.p.b2 + (size_t)g * a.p.sb2_g;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < 10; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * ks + 8 * q + j, kk = k >> 6, ci = k & 63;
+                    w2f[mt][ks][j] = w2[((16 * mt + r) * C1 + ci) * KW + kk];
+                }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias2[mt][e] = (float)b2[16 * mt + 4 * q + e];
+        }
+    }
+    const __bf16 *xg = (const __bf16 *)a.x + (size_t)g * a.sx_g;
+    __bf16 *og = (__bf16 *)a.out + (size_t)g * a.so_g;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n0 = tile * TS;
+        stage_x(xg, a.sx_n, n0, N, ge, xs, nullptr);
+        __syncthreads();
+        for (int p = w; p < ge.L1; p += NW) {
+            const bf16x8 xb = ld8(xs + r * ge.XS + 2 * p * ge.C + 8 * q);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                *(bf16x4 *)(a1 + r * ge.A1S + p * C1 + 16 * mt + 4 * q) = narrow(relu4(MFMA(w1f[mt], xb, bias1[mt])));
+        }
+        __syncthreads();
+        for (int l2 = w; l2 < ge.L2; l2 += NW) {
+            f32x4 acc[2] = {bias2[0], bias2[1]};
+#pragma unroll
+            for (int ks = 0; ks < 10; ++ks) {
+                const bf16x8 ab = *(const bf16x8 *)(a1 + r * ge.A1S + 3 * C1 * l2 + 32 * ks + 8 * q);
+                acc[0] = MFMA(w2f[0][ks], ab, acc[0]);
+                acc[1] = MFMA(w2f[1][ks], ab, acc[1]);
+            }
+            if (n0 + r < N) {
+                __bf16 *o = og + (size_t)(n0 + r) * a.so_n + l2 * C2 + 4 * q;
+                *(bf16x4 *)(o) = narrow(relu4(acc[0]));
+                *(bf16x4 *)(o + 16) = narrow(relu4(acc[1]));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(NW *LANES) void trunk_bwd_kernel(const cat_trunk_bwd a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Geo ge(a.d);
+    __bf16 *xs = (__bf16 *)smem;                    // [16][XS]          input rows, (ray, channel)
+    __bf16 *xT = xs + TS * ge.XS;                   // [XS][16]          the same, sample-contiguous
+    __bf16 *a1T = xT + TS * ge.XS;                  // [L1 * 64][16]     intermediate after ReLU, sample-contiguous
+    __bf16 *dp1T = a1T + ge.L1 * C1 * TS;           // [L1 * 64][16]     gradient before the first ReLU
+    __bf16 *dp2 = dp1T + ge.L1 * C1 * TS;           // [16][D2S]         gradient before the second ReLU
+    __bf16 *dp2T = dp2 + TS * ge.D2S;               // [L2 * 32][16]     the same, sample-contiguous
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, r = l & 15;
+    const int g = blockIdx.y, N = a.d.N, ntiles = (N + TS - 1) / TS;
+    const int L1 = ge.L1, L2 = ge.L2;
+
+    bf16x8 w1f[4], w2t[KW][4];
+    f32x4 bias1[4];
+    load_w1(a.p, g, ge.C, q, r, w1f, bias1);
+    {   // A[row = ci 16 mt + r][k = out channel 8 q + j] = w2[out][ci][kk]
+        const __bf16 *w2 = (const __bf16 *)a.p.w2 + (size_t)g * a.p.sw2_g;
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w2t[kk][mt][j] = w2[((8 * q + j) * C1 + 16 * mt + r) * KW + kk];
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 zero8 = splat8(0.0f), ones8 = splat8(1.0f);
+    f32x4 dw2[2][5], dw1[2] = {zero, zero}, db1 = zero, db2[2] = {zero, zero};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dw2[mt][i] = zero;
+
+    const __bf16 *xg = (const __bf16 *)a.x + (size_t)g * a.sx_g;
+    const __bf16 *og = (const __bf16 *)a.out + (size_t)g * a.so_g, *dg = (const __bf16 *)a.d_out + (size_t)g * a.so_g;
+    const int sh = 8 * (q & 1), half = q >> 1;      // a K step of the weight-gradient products = 2 positions x 16 samples
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n0 = tile * TS;
+        stage_x(xg, a.sx_n, n0, N, ge, xs, xT);
+        for (int e = threadIdx.x; e < TS * ge.D2; e += NW * LANES) {
+            const int s = e / ge.D2, j = e - s * ge.D2;
+            __bf16 v = (__bf16)0.0f;
+            if (n0 + s < N) {
+                const size_t o = (size_t)(n0 + s) * a.so_n + j;
+                if ((float)og[o] > 0.0f) v = dg[o];
+            }
+            dp2[s * ge.D2S + j] = v;
+            dp2T[j * TS + s] = v;
+        }
+        __syncthreads();
+        for (int p = w; p < L1; p += NW) {           // the intermediate again
+            const bf16x8 xb = ld8(xs + r * ge.XS + 2 * p * ge.C + 8 * q);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const bf16x4 v = narrow(relu4(MFMA(w1f[mt], xb, bias1[mt])));
+                __bf16 *dst = a1T + (p * C1 + 16 * mt + 4 * q) * TS + r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[e * TS] = v[e];
+            }
+        }
+        __syncthreads();
+        for (int p = w; p < L1; p += NW) {           // gradient of position p: the (output position, tap) pairs covering it
+            f32x4 acc[4] = {zero, zero, zero, zero};
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) {
+                const int t = p - kk, l2 = t / 3;
+                if (t >= 0 && t == 3 * l2 && l2 < L2) {
+                    const bf16x8 db = *(const bf16x8 *)(dp2 + r * ge.D2S + l2 * C2 + 8 * q);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA(w2t[kk][mt], db, acc[mt]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int col = (p * C1 + 16 * mt + 4 * q) * TS + r;
+                const bf16x4 v = narrow(acc[mt]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp1T[col + e * TS] = ((float)a1T[col + e * TS] > 0.0f) ? v[e] : (__bf16)0.0f;
+            }
+        }
+        __syncthreads();
+        for (int l0 = 0; l0 < L2; l0 += 2) {         // dW2[out][window column] += sum over (sample, position)
+            const int lq = l0 + half;
+            const bool ok = lq < L2;
+            bf16x8 af[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[mt] = ok ? *(const bf16x8 *)(dp2T + (lq * C2 + 16 * mt + r) * TS + sh) : zero8;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const bf16x8 bf = ok ? *(const bf16x8 *)(a1T + (3 * C1 * lq + 16 * (w + NW * i) + r) * TS + sh) : zero8;
+                dw2[0][i] = MFMA(af[0], bf, dw2[0][i]);
+                dw2[1][i] = MFMA(af[1], bf, dw2[1][i]);
+            }
+            if (w == 0) {
+                db2[0] = MFMA(af[0], ones8, db2[0]);
+                db2[1] = MFMA(af[1], ones8, db2[1]);
+            }
+        }
+        for (int p0 = 0; p0 < L1; p0 += 2) {         // dW1[channel][kk * C + c]: wave w owns channels [16 w, 16 w + 16)
+            const int pq = p0 + half;
+            const bool ok = pq < L1;
+            const bf16x8 af = ok ? *(const bf16x8 *)(dp1T + (pq * C1 + 16 * w + r) * TS + sh) : zero8;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const bf16x8 bf = ok ? *(const bf16x8 *)(xT + (2 * pq * ge.C + 16 * nt + r) * TS + sh) : zero8;
+                dw1[nt] = MFMA(af, bf, dw1[nt]);
+            }
+            db1 = MFMA(af, ones8, db1);
+        }
+        __syncthreads();
+    }
+
+    const size_t slab = (size_t)g * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                a.part_dw2[(slab * C2 + 16 * mt + 4 * q + e) * WIN2 + 16 * (w + NW * i) + r] = dw2[mt][i][e];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) a.part_dw1[(slab * C1 + 16 * w + 4 * q + e) * 32 + 16 * nt + r] = dw1[nt][e];
+        if (r == 0) {
+            a.part_db1[slab * C1 + 16 * w + 4 * q + e] = db1[e];
+            if (w == 0) {
+                a.part_db2[slab * C2 + 4 * q + e] = db2[0][e];
+                a.part_db2[slab * C2 + 16 + 4 * q + e] = db2[1][e];
+            }
+        }
+    }
+}
+
+thread_local char g_err[256] = "";
+int fail(int code, const char *msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+
+int g_cus = 0;
+int compute_units()
+{
+    if (g_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cus = prop.multiProcessorCount;
+        if (g_cus <= 0) g_cus = 256;          // MI355X; also what a build host without a device assumes
+    }
+    return g_cus;
+}
+
+bool dims_ok(const cat_trunk_dims &d)
+{
+    return d.G > 0 && d.G <= 65535 && d.N > 0 && (d.C == 2 || d.C == 4) && d.R >= 20 && d.R <= 512 && d.R % 2 == 0;
+}
+bool aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
+int tiles_of(const cat_trunk_dims &d) { return (d.N + TS - 1) / TS; }
+int bwd_blocks(const cat_trunk_dims &d)
+{
+    const int per_net = compute_units() / d.G;          // backward: one workgroup per CU (its LDS fills the CU)
+    const int b = per_net < 1 ? 1 : per_net;
+    return b < tiles_of(d) ? b : tiles_of(d);
+}
+int fwd_blocks(const cat_trunk_dims &d)
+{
+    const int per_net = 2 * compute_units() / d.G;
+    const int b = per_net < 1 ? 1 : per_net;
+    return b < tiles_of(d) ? b : tiles_of(d);
+}
+bool params_ok(const cat_trunk_params &p)
+{
+    return p.w1 && p.b1 && p.w2 && p.b2 && aligned(p.w1, 2) && aligned(p.b1, 2) && aligned(p.w2, 2) && aligned(p.b2, 2);
+}
+
+}   // namespace
+
+extern "C" int cat_trunk_abi_version(void) { return CAT_TRUNK_ABI_VERSION; }
+extern "C" const char *cat_trunk_last_error(void) { return g_err; }
+extern "C" int cat_trunk_out_positions(const cat_trunk_dims *d) { return d && dims_ok(*d) ? Geo(*d).L2 : CAT_TRUNK_ERR_BAD_ARG; }
+extern "C" int cat_trunk_supported(const cat_trunk_dims *d)
+{
+    return d && dims_ok(*d) && Geo(*d).L2 >= 1 && Geo(*d).bwd_lds() <= (size_t)LDS_LIMIT ? 1 : 0;
+}
+extern "C" int cat_trunk_backward_blocks(const cat_trunk_dims *d) { return d && dims_ok(*d) ? bwd_blocks(*d) : CAT_TRUNK_ERR_BAD_ARG; }
+
+extern "C" int cat_trunk_forward(const cat_trunk_fwd *a, void *stream)
+{
+    if (!a || !dims_ok(a->d)) return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_forward: bad dimensions");
+    if (!cat_trunk_supported(&a->d)) return fail(CAT_TRUNK_ERR_TOO_LARGE, "cat_trunk_forward: these dimensions do not fit the LDS");
+    if (!params_ok(a->p) || !a->x || !a->out) return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_forward: a required buffer is NULL or misaligned");
+    if (!aligned(a->x, 2) || !aligned(a->out, 8) || (a->so_g % 4) || (a->so_n % 4))
+        return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_forward: misaligned buffer or stride");
+    const Geo ge(a->d);
+    const int lds = (int)ge.fwd_lds();
+    static int lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(trunk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return fail(CAT_TRUNK_ERR_HIP, "cat_trunk_forward: hipFuncSetAttribute failed");
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(trunk_fwd_kernel, dim3(fwd_blocks(a->d), a->d.G), dim3(NW * LANES), lds, (hipStream_t)stream, *a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_TRUNK_OK : fail(CAT_TRUNK_ERR_HIP, hipGetErrorString(e));
+}
+
+extern "C" int cat_trunk_backward(const cat_trunk_bwd *a, void *stream)
+{
+    if (!a || !dims_ok(a->d)) return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_backward: bad dimensions");
+    if (!cat_trunk_supported(&a->d)) return fail(CAT_TRUNK_ERR_TOO_LARGE, "cat_trunk_backward: these dimensions do not fit the LDS");
+    if (!params_ok(a->p) || !a->x || !a->out || !a->d_out || !a->part_dw1 || !a->part_db1 || !a->part_dw2 || !a->part_db2)
+        return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_backward: a required buffer is NULL or misaligned");
+    if (!aligned(a->x, 2) || !aligned(a->out, 2) || !aligned(a->d_out, 2) || !aligned(a->part_dw1, 4) || !aligned(a->part_dw2, 4))
+        return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_backward: misaligned buffer");
+    const Geo ge(a->d);
+    const int lds = (int)ge.bwd_lds();
+    static int lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(trunk_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return fail(CAT_TRUNK_ERR_HIP, "cat_trunk_backward: hipFuncSetAttribute failed");
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(trunk_bwd_kernel, dim3(bwd_blocks(a->d), a->d.G), dim3(NW * LANES), lds, (hipStream_t)stream, *a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_TRUNK_OK : fail(CAT_TRUNK_ERR_HIP, hipGetErrorString(e));
+}

@@ -9,19 +9,20 @@ accumulate into views of one flat gradient buffer, so the gradient all-reduce, t
 Adam are a handful of kernels per optimiser step whatever the number of layers.
 
 The LSTM recurrence over a BPTT window is one autograd node (``_LSTMSeq``): in bf16 on the GPU one launch of
-``libcat_lstm.so`` forward and one backward for the whole window of a layer (``csrc/cat_lstm.hip``), the weight
+``libcat_learn.so`` forward and one backward for the whole window of a layer (``csrc/cat_lstm.hip``), the weight
 gradient ONE GEMM over all steps (fp32 accumulation); in fp32 / on the CPU the same recurrence step by step.
 """
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 
-from .. import _lstm_native
+from .. import _learn_native
 from .models import LSTMPolicy, LSTMValue, conv_out_len
 
 HIDDEN = 128
@@ -67,7 +68,7 @@ class _LSTMSeq(torch.autograd.Function):
     (an episode starts at step t).  xproj [G, T, B, 4H]; w_hh [G, 4H, H]; h0, c0 [G, B, H]; keep fp32 [T, B] or None.
     Returns out [G, T, B, H], h_T, c_T.
 
-    bf16 on a GPU: the whole window is ONE launch of ``libcat_lstm.so`` per direction (``csrc/cat_lstm.hip``: W_hh
+    bf16 on a GPU: the whole window is ONE launch of ``libcat_learn.so`` per direction (``csrc/cat_lstm.hip``: W_hh
     resident in registers, the products on the matrix cores, the cell in fp32) -- no other path exists there.  fp32 /
     CPU (the parity tests, ``compute_bf16=False``): the same recurrence step by step in torch."""
 
@@ -79,7 +80,7 @@ class _LSTMSeq(torch.autograd.Function):
         ctx.set_materialize_grads(False)           # unused final-state gradients arrive as None, not as zero tensors
         ctx.native = xproj.is_cuda and xproj.dtype == torch.bfloat16
         if ctx.native:
-            out, hT, cT, (h_in, acts, cell) = _lstm_native.seq_forward(xproj, w_hh, h0, c0, keep, save=train)
+            out, hT, cT, (h_in, acts, cell) = _learn_native.seq_forward(xproj, w_hh, h0, c0, keep, save=train)
             if train:
                 ctx.save_for_backward(w_hh, h_in, acts, cell, keep if keep is not None else torch.empty(0))
                 ctx.dims = (G, T, B)
@@ -109,7 +110,7 @@ class _LSTMSeq(torch.autograd.Function):
             w_hh, h_in, acts, cell, keep = ctx.saved_tensors
             G, T, B = ctx.dims
             want_state = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
-            dg_all, dh, dc = _lstm_native.seq_backward(d_out, d_hT, d_cT, w_hh, keep if ctx.has_keep else None, acts, cell,
+            dg_all, dh, dc = _learn_native.seq_backward(d_out, d_hT, d_cT, w_hh, keep if ctx.has_keep else None, acts, cell,
                                                        ctx.dims, want_state)
         else:
             w_hh, h_in, cs, cys, wss, keep = ctx.saved_tensors
@@ -251,6 +252,33 @@ class _Expand(torch.autograd.Function):
         return ext.index_select(1, back.reshape(-1)).view(go.shape[0], ctx.n, -1).sum(-1), None, None
 
 
+class _ConvTrunk(torch.autograd.Function):
+    """Conv1d(C, 64, 5, stride 2) -> ReLU -> Conv1d(64, 32, 5, stride 3) -> ReLU of the G stacked networks, bf16 on the
+    GPU: one launch of ``libcat_learn.so`` forward and one backward (``csrc/cat_trunk.hip``); the 64-channel intermediate
+    never leaves the LDS.  x [G, N, C * R] (channel, ray); w1 [G, 64, C, 5]; b1 [G, 64]; w2 [G, 32, 64, 5]; b2 [G, 32].
+    Returns [G, N, L2 * 32] in (position, channel) order, like the dense path below."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, R):
+        out = _learn_native.trunk_forward(x, w1, b1, w2, b2, R)
+        ctx.save_for_backward(x, w1, b1, w2, b2, out)
+        ctx.R = R
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, w1, b1, w2, b2, out = ctx.saved_tensors
+        G, C = w1.shape[0], w1.shape[2]
+        parts = _learn_native.trunk_backward(x, w1, b1, w2, b2, out, go, ctx.R)
+        nb = parts[0].shape[1]
+        ones = torch.ones(G, 1, nb, dtype=torch.float32, device=go.device)
+        dw1, db1, dw2, db2 = (torch.bmm(ones, p.view(G, nb, -1)).squeeze(1) for p in parts)      # add the slabs up
+        dw1 = dw1.view(G, 64, 32)[:, :, :5 * C].reshape(G, 64, 5, C).transpose(2, 3)              # column kk * C + c
+        dw2 = dw2.view(G, 32, 5, 64).transpose(2, 3)                                             # column kk * 64 + c_in
+        dt = w1.dtype
+        return None, dw1.to(dt), db1.to(dt), dw2.to(dt), db2.to(dt), None
+
+
 def _conv_as_dense_indices(c_out: int, c_in: int, k: int, stride: int, l_in: int, in_layout: str, device):
     """Index tensors for ``_Expand``: the [l_out * c_out, l_in * c_in] matrix of Conv1d(c_in, c_out, k, stride) on an input
     flattened as (channel, position) [``in_layout`` "cl", the observation vector] or (position, channel) ["lc", the
@@ -285,6 +313,8 @@ class StackedNet:
         # the flops by ~10 -- irrelevant on the matrix cores -- and removes what the update was actually spending its
         # time on: the im2col copies of a [samples * positions, channels * taps] matrix (hundreds of MB per minibatch),
         # their unfold backward, and GEMMs with a 10..320-wide inner dimension over half a million rows.
+        # (bf16 on the GPU with R <= 64 the two convolutions are one kernel instead, ``_ConvTrunk``.)
+        self.fused_trunk = os.environ.get("CAT_DENSE_TRUNK", "0") != "1"
         self.t1 = _conv_as_dense_indices(64, self.C, 5, 2, R, "cl", dev)
         self.t2 = _conv_as_dense_indices(32, 64, 5, 3, self.L1, "lc", dev)
         assert self.t1[4] == self.L1 and self.t2[4] == self.L2
@@ -303,11 +333,15 @@ class StackedNet:
         dt = self.fp.compute_dtype
         N = T * B
         z = x.reshape(G, N, self.C * self.R).to(dt)                                              # (channel, ray) order
-        for name, (idx, back, b_idx, b_back, l_out), c_out, width in (("trunk.features.0", self.t1, 64, self.C * self.R),
-                                                                       ("trunk.features.2", self.t2, 32, self.L1 * 64)):
-            w = _Expand.apply(self.w(name + ".weight").reshape(G, -1), idx, back).view(G, l_out * c_out, width)
-            b = _Expand.apply(self.w(name + ".bias"), b_idx, b_back)
-            z = torch.relu(_lin(z, w, b))                                                        # [G, N, l_out * c_out], (l, c)
+        if self.fused_trunk and z.is_cuda and dt == torch.bfloat16 and _learn_native.trunk_supported(G, N, self.C, self.R):
+            z = _ConvTrunk.apply(z, self.w("trunk.features.0.weight"), self.w("trunk.features.0.bias"),
+                                 self.w("trunk.features.2.weight"), self.w("trunk.features.2.bias"), self.R)
+        else:   # fp32 / CPU, or a ray count whose intermediate does not fit the LDS (R = 90): dense GEMMs
+            for name, (idx, back, b_idx, b_back, l_out), c_out, width in (("trunk.features.0", self.t1, 64, self.C * self.R),
+                                                                           ("trunk.features.2", self.t2, 32, self.L1 * 64)):
+                w = _Expand.apply(self.w(name + ".weight").reshape(G, -1), idx, back).view(G, l_out * c_out, width)
+                b = _Expand.apply(self.w(name + ".bias"), b_idx, b_back)
+                z = torch.relu(_lin(z, w, b))                                                    # [G, N, l_out * c_out], (l, c)
         wfc = self.w("trunk.features.5.weight").view(G, 256, 32, self.L2).transpose(2, 3).reshape(G, 256, self.L2 * 32)
         f = torch.tanh(_lin(z, wfc, self.w("trunk.features.5.bias")))                            # [G, T*B, 256]
         h0, c0 = state

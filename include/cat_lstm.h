@@ -1,5 +1,5 @@
 /*
- * cat_lstm.h -- C ABI of libcat_lstm.so: the LSTM recurrence of the self-play learner (SURVEY.md
+ * cat_lstm.h -- C ABI of libcat_learn.so: the LSTM recurrence of the self-play learner (SURVEY.md
  * section 8(f), rank 2: the caller of the env hot path) as two MI355X (gfx950) kernels.
  *
  * Replaces, for the role-stacked networks of as_cops_and_thieves_amd/selfplay/stacked.py, what the

@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_lstm_library_exports_every_declared_symbol_and_struct_layouts_match():
-    """include/cat_lstm.h <-> libcat_lstm.so <-> the ctypes mirror (no compute call: no GPU here)."""
-    from as_cops_and_thieves_amd import _lstm_native as ln
+    """include/cat_lstm.h <-> libcat_learn.so <-> the ctypes mirror (no compute call: no GPU here)."""
+    from as_cops_and_thieves_amd import _learn_native as ln
     ln.build()
     L = ln.lib()
     text = (ROOT / "include" / "cat_lstm.h").read_text()

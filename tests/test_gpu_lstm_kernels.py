@@ -1,4 +1,4 @@
-"""GPU: the LSTM-window kernels of libcat_lstm.so (include/cat_lstm.h, csrc/cat_lstm.hip) against a plain PyTorch fp32
+"""GPU: the LSTM-window kernels of libcat_learn.so (include/cat_lstm.h, csrc/cat_lstm.hip) against a plain PyTorch fp32
 reference of the same recurrence (nn.LSTM semantics, gate order i f g o, states zeroed where keep == 0).
 
 Tolerances: operands and stored results are bf16 (8 significant bits), accumulation and the cell are fp32; the
