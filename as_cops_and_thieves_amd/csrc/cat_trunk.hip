@@ -82,18 +82,44 @@ __device__ __forceinline__ void load_w1(const cat_trunk_params &p, int g, int C,
     }
 }
 
-// input tile -> LDS in (ray, channel) order (and optionally [column][sample]); rows past N and the row tails are zero
+// input tile -> LDS in (ray, channel) order (and optionally [column][sample]).  Thread (sample s = t / 16, u = t % 16)
+// takes runs of 4 rays: one 8-byte load per channel, interleaved in registers, written as one run of 4 C elements.
+// Rows past N read as zero; the row tails (columns >= C R) are zeroed once per launch by clear_tails.
 __device__ __forceinline__ void stage_x(const __bf16 *xg, int64_t sx_n, int n0, int N, const Geo &ge, __bf16 *xs, __bf16 *xT)
 {
-    for (int e = threadIdx.x; e < TS * ge.XS; e += NW * LANES) {
-        const int s = e / ge.XS, j = e - s * ge.XS;
-        __bf16 v = (__bf16)0.0f;
-        if (j < ge.CR && n0 + s < N) {
-            const int ray = j / ge.C, c = j - ray * ge.C;
-            v = xg[(size_t)(n0 + s) * sx_n + c * ge.R + ray];
+    const int s = threadIdx.x >> 4, u = threadIdx.x & 15;
+    const bool ok = n0 + s < N;
+    const __bf16 *row = xg + (size_t)(n0 + s) * sx_n;
+    const bf16x4 z4 = narrow(f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int ch = u; ch < ge.R / 4; ch += 16) {
+        bf16x4 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (ok && c < ge.C) ? *(const bf16x4 *)(row + c * ge.R + 4 * ch) : z4;
+        __bf16 *dst = xs + s * ge.XS + 4 * ch * ge.C;
+        if (ge.C == 2) {
+            *(bf16x8 *)dst = bf16x8{v[0][0], v[1][0], v[0][1], v[1][1], v[0][2], v[1][2], v[0][3], v[1][3]};
+        } else {
+            *(bf16x8 *)dst = bf16x8{v[0][0], v[1][0], v[2][0], v[3][0], v[0][1], v[1][1], v[2][1], v[3][1]};
+            *(bf16x8 *)(dst + 8) = bf16x8{v[0][2], v[1][2], v[2][2], v[3][2], v[0][3], v[1][3], v[2][3], v[3][3]};
         }
-        xs[e] = v;
-        if (xT) xT[j * TS + s] = v;
+        if (xT) {
+            __bf16 *t = xT + (4 * ch * ge.C) * TS + s;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < ge.C) t[(i * ge.C + c) * TS] = v[c][i];
+        }
+    }
+}
+
+__device__ __forceinline__ void clear_tails(const Geo &ge, __bf16 *xs, __bf16 *xT)
+{
+    const int tail = ge.XS - ge.CR;
+    for (int e = threadIdx.x; e < TS * tail; e += NW * LANES) {
+        const int s = e / tail, j = ge.CR + e - s * tail;
+        xs[s * ge.XS + j] = (__bf16)0.0f;
+        if (xT) xT[j * TS + s] = (__bf16)0.0f;
     }
 }
 
@@ -125,6 +151,7 @@ __global__ __launch_bounds__(NW *LANES) void trunk_fwd_kernel(const cat_trunk_fw
     }
     const __bf16 *xg = (const __bf16 *)a.x + (size_t)g * a.sx_g;
     __bf16 *og = (__bf16 *)a.out + (size_t)g * a.so_g;
+    clear_tails(ge, xs, nullptr);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n0 = tile * TS;
@@ -155,7 +182,67 @@ __global__ __launch_bounds__(NW *LANES) void trunk_fwd_kernel(const cat_trunk_fw
     }
 }
 
-__global__ __launch_bounds__(NW *LANES) void trunk_bwd_kernel(const cat_trunk_bwd a)
+// ---- backward: 8 waves (two per SIMD: the workgroup's LDS fills the CU, so latency is hidden inside the workgroup) ----
+constexpr int NWB = 8;
+
+struct Raw {            // one tile's global data in flight: fetched a tile ahead, committed to LDS at the top of the loop
+    bf16x4 x[4];        // thread (sample t / 32, u = t % 32): rays 4 u .. 4 u + 3 of every channel
+    bf16x4 y[3], d[3];  // runs 4 (u + 32 i) .. of the layer's output and of its gradient
+};
+
+__device__ __forceinline__ void fetch_raw(Raw &rw, const __bf16 *xg, int64_t sx_n, const __bf16 *og, const __bf16 *dg, int64_t so_n,
+                                          int n0, int N, const Geo &ge)
+{
+    const int s = threadIdx.x >> 5, u = threadIdx.x & 31;
+    const bool ok = n0 + s < N;
+    const bf16x4 z4 = narrow(f32x4{0.f, 0.f, 0.f, 0.f});
+    const __bf16 *row = xg + (size_t)(n0 + s) * sx_n;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rw.x[c] = (ok && c < ge.C && 4 * u < ge.R) ? *(const bf16x4 *)(row + c * ge.R + 4 * u) : z4;
+    const size_t o = (size_t)(n0 + s) * so_n;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = u + 32 * i;
+        const bool in = ok && 4 * ch < ge.D2;
+        rw.y[i] = in ? *(const bf16x4 *)(og + o + 4 * ch) : z4;
+        rw.d[i] = in ? *(const bf16x4 *)(dg + o + 4 * ch) : z4;
+    }
+}
+
+__device__ __forceinline__ void commit_raw(const Raw &rw, const Geo &ge, __bf16 *xs, __bf16 *xT, __bf16 *dp2, __bf16 *dp2T)
+{
+    const int s = threadIdx.x >> 5, u = threadIdx.x & 31;
+    if (4 * u < ge.R) {
+        const bf16x4 *v = rw.x;
+        __bf16 *dst = xs + s * ge.XS + 4 * u * ge.C;
+        if (ge.C == 2) {
+            *(bf16x8 *)dst = bf16x8{v[0][0], v[1][0], v[0][1], v[1][1], v[0][2], v[1][2], v[0][3], v[1][3]};
+        } else {
+            *(bf16x8 *)dst = bf16x8{v[0][0], v[1][0], v[2][0], v[3][0], v[0][1], v[1][1], v[2][1], v[3][1]};
+            *(bf16x8 *)(dst + 8) = bf16x8{v[0][2], v[1][2], v[2][2], v[3][2], v[0][3], v[1][3], v[2][3], v[3][3]};
+        }
+        __bf16 *t = xT + (4 * u * ge.C) * TS + s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < ge.C) t[(i * ge.C + c) * TS] = v[c][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = u + 32 * i;
+        if (4 * ch < ge.D2) {                       // gradient before the second ReLU, row-major and sample-contiguous
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((float)rw.y[i][e] > 0.0f) ? rw.d[i][e] : (__bf16)0.0f;
+            *(bf16x4 *)(dp2 + s * ge.D2S + 4 * ch) = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp2T[(4 * ch + e) * TS + s] = v[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(NWB *LANES) void trunk_bwd_kernel(const cat_trunk_bwd a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Geo ge(a.d);
@@ -169,10 +256,21 @@ __global__ __launch_bounds__(NW *LANES) void trunk_bwd_kernel(const cat_trunk_bw
     const int g = blockIdx.y, N = a.d.N, ntiles = (N + TS - 1) / TS;
     const int L1 = ge.L1, L2 = ge.L2;
 
+    // The intermediate and its gradient are computed with the SAMPLES on the accumulator's rows here (operands swapped
+    // w.r.t. forward): a lane then holds four consecutive samples of one channel = one 8-byte run of the [column][sample]
+    // images the weight-gradient products read.  The bias becomes a per-lane (per-column) constant.
     bf16x8 w1f[4], w2t[KW][4];
-    f32x4 bias1[4];
-    load_w1(a.p, g, ge.C, q, r, w1f, bias1);
-    {   // A[row = ci 16 mt + r][k = out channel 8 q + j] = w2[out][ci][kk]
+    f32x4 bias1n[4];
+    {
+        f32x4 unused[4];
+        load_w1(a.p, g, ge.C, q, r, w1f, unused);
+        const __bf16 *b1 = (const __bf16 *)a.p.b1 + (size_t)g * a.p.sb1_g;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float b = (float)b1[16 * mt + r];
+            bias1n[mt] = f32x4{b, b, b, b};
+        }
+        // B[k = out channel 8 q + j][n = ci 16 mt + r] = w2[out][ci][kk]
         const __bf16 *w2 = (const __bf16 *)a.p.w2 + (size_t)g * a.p.sw2_g;
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk)
@@ -183,42 +281,33 @@ __global__ __launch_bounds__(NW *LANES) void trunk_bwd_kernel(const cat_trunk_bw
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const bf16x8 zero8 = splat8(0.0f), ones8 = splat8(1.0f);
-    f32x4 dw2[2][5], dw1[2] = {zero, zero}, db1 = zero, db2[2] = {zero, zero};
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int i = 0; i < 5; ++i) dw2[mt][i] = zero;
+    // weight-gradient tiles of this wave: dW2 row tile (w & 1), column tiles (w >> 1) + 4 i; dW1 row tile (w >> 1), column tile (w & 1)
+    const int mt2 = w & 1, ct2 = w >> 1, rt1 = w >> 1, nt1 = w & 1;
+    f32x4 dw2[5] = {zero, zero, zero, zero, zero}, dw1 = zero, db1 = zero, db2 = zero;
 
     const __bf16 *xg = (const __bf16 *)a.x + (size_t)g * a.sx_g;
     const __bf16 *og = (const __bf16 *)a.out + (size_t)g * a.so_g, *dg = (const __bf16 *)a.d_out + (size_t)g * a.so_g;
     const int sh = 8 * (q & 1), half = q >> 1;      // a K step of the weight-gradient products = 2 positions x 16 samples
+    for (int e = threadIdx.x; e < TS * (ge.XS - ge.CR); e += NWB * LANES) {      // the zero tails, once
+        const int tail = ge.XS - ge.CR, s = e / tail, j = ge.CR + e - s * tail;
+        xs[s * ge.XS + j] = (__bf16)0.0f;
+        xT[j * TS + s] = (__bf16)0.0f;
+    }
+    Raw raw;
+    fetch_raw(raw, xg, a.sx_n, og, dg, a.so_n, blockIdx.x * TS, N, ge);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int n0 = tile * TS;
-        stage_x(xg, a.sx_n, n0, N, ge, xs, xT);
-        for (int e = threadIdx.x; e < TS * ge.D2; e += NW * LANES) {
-            const int s = e / ge.D2, j = e - s * ge.D2;
-            __bf16 v = (__bf16)0.0f;
-            if (n0 + s < N) {
-                const size_t o = (size_t)(n0 + s) * a.so_n + j;
-                if ((float)og[o] > 0.0f) v = dg[o];
-            }
-            dp2[s * ge.D2S + j] = v;
-            dp2T[j * TS + s] = v;
-        }
+        commit_raw(raw, ge, xs, xT, dp2, dp2T);
+        fetch_raw(raw, xg, a.sx_n, og, dg, a.so_n, (tile + (int)gridDim.x) * TS, N, ge);      // past the end: zeros, unused
         __syncthreads();
-        for (int p = w; p < L1; p += NW) {           // the intermediate again
+        for (int p = w; p < L1; p += NWB) {          // the intermediate again: D[sample 4 q + e][channel 16 mt + r]
             const bf16x8 xb = ld8(xs + r * ge.XS + 2 * p * ge.C + 8 * q);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const bf16x4 v = narrow(relu4(MFMA(w1f[mt], xb, bias1[mt])));
-                __bf16 *dst = a1T + (p * C1 + 16 * mt + 4 * q) * TS + r;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dst[e * TS] = v[e];
-            }
+            for (int mt = 0; mt < 4; ++mt)
+                *(bf16x4 *)(a1T + (p * C1 + 16 * mt + r) * TS + 4 * q) = narrow(relu4(MFMA(xb, w1f[mt], bias1n[mt])));
         }
         __syncthreads();
-        for (int p = w; p < L1; p += NW) {           // gradient of position p: the (output position, tap) pairs covering it
+        for (int p = w; p < L1; p += NWB) {          // gradient of position p: the (output position, tap) pairs covering it
             f32x4 acc[4] = {zero, zero, zero, zero};
 #pragma unroll
             for (int kk = 0; kk < KW; ++kk) {
@@ -226,45 +315,38 @@ __global__ __launch_bounds__(NW *LANES) void trunk_bwd_kernel(const cat_trunk_bw
                 if (t >= 0 && t == 3 * l2 && l2 < L2) {
                     const bf16x8 db = *(const bf16x8 *)(dp2 + r * ge.D2S + l2 * C2 + 8 * q);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA(w2t[kk][mt], db, acc[mt]);
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA(db, w2t[kk][mt], acc[mt]);
                 }
             }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const int col = (p * C1 + 16 * mt + 4 * q) * TS + r;
-                const bf16x4 v = narrow(acc[mt]);
+                const int at = (p * C1 + 16 * mt + r) * TS + 4 * q;
+                const bf16x4 y = *(const bf16x4 *)(a1T + at);
+                bf16x4 v = narrow(acc[mt]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dp1T[col + e * TS] = ((float)a1T[col + e * TS] > 0.0f) ? v[e] : (__bf16)0.0f;
+                for (int e = 0; e < 4; ++e) v[e] = ((float)y[e] > 0.0f) ? v[e] : (__bf16)0.0f;
+                *(bf16x4 *)(dp1T + at) = v;
             }
         }
         __syncthreads();
         for (int l0 = 0; l0 < L2; l0 += 2) {         // dW2[out][window column] += sum over (sample, position)
             const int lq = l0 + half;
             const bool ok = lq < L2;
-            bf16x8 af[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) af[mt] = ok ? *(const bf16x8 *)(dp2T + (lq * C2 + 16 * mt + r) * TS + sh) : zero8;
+            const bf16x8 af = ok ? *(const bf16x8 *)(dp2T + (lq * C2 + 16 * mt2 + r) * TS + sh) : zero8;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                const bf16x8 bf = ok ? *(const bf16x8 *)(a1T + (3 * C1 * lq + 16 * (w + NW * i) + r) * TS + sh) : zero8;
-                dw2[0][i] = MFMA(af[0], bf, dw2[0][i]);
-                dw2[1][i] = MFMA(af[1], bf, dw2[1][i]);
+                const bf16x8 bf = ok ? *(const bf16x8 *)(a1T + (3 * C1 * lq + 16 * (ct2 + 4 * i) + r) * TS + sh) : zero8;
+                dw2[i] = MFMA(af, bf, dw2[i]);
             }
-            if (w == 0) {
-                db2[0] = MFMA(af[0], ones8, db2[0]);
-                db2[1] = MFMA(af[1], ones8, db2[1]);
-            }
+            if (ct2 == 0) db2 = MFMA(af, ones8, db2);
         }
-        for (int p0 = 0; p0 < L1; p0 += 2) {         // dW1[channel][kk * C + c]: wave w owns channels [16 w, 16 w + 16)
+        for (int p0 = 0; p0 < L1; p0 += 2) {         // dW1[channel][kk * C + c]
             const int pq = p0 + half;
             const bool ok = pq < L1;
-            const bf16x8 af = ok ? *(const bf16x8 *)(dp1T + (pq * C1 + 16 * w + r) * TS + sh) : zero8;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const bf16x8 bf = ok ? *(const bf16x8 *)(xT + (2 * pq * ge.C + 16 * nt + r) * TS + sh) : zero8;
-                dw1[nt] = MFMA(af, bf, dw1[nt]);
-            }
-            db1 = MFMA(af, ones8, db1);
+            const bf16x8 af = ok ? *(const bf16x8 *)(dp1T + (pq * C1 + 16 * rt1 + r) * TS + sh) : zero8;
+            const bf16x8 bf = ok ? *(const bf16x8 *)(xT + (2 * pq * ge.C + 16 * nt1 + r) * TS + sh) : zero8;
+            dw1 = MFMA(af, bf, dw1);
+            if (nt1 == 0) db1 = MFMA(af, ones8, db1);
         }
         __syncthreads();
     }
@@ -273,18 +355,11 @@ __global__ __launch_bounds__(NW *LANES) void trunk_bwd_kernel(const cat_trunk_bw
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-                a.part_dw2[(slab * C2 + 16 * mt + 4 * q + e) * WIN2 + 16 * (w + NW * i) + r] = dw2[mt][i][e];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) a.part_dw1[(slab * C1 + 16 * w + 4 * q + e) * 32 + 16 * nt + r] = dw1[nt][e];
+        for (int i = 0; i < 5; ++i) a.part_dw2[(slab * C2 + 16 * mt2 + 4 * q + e) * WIN2 + 16 * (ct2 + 4 * i) + r] = dw2[i][e];
+        a.part_dw1[(slab * C1 + 16 * rt1 + 4 * q + e) * 32 + 16 * nt1 + r] = dw1[e];
         if (r == 0) {
-            a.part_db1[slab * C1 + 16 * w + 4 * q + e] = db1[e];
-            if (w == 0) {
-                a.part_db2[slab * C2 + 4 * q + e] = db2[0][e];
-                a.part_db2[slab * C2 + 16 + 4 * q + e] = db2[1][e];
-            }
+            if (nt1 == 0) a.part_db1[slab * C1 + 16 * rt1 + 4 * q + e] = db1[e];
+            if (ct2 == 0) a.part_db2[slab * C2 + 16 * mt2 + 4 * q + e] = db2[e];
         }
     }
 }
@@ -310,7 +385,7 @@ int compute_units()
 
 bool dims_ok(const cat_trunk_dims &d)
 {
-    return d.G > 0 && d.G <= 65535 && d.N > 0 && (d.C == 2 || d.C == 4) && d.R >= 20 && d.R <= 512 && d.R % 2 == 0;
+    return d.G > 0 && d.G <= 65535 && d.N > 0 && (d.C == 2 || d.C == 4) && d.R >= 20 && d.R <= 512 && d.R % 4 == 0;
 }
 bool aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
 int tiles_of(const cat_trunk_dims &d) { return (d.N + TS - 1) / TS; }
@@ -347,7 +422,7 @@ extern "C" int cat_trunk_forward(const cat_trunk_fwd *a, void *stream)
     if (!a || !dims_ok(a->d)) return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_forward: bad dimensions");
     if (!cat_trunk_supported(&a->d)) return fail(CAT_TRUNK_ERR_TOO_LARGE, "cat_trunk_forward: these dimensions do not fit the LDS");
     if (!params_ok(a->p) || !a->x || !a->out) return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_forward: a required buffer is NULL or misaligned");
-    if (!aligned(a->x, 2) || !aligned(a->out, 8) || (a->so_g % 4) || (a->so_n % 4))
+    if (!aligned(a->x, 8) || (a->sx_g % 4) || (a->sx_n % 4) || !aligned(a->out, 8) || (a->so_g % 4) || (a->so_n % 4))
         return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_forward: misaligned buffer or stride");
     const Geo ge(a->d);
     const int lds = (int)ge.fwd_lds();
@@ -368,8 +443,9 @@ extern "C" int cat_trunk_backward(const cat_trunk_bwd *a, void *stream)
     if (!cat_trunk_supported(&a->d)) return fail(CAT_TRUNK_ERR_TOO_LARGE, "cat_trunk_backward: these dimensions do not fit the LDS");
     if (!params_ok(a->p) || !a->x || !a->out || !a->d_out || !a->part_dw1 || !a->part_db1 || !a->part_dw2 || !a->part_db2)
         return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_backward: a required buffer is NULL or misaligned");
-    if (!aligned(a->x, 2) || !aligned(a->out, 2) || !aligned(a->d_out, 2) || !aligned(a->part_dw1, 4) || !aligned(a->part_dw2, 4))
-        return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_backward: misaligned buffer");
+    if (!aligned(a->x, 8) || (a->sx_g % 4) || (a->sx_n % 4) || !aligned(a->out, 8) || !aligned(a->d_out, 8) || (a->so_g % 4) ||
+        (a->so_n % 4) || !aligned(a->part_dw1, 4) || !aligned(a->part_dw2, 4))
+        return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_backward: misaligned buffer or stride");
     const Geo ge(a->d);
     const int lds = (int)ge.bwd_lds();
     static int lds_set = 0;
@@ -378,7 +454,7 @@ extern "C" int cat_trunk_backward(const cat_trunk_bwd *a, void *stream)
             return fail(CAT_TRUNK_ERR_HIP, "cat_trunk_backward: hipFuncSetAttribute failed");
         lds_set = lds;
     }
-    hipLaunchKernelGGL(trunk_bwd_kernel, dim3(bwd_blocks(a->d), a->d.G), dim3(NW * LANES), lds, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(trunk_bwd_kernel, dim3(bwd_blocks(a->d), a->d.G), dim3(NWB * LANES), lds, (hipStream_t)stream, *a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAT_TRUNK_OK : fail(CAT_TRUNK_ERR_HIP, hipGetErrorString(e));
 }

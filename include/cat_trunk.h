@@ -33,7 +33,7 @@ typedef struct cat_trunk_dims {
     int32_t G;      /* stacked networks */
     int32_t N;      /* samples per network */
     int32_t C;      /* input channels: 2 or 4 */
-    int32_t R;      /* rays (input positions), R % 2 == 0 */
+    int32_t R;      /* rays (input positions), R % 4 == 0 */
 } cat_trunk_dims;
 
 /* L1 = (R - 5) / 2 + 1 positions after the first convolution, L2 = (L1 - 5) / 3 + 1 after the second. */
