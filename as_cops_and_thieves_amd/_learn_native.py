@@ -11,8 +11,8 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 LIB_PATH = PKG / "libcat_learn.so"
-SOURCES = (PKG / "csrc" / "cat_lstm.hip", PKG / "csrc" / "cat_trunk.hip")
-HEADERS = (ROOT / "include" / "cat_lstm.h", ROOT / "include" / "cat_trunk.h")
+SOURCES = (PKG / "csrc" / "cat_lstm.hip", PKG / "csrc" / "cat_trunk.hip", PKG / "csrc" / "cat_ppo.hip")
+HEADERS = (ROOT / "include" / "cat_lstm.h", ROOT / "include" / "cat_trunk.h", ROOT / "include" / "cat_ppo.h")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared"]
 HIDDEN = 128
 EXPORTED_SYMBOLS = ("cat_lstm_abi_version", "cat_lstm_last_error", "cat_lstm_saved_acts_bytes", "cat_lstm_saved_cell_bytes",
@@ -59,6 +59,26 @@ class TrunkBwd(C.Structure):
     _fields_ = [("d", TrunkDims), ("p", TrunkParams), ("x", C.c_void_p), ("sx_g", C.c_int64), ("sx_n", C.c_int64),
                 ("out", C.c_void_p), ("d_out", C.c_void_p), ("so_g", C.c_int64), ("so_n", C.c_int64),
                 ("part_dw1", C.c_void_p), ("part_db1", C.c_void_p), ("part_dw2", C.c_void_p), ("part_db2", C.c_void_p)]
+
+
+PPO_SYMBOLS = ("cat_ppo_abi_version", "cat_ppo_last_error", "cat_ppo_loss_grad", "cat_ppo_adam_step")
+
+
+class PpoLoss(C.Structure):
+    _fields_ = [("G", C.c_int32), ("M", C.c_int32), ("chunks", C.c_int32), ("pad", C.c_int32),
+                ("logits", C.c_void_p), ("values", C.c_void_p), ("actions", C.c_void_p),
+                ("old_logp", C.c_void_p), ("adv", C.c_void_p), ("ret", C.c_void_p),
+                ("ratio_clip", C.c_float), ("value_scale", C.c_float), ("entropy_scale", C.c_float), ("pad2", C.c_float),
+                ("d_logits", C.c_void_p), ("d_values", C.c_void_p), ("partial", C.c_void_p)]
+
+
+class PpoAdam(C.Structure):
+    _fields_ = [("G", C.c_int32), ("P", C.c_int32), ("chunks", C.c_int32), ("pad", C.c_int32),
+                ("ar", C.c_void_p), ("col_train", C.c_void_p), ("epoch_active", C.c_void_p),
+                ("m", C.c_void_p), ("v", C.c_void_p), ("steps", C.c_void_p), ("master", C.c_void_p), ("lp", C.c_void_p),
+                ("kl_out", C.c_void_p), ("norm_partial", C.c_void_p),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("grad_norm_clip", C.c_float), ("kl_threshold", C.c_float)]
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -111,13 +131,20 @@ def lib() -> C.CDLL:
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
         assert L.cat_trunk_abi_version() == 1
+        L.cat_ppo_abi_version.restype = C.c_int
+        L.cat_ppo_last_error.restype = C.c_char_p
+        for n in ("cat_ppo_loss_grad", "cat_ppo_adam_step"):
+            getattr(L, n).restype = C.c_int
+            getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
+        assert L.cat_ppo_abi_version() == 1
         _lib = L
     return _lib
 
 
 def _check(rc: int, what: str) -> None:
     if rc != 0:
-        err = lib().cat_trunk_last_error() if "trunk" in what else lib().cat_lstm_last_error()
+        err = (lib().cat_trunk_last_error() if "trunk" in what else lib().cat_ppo_last_error() if "ppo" in what
+               else lib().cat_lstm_last_error())
         raise RuntimeError(f"{what} failed ({rc}): {err.decode()}")
 
 
@@ -232,3 +259,41 @@ def trunk_backward(x, w1, b1, w2, b2, out, d_out, R: int):
                  out.stride(0), out.stride(1), pw1.data_ptr(), pb1.data_ptr(), pw2.data_ptr(), pb2.data_ptr())
     _check(lib().cat_trunk_backward(C.byref(a), _stream()), "cat_trunk_backward")
     return pw1, pb1, pw2, pb2
+
+
+# ---------------------------------------------------------------------------------------------- PPO loss / optimiser step
+PPO_CHUNKS = 64
+
+
+def ppo_loss_grad(logits, values, actions, old_logp, adv, ret, ratio_clip: float, value_scale: float, entropy_scale: float):
+    """logits bf16 [G, ..., 4], values bf16 [G, ...(, 1)], actions int64 / old_logp / adv / ret fp32 [G, ...] (M samples per
+    agent each, contiguous).  Returns (sums fp32 [G, 4] = surrogate, squared value error, entropy, KL; d_logits; d_values)."""
+    import torch
+    G = logits.shape[0]
+    M = logits[0].numel() // 4
+    for t, dt in ((logits, torch.bfloat16), (values, torch.bfloat16), (actions, torch.int64), (old_logp, torch.float32),
+                  (adv, torch.float32), (ret, torch.float32)):
+        assert t.dtype == dt and t.is_contiguous() and t.shape[0] == G
+    assert values[0].numel() == M and actions[0].numel() == M and old_logp[0].numel() == M and adv[0].numel() == M and ret[0].numel() == M
+    d_logits, d_values = torch.empty_like(logits), torch.empty_like(values)
+    partial = torch.empty(G, PPO_CHUNKS, 4, dtype=torch.float32, device=logits.device)
+    a = PpoLoss(G, M, PPO_CHUNKS, 0, logits.data_ptr(), values.data_ptr(), actions.data_ptr(), old_logp.data_ptr(), adv.data_ptr(),
+                ret.data_ptr(), ratio_clip, value_scale, entropy_scale, 0.0, d_logits.data_ptr(), d_values.data_ptr(), partial.data_ptr())
+    _check(lib().cat_ppo_loss_grad(C.byref(a), _stream()), "cat_ppo_loss_grad")
+    ones = torch.ones(G, 1, PPO_CHUNKS, dtype=torch.float32, device=logits.device)
+    return torch.bmm(ones, partial).squeeze(1), d_logits, d_values
+
+
+def ppo_adam_step(ar, col_train, epoch_active, m, v, steps, master, lp, kl_out, scratch, lr, beta1, beta2, eps, grad_norm_clip,
+                  kl_threshold) -> None:
+    """In-place optimiser step on the flat [G, P] buffers (see include/cat_ppo.h); ``lp`` = bf16 copy or None;
+    ``scratch`` fp32 [G, 256]."""
+    import torch
+    G, P = master.shape
+    for t in (ar, col_train, epoch_active, m, v, steps, master, kl_out, scratch):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert ar.shape == (G, P + 1) and col_train.shape == (G, P) and scratch.shape == (G, 256) and kl_out.shape == (G,)
+    assert lp is None or (lp.dtype == torch.bfloat16 and lp.is_contiguous() and lp.shape == (G, P))
+    a = PpoAdam(G, P, 256, 0, ar.data_ptr(), col_train.data_ptr(), epoch_active.data_ptr(), m.data_ptr(), v.data_ptr(), steps.data_ptr(),
+                master.data_ptr(), _ptr(lp), kl_out.data_ptr(), scratch.data_ptr(), lr, beta1, beta2, eps, grad_norm_clip, kl_threshold or 0.0)
+    _check(lib().cat_ppo_adam_step(C.byref(a), _stream()), "cat_ppo_adam_step")

@@ -32,6 +32,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from .. import packing
+from .. import _learn_native
 from .stacked import (FlatParams, StackedNet, agent_state_dict, init_from_modules, load_agent_state_dict,
                       role_param_shapes)
 
@@ -122,6 +123,21 @@ def _sample(logp_all: torch.Tensor) -> torch.Tensor:
     return (u >= cdf).sum(dim=-1)
 
 
+class _GradsOf(torch.autograd.Function):
+    """A scalar whose gradient w.r.t. (logits, values) is the given pair: hooks the analytically computed gradient of
+    the PPO loss (``cat_ppo_loss_grad``) into the autograd graph of the networks."""
+
+    @staticmethod
+    def forward(ctx, logits, values, d_logits, d_values):
+        ctx.save_for_backward(d_logits, d_values)
+        return logits.new_zeros(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d_logits, d_values = ctx.saved_tensors
+        return d_logits, d_values, None, None
+
+
 def _dist_ready() -> bool:
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -156,6 +172,8 @@ class RoleLearner:
         self.epoch_active = torch.ones(G, **f32)               # KL early stop: 0 = skip the rest of this epoch
         self.ar = torch.zeros(G, P + 1, **f32)                 # all-reduce buffer: fp32 gradients | KL
         self.stat = torch.zeros(3, G, **f32)                   # last policy loss, value loss, KL per agent
+        self._norm_scratch = torch.zeros(G, 256, **f32)
+        self.native = self.device.type == "cuda" and compute_dtype == torch.bfloat16   # libcat_learn.so loss kernel
         W, S = self.W, self.W * N
         B = S // cfg.mini_batches
         self.B = B
@@ -208,19 +226,26 @@ class RoleLearner:
         st = lambda s: s.index_select(2, idx)
         logits, _ = self.policy.forward(sel(b["pin"]), (st(self.p0[0]), st(self.p0[1])), keep)
         values, _ = self.value.forward(sel(b["vin"]), (st(self.v0[0]), st(self.v0[1])), keep)
-        logp_all = torch.log_softmax(logits.float(), dim=-1)                            # [G, T, B, 4]
-        logp = logp_all.gather(-1, sel(b["act"]).unsqueeze(-1)).squeeze(-1)
-        old = sel(b["logp"])
-        ratio = torch.exp(logp - old)
-        M = float(logp.shape[1] * logp.shape[2])                                         # samples per agent in the minibatch
-        with torch.no_grad():
-            kl = _rowsum((ratio - 1) - (logp - old)) / M                                # [G]
-        adv = sel(b["adv"])
-        surr = torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.ratio_clip, 1 + cfg.ratio_clip))
-        policy_loss = -_rowsum(surr) / M
-        entropy = -_rowsum((logp_all.exp() * logp_all).sum(-1)) / M
-        value_loss = cfg.value_loss_scale * _rowsum((values.float().squeeze(-1) - sel(b["ret"])) ** 2) / M
-        (policy_loss - cfg.entropy_loss_scale * entropy + value_loss).sum().backward()   # agents share no parameter
+        M = float(logits.shape[1] * logits.shape[2])                                     # samples per agent in the minibatch
+        if self.native:   # loss, statistics and d loss / d (logits, values) in one launch (csrc/cat_ppo.hip)
+            sums, d_logits, d_values = _learn_native.ppo_loss_grad(
+                logits, values, sel(b["act"]), sel(b["logp"]), sel(b["adv"]), sel(b["ret"]), cfg.ratio_clip, cfg.value_loss_scale,
+                cfg.entropy_loss_scale)
+            policy_loss, value_loss, kl = -sums[:, 0] / M, cfg.value_loss_scale * sums[:, 1] / M, sums[:, 3] / M
+            _GradsOf.apply(logits, values, d_logits, d_values).backward()
+        else:
+            logp_all = torch.log_softmax(logits.float(), dim=-1)                        # [G, T, B, 4]
+            logp = logp_all.gather(-1, sel(b["act"]).unsqueeze(-1)).squeeze(-1)
+            old = sel(b["logp"])
+            ratio = torch.exp(logp - old)
+            with torch.no_grad():
+                kl = _rowsum((ratio - 1) - (logp - old)) / M                            # [G]
+            adv = sel(b["adv"])
+            surr = torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.ratio_clip, 1 + cfg.ratio_clip))
+            policy_loss = -_rowsum(surr) / M
+            entropy = -_rowsum((logp_all.exp() * logp_all).sum(-1)) / M
+            value_loss = cfg.value_loss_scale * _rowsum((values.float().squeeze(-1) - sel(b["ret"])) ** 2) / M
+            (policy_loss - cfg.entropy_loss_scale * entropy + value_loss).sum().backward()   # agents share no parameter
         with torch.no_grad():
             self.ar[:, :-1].copy_(self.fp.grad)
             self.ar[:, -1].copy_(kl)
@@ -230,6 +255,11 @@ class RoleLearner:
     def _step_apply(self) -> None:
         """KL gate, joint policy+value gradient-norm clip per agent, masked Adam, refresh of the compute copy."""
         cfg = self.cfg
+        if self.device.type == "cuda":   # the same step in two launches (csrc/cat_ppo.hip)
+            _learn_native.ppo_adam_step(self.ar, self.col_train, self.epoch_active, self.m, self.v, self.steps, self.fp.master,
+                                        None if self.fp.lp is self.fp.master else self.fp.lp, self.stat[2], self._norm_scratch,
+                                        cfg.learning_rate, self.BETA1, self.BETA2, self.EPS, cfg.grad_norm_clip, cfg.kl_threshold)
+            return
         kl = self.ar[:, -1]
         self.stat[2].copy_(kl)
         if cfg.kl_threshold:

@@ -1,0 +1,80 @@
+"""GPU: the PPO loss/gradient kernel and the optimiser-step kernels of libcat_learn.so (include/cat_ppo.h) against the plain
+PyTorch fp32 formulation the CPU path of ``selfplay/mappo.py`` uses (autograd for the gradients).
+
+Tolerances: the loss kernel reads bf16 logits/values, computes in fp32 and stores bf16 gradients: sums within 1e-4
+relative, gradients within bf16 rounding (2^-8 relative + 1e-9).  The optimiser step is fp32 throughout: 2e-6 relative on
+the weights' CHANGE."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_loss_sums_and_gradients_match_autograd_in_fp32():
+    import torch
+    from as_cops_and_thieves_amd import _learn_native as ln
+    G, T, B = 3, 16, 1000
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    logits = (2.0 * torch.randn(G, T, B, 4, generator=gen, device="cuda")).to(torch.bfloat16)
+    values = torch.randn(G, T, B, 1, generator=gen, device="cuda").to(torch.bfloat16)
+    act = torch.randint(0, 4, (G, T, B), generator=gen, device="cuda")
+    ret = torch.randn(G, T, B, generator=gen, device="cuda")
+    adv = torch.randn(G, T, B, generator=gen, device="cuda")
+    lf = logits.float().requires_grad_(True)
+    vf = values.float().requires_grad_(True)
+    logp_all = torch.log_softmax(lf, dim=-1)
+    logp = logp_all.gather(-1, act.unsqueeze(-1)).squeeze(-1)
+    old = (logp + 0.25 * torch.randn(G, T, B, generator=gen, device="cuda")).detach()     # ratios on both sides of the clip range
+    clip, vls, ent_scale, M = 0.15, 0.5, 0.02, float(T * B)
+    ratio = torch.exp(logp - old)
+    surr = torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - clip, 1 + clip))
+    entropy = -(logp_all.exp() * logp_all).sum(-1)
+    sq = (vf.squeeze(-1) - ret) ** 2
+    want = torch.stack([surr.sum((1, 2)), sq.sum((1, 2)), entropy.sum((1, 2)), ((ratio - 1) - (logp - old)).sum((1, 2))], 1)
+    ((-surr.sum((1, 2)) - ent_scale * entropy.sum((1, 2)) + vls * sq.sum((1, 2))) / M).sum().backward()
+    sums, d_logits, d_values = ln.ppo_loss_grad(logits, values, act, old, adv, ret, clip, vls, ent_scale)
+    torch.cuda.synchronize()
+    assert torch.allclose(sums, want.detach(), rtol=1e-4, atol=1e-2), (sums, want)
+    assert float(((ratio < 1 - clip) | (ratio > 1 + clip)).float().mean()) > 0.2        # the clipped branches were exercised
+    for got, ref in ((d_logits, lf.grad), (d_values, vf.grad)):
+        assert torch.allclose(got.float(), ref, rtol=2 ** -7, atol=1e-9), float((got.float() - ref).abs().max())
+
+
+def test_optimiser_step_matches_the_torch_formulation():
+    """Several steps with frozen columns, a KL gate that closes for one agent, and the norm clip active."""
+    import torch
+    from as_cops_and_thieves_amd import _learn_native as ln
+    G, P = 3, 70001
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    f = dict(device="cuda", dtype=torch.float32)
+    master = torch.randn(G, P, generator=gen, **f)
+    start = master.clone()
+    col = (torch.rand(G, P, generator=gen, **f) > 0.3).float()
+    state = {k: torch.zeros(G, P, **f) for k in ("m", "v", "steps")}
+    ref = {k: torch.zeros(G, P, **f) for k in ("m", "v", "steps")}
+    ref_master, active, ref_active = master.clone(), torch.ones(G, **f), torch.ones(G, **f)
+    lp = torch.zeros(G, P, device="cuda", dtype=torch.bfloat16)
+    kl_out, scratch = torch.zeros(G, **f), torch.zeros(G, 256, **f)
+    lr, b1, b2, eps, clip, thr = 1e-3, 0.9, 0.999, 1e-8, 0.5, 0.015
+    for step in range(4):
+        ar = torch.randn(G, P + 1, generator=gen, **f) * (0.001 if step == 2 else 1.0)       # step 2: norm below the clip
+        ar[:, -1] = torch.tensor([0.001, 0.02 if step == 1 else 0.002, 0.003], **f)           # agent 1 trips the KL gate at step 1
+        ln.ppo_adam_step(ar, col, active, state["m"], state["v"], state["steps"], master, lp, kl_out, scratch, lr, b1, b2, eps, clip, thr)
+        kl = ar[:, -1]
+        ref_active.mul_((kl <= thr).float())
+        g = ar[:, :-1] * col
+        norm = g.double().pow(2).sum(1).sqrt().float().unsqueeze(1)
+        g = g * torch.clamp(clip / (norm + 1e-6), max=1.0)
+        gate = ref_active.unsqueeze(1) * col
+        ref["steps"].add_(gate)
+        ref["m"].add_(gate * (1 - b1) * (g - ref["m"]))
+        ref["v"].add_(gate * (1 - b2) * (g * g - ref["v"]))
+        s = ref["steps"].clamp_min(1.0)
+        ref_master.sub_(gate * lr * (ref["m"] / (1 - b1 ** s)) / ((ref["v"] / (1 - b2 ** s)).sqrt() + eps))
+        torch.cuda.synchronize()
+        assert torch.equal(active, ref_active) and torch.equal(kl_out, kl)
+        assert torch.equal(state["steps"], ref["steps"])
+        moved = float((ref_master - start).abs().max())
+        assert float((master - ref_master).abs().max()) <= 2e-6 * moved + 1e-6, step      # + a few fp32 ulps of the O(1) weights
+        assert torch.equal(lp, master.to(torch.bfloat16))
+    assert float(ref_active[1]) == 0.0 and float(ref_active[0]) == 1.0
+    assert torch.equal(master[col == 0], start[col == 0])                                   # frozen columns never move

@@ -3,7 +3,8 @@
 the stacked policies and critics per tick, one HIP graph) and the PPO update (HIP-graph minibatch steps) -- beside the
 bare env rate of bench.py.  Usage: python tools/train_throughput.py [envs] [rollouts] [map] [horizon]"""
 import sys, time, faulthandler
-faulthandler.dump_traceback_later(100, exit=True)    # a hang shows where
+import os
+faulthandler.dump_traceback_later(int(os.environ.get("CAT_WATCHDOG_S", "100")), exit=True)    # a hang shows where
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
