@@ -11,11 +11,11 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 LIB_PATH = PKG / "libcat_learn.so"
-SOURCES = (PKG / "csrc" / "cat_lstm.hip", PKG / "csrc" / "cat_trunk.hip", PKG / "csrc" / "cat_ppo.hip")
-HEADERS = (ROOT / "include" / "cat_lstm.h", ROOT / "include" / "cat_trunk.h", ROOT / "include" / "cat_ppo.h")
+SOURCES = tuple(PKG / "csrc" / f"cat_{n}.hip" for n in ("lstm", "trunk", "ppo", "dense"))
+HEADERS = tuple(ROOT / "include" / f"cat_{n}.h" for n in ("lstm", "trunk", "ppo", "dense"))
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared"]
 HIDDEN = 128
-EXPORTED_SYMBOLS = ("cat_lstm_abi_version", "cat_lstm_last_error", "cat_lstm_saved_acts_bytes", "cat_lstm_saved_cell_bytes",
+EXPORTED_SYMBOLS = ("cat_lstm_abi_version", "cat_lstm_last_error", "cat_lstm_blocks", "cat_lstm_saved_acts_bytes", "cat_lstm_saved_cell_bytes",
                     "cat_lstm_seq_forward", "cat_lstm_seq_backward")
 TRUNK_SYMBOLS = ("cat_trunk_abi_version", "cat_trunk_last_error", "cat_trunk_out_positions", "cat_trunk_supported",
                  "cat_trunk_backward_blocks", "cat_trunk_forward", "cat_trunk_backward")
@@ -27,7 +27,7 @@ class Dims(C.Structure):
 
 class FwdArgs(C.Structure):
     _fields_ = [("d", Dims), ("xproj", C.c_void_p), ("sx_g", C.c_int64), ("sx_t", C.c_int64), ("sx_b", C.c_int64),
-                ("w_hh", C.c_void_p), ("sw_g", C.c_int64), ("h0", C.c_void_p), ("c0", C.c_void_p), ("keep", C.c_void_p),
+                ("bias", C.c_void_p), ("sb_g", C.c_int64), ("w_hh", C.c_void_p), ("sw_g", C.c_int64), ("h0", C.c_void_p), ("c0", C.c_void_p), ("keep", C.c_void_p),
                 ("out", C.c_void_p), ("so_g", C.c_int64), ("so_t", C.c_int64), ("so_b", C.c_int64),
                 ("h_last", C.c_void_p), ("c_last", C.c_void_p), ("h_in", C.c_void_p), ("saved_acts", C.c_void_p),
                 ("saved_cell", C.c_void_p)]
@@ -38,7 +38,7 @@ class BwdArgs(C.Structure):
                 ("d_h_last", C.c_void_p), ("d_c_last", C.c_void_p), ("w_hh", C.c_void_p), ("sw_g", C.c_int64),
                 ("keep", C.c_void_p), ("saved_acts", C.c_void_p), ("saved_cell", C.c_void_p),
                 ("d_xproj", C.c_void_p), ("sx_g", C.c_int64), ("sx_t", C.c_int64), ("sx_b", C.c_int64),
-                ("d_h0", C.c_void_p), ("d_c0", C.c_void_p)]
+                ("d_h0", C.c_void_p), ("d_c0", C.c_void_p), ("part_dbias", C.c_void_p)]
 
 
 class TrunkDims(C.Structure):
@@ -61,6 +61,7 @@ class TrunkBwd(C.Structure):
                 ("part_dw1", C.c_void_p), ("part_db1", C.c_void_p), ("part_dw2", C.c_void_p), ("part_db2", C.c_void_p)]
 
 
+DENSE_SYMBOLS = ("cat_dense_abi_version", "cat_dense_last_error", "cat_dense_bias_act", "cat_dense_act_grad")
 PPO_SYMBOLS = ("cat_ppo_abi_version", "cat_ppo_last_error", "cat_ppo_loss_grad", "cat_ppo_adam_step")
 
 
@@ -115,6 +116,8 @@ def lib() -> C.CDLL:
         L = C.CDLL(str(LIB_PATH))
         L.cat_lstm_abi_version.restype = C.c_int
         L.cat_lstm_last_error.restype = C.c_char_p
+        L.cat_lstm_blocks.restype = C.c_int
+        L.cat_lstm_blocks.argtypes = [C.c_void_p]
         for n in ("cat_lstm_saved_acts_bytes", "cat_lstm_saved_cell_bytes"):
             getattr(L, n).restype = C.c_size_t
             getattr(L, n).argtypes = [C.c_void_p]
@@ -137,6 +140,13 @@ def lib() -> C.CDLL:
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
         assert L.cat_ppo_abi_version() == 1
+        L.cat_dense_abi_version.restype = C.c_int
+        L.cat_dense_last_error.restype = C.c_char_p
+        L.cat_dense_bias_act.restype = C.c_int
+        L.cat_dense_bias_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.cat_dense_act_grad.restype = C.c_int
+        L.cat_dense_act_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        assert L.cat_dense_abi_version() == 1
         _lib = L
     return _lib
 
@@ -144,7 +154,7 @@ def lib() -> C.CDLL:
 def _check(rc: int, what: str) -> None:
     if rc != 0:
         err = (lib().cat_trunk_last_error() if "trunk" in what else lib().cat_ppo_last_error() if "ppo" in what
-               else lib().cat_lstm_last_error())
+               else lib().cat_dense_last_error() if "dense" in what else lib().cat_lstm_last_error())
         raise RuntimeError(f"{what} failed ({rc}): {err.decode()}")
 
 
@@ -162,9 +172,9 @@ def saved_sizes(G: int, T: int, B: int):
     return lib().cat_lstm_saved_acts_bytes(C.byref(d)), lib().cat_lstm_saved_cell_bytes(C.byref(d))
 
 
-def seq_forward(xproj, w_hh, h0, c0, keep, save: bool):
-    """xproj bf16 [G, T, B, 4H] (any outer strides), w_hh bf16 [G, 4H, H] (rows contiguous), h0/c0 bf16 [G, B, H],
-    keep fp32 [T, B] or None.  Returns out [G, T, B, H], h_T, c_T and, with ``save``, (h_in, acts, cell) for backward."""
+def seq_forward(xproj, w_hh, bias, h0, c0, keep, save: bool):
+    """xproj bf16 [G, T, B, 4H] (any outer strides), w_hh bf16 [G, 4H, H] (rows contiguous), bias bf16 [G, 4H] or None,
+    h0/c0 bf16 [G, B, H], keep fp32 [T, B] or None.  Returns out [G, T, B, H], h_T, c_T and, with ``save``, (h_in, acts, cell) for backward."""
     import torch
     G, T, B, H4 = xproj.shape
     assert H4 == 4 * HIDDEN and xproj.dtype == torch.bfloat16 and xproj.stride(3) == 1
@@ -182,16 +192,19 @@ def seq_forward(xproj, w_hh, h0, c0, keep, save: bool):
         h_in = torch.empty(G, T, B, HIDDEN, dtype=torch.bfloat16, device=dev)
         acts = torch.empty(na, dtype=torch.uint8, device=dev)
         cell = torch.empty(nc, dtype=torch.uint8, device=dev)
+    if bias is not None:
+        assert bias.shape == (G, H4) and bias.dtype == torch.bfloat16 and bias.stride(1) == 1
     a = FwdArgs(Dims(G, T, B, 0), xproj.data_ptr(), xproj.stride(0), xproj.stride(1), xproj.stride(2),
-                w_hh.data_ptr(), w_hh.stride(0), h0.data_ptr(), c0.data_ptr(), _ptr(keep),
+                _ptr(bias), 0 if bias is None else bias.stride(0), w_hh.data_ptr(), w_hh.stride(0), h0.data_ptr(), c0.data_ptr(), _ptr(keep),
                 out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), hT.data_ptr(), cT.data_ptr(),
                 _ptr(h_in), _ptr(acts), _ptr(cell))
     _check(lib().cat_lstm_seq_forward(C.byref(a), _stream()), "cat_lstm_seq_forward")
     return out, hT, cT, (h_in, acts, cell)
 
 
-def seq_backward(d_out, d_hT, d_cT, w_hh, keep, acts, cell, dims, want_state_grads: bool):
-    """Gradients of seq_forward: d_xproj [G, T, B, 4H] and, if wanted, d_h0 / d_c0."""
+def seq_backward(d_out, d_hT, d_cT, w_hh, keep, acts, cell, dims, want_state_grads: bool, want_bias_grad: bool = False):
+    """Gradients of seq_forward: d_xproj [G, T, B, 4H], if wanted d_h0 / d_c0, and if wanted the per-workgroup partial sums
+    [G, blocks, 4H] of the bias gradient."""
     import torch
     G, T, B = dims
     dev = w_hh.device
@@ -204,12 +217,16 @@ def seq_backward(d_out, d_hT, d_cT, w_hh, keep, acts, cell, dims, want_state_gra
     d_x = torch.empty(G, T, B, 4 * HIDDEN, dtype=torch.bfloat16, device=dev)
     d_h0 = torch.empty(G, B, HIDDEN, dtype=torch.bfloat16, device=dev) if want_state_grads else None
     d_c0 = torch.empty(G, B, HIDDEN, dtype=torch.bfloat16, device=dev) if want_state_grads else None
+    part = None
+    if want_bias_grad:
+        dd = Dims(G, T, B, 0)
+        part = torch.empty(G, lib().cat_lstm_blocks(C.byref(dd)), 4 * HIDDEN, dtype=torch.float32, device=dev)
     so = (0, 0, 0) if d_out is None else d_out.stride()[:3]
     a = BwdArgs(Dims(G, T, B, 0), _ptr(d_out), so[0], so[1], so[2], _ptr(d_hT), _ptr(d_cT), w_hh.data_ptr(), w_hh.stride(0),
                 _ptr(keep), acts.data_ptr(), cell.data_ptr(), d_x.data_ptr(), d_x.stride(0), d_x.stride(1), d_x.stride(2),
-                _ptr(d_h0), _ptr(d_c0))
+                _ptr(d_h0), _ptr(d_c0), _ptr(part))
     _check(lib().cat_lstm_seq_backward(C.byref(a), _stream()), "cat_lstm_seq_backward")
-    return d_x, d_h0, d_c0
+    return d_x, d_h0, d_c0, part
 
 
 # ---------------------------------------------------------------------------------------------- convolutional trunk
@@ -297,3 +314,38 @@ def ppo_adam_step(ar, col_train, epoch_active, m, v, steps, master, lp, kl_out, 
     a = PpoAdam(G, P, 256, 0, ar.data_ptr(), col_train.data_ptr(), epoch_active.data_ptr(), m.data_ptr(), v.data_ptr(), steps.data_ptr(),
                 master.data_ptr(), _ptr(lp), kl_out.data_ptr(), scratch.data_ptr(), lr, beta1, beta2, eps, grad_norm_clip, kl_threshold or 0.0)
     _check(lib().cat_ppo_adam_step(C.byref(a), _stream()), "cat_ppo_adam_step")
+
+
+# ---------------------------------------------------------------------------------------------- dense-layer epilogues
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+DENSE_CHUNKS = 64
+
+
+class DenseDims(C.Structure):
+    _fields_ = [("G", C.c_int32), ("M", C.c_int32), ("out", C.c_int32), ("act", C.c_int32)]
+
+
+def dense_bias_act_(y, bias, act: int):
+    """y bf16 [G, M, out] contiguous <- act(y + bias[g]) in place; bias bf16 [G, out] (row stride free)."""
+    import torch
+    G, M, out = y.shape
+    assert y.dtype == torch.bfloat16 and y.is_contiguous() and bias.shape == (G, out) and bias.dtype == torch.bfloat16 and bias.stride(1) == 1
+    d = DenseDims(G, M, out, act)
+    _check(lib().cat_dense_bias_act(C.byref(d), y.data_ptr(), bias.data_ptr(), bias.stride(0), _stream()), "cat_dense_bias_act")
+    return y
+
+
+def dense_act_grad(d_y, y, act: int):
+    """(d_y * act'(y), fp32 column sums [G, out] of it).  With ACT_NONE the first result is d_y itself."""
+    import torch
+    G, M, out = d_y.shape
+    d_y = d_y.contiguous()
+    assert d_y.dtype == torch.bfloat16 and (act == ACT_NONE or (y.shape == d_y.shape and y.is_contiguous()))
+    g_out = torch.empty_like(d_y) if act != ACT_NONE else None
+    chunks = max(1, min(DENSE_CHUNKS, M // 64))
+    partial = torch.empty(G, chunks, out, dtype=torch.float32, device=d_y.device)
+    d = DenseDims(G, M, out, act)
+    _check(lib().cat_dense_act_grad(C.byref(d), d_y.data_ptr(), _ptr(y) if act != ACT_NONE else 0, _ptr(g_out), partial.data_ptr(), chunks,
+                                    _stream()), "cat_dense_act_grad")
+    ones = torch.ones(G, 1, chunks, dtype=torch.float32, device=d_y.device)
+    return (g_out if g_out is not None else d_y), torch.bmm(ones, partial).squeeze(1)

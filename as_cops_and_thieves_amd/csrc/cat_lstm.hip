@@ -74,6 +74,13 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_fwd_kernel(const cat_lstm_
     const size_t state_row = ((size_t)g * B + b) * H;
     const bool save = a.saved_acts != nullptr;
 
+    f32x4 bias[4][2];
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            bias[gt][hh] = a.bias ? widen(*(const bf16x4 *)((const __bf16 *)a.bias + (size_t)g * a.sb_g + gt * H + hid0 + 16 * hh))
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 c[2];
     {
         const float k0 = (a.keep && row_ok) ? a.keep[b] : 1.0f;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_fwd_kernel(const cat_lstm_
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
-                acc[gt][hh] = widen(row_ok ? *(const bf16x4 *)(xg + (size_t)t * a.sx_t + gt * H + hid0 + 16 * hh) : zero4());
+                acc[gt][hh] = widen(row_ok ? *(const bf16x4 *)(xg + (size_t)t * a.sx_t + gt * H + hid0 + 16 * hh) : zero4()) + bias[gt][hh];
         const float kn = (a.keep && row_ok && t + 1 < T) ? a.keep[(size_t)(t + 1) * B + b] : 1.0f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -171,6 +178,9 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_
     const size_t state_row = ((size_t)g * B + b) * H;
     const __bf16 *sa = (const __bf16 *)a.saved_acts, *sc = (const __bf16 *)a.saved_cell;
 
+    f32x4 dbs[4][2];                                  // sums over the steps of this lane's gate gradients (bias gradient)
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) dbs[gt][0] = dbs[gt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 dh[2], dc[2];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -204,6 +214,7 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_
                 dc[hh][i] = dct * gf[i] * kt;
             }
             const bf16x4 v0 = narrow(di), v1 = narrow(df), v2 = narrow(dg), v3 = narrow(d_o);
+            if (row_ok) { dbs[0][hh] += widen(v0); dbs[1][hh] += widen(v1); dbs[2][hh] += widen(v2); dbs[3][hh] += widen(v3); }
             *(bf16x4 *)&dgbuf[buf][r][0 * H + hid] = v0;
             *(bf16x4 *)&dgbuf[buf][r][1 * H + hid] = v1;
             *(bf16x4 *)&dgbuf[buf][r][2 * H + hid] = v2;
@@ -229,6 +240,20 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_
             dh[0] = acc[0] * kt;
             dh[1] = acc[1] * kt;
         }
+    }
+    if (a.part_dbias) {   // add the 16 rows (lanes r) up; lane r == 0 of every group of 16 writes four columns
+        float *out = a.part_dbias + ((size_t)g * nblk + blk) * H4;
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                f32x4 v = dbs[gt][hh];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) v[e] += __shfl_down(v[e], off, 16);
+                if (r == 0) *(f32x4 *)(out + gt * H + hid0 + 16 * hh) = v;
+            }
     }
     if (row_ok) {
 #pragma unroll
@@ -257,6 +282,8 @@ int blocks_of(const cat_lstm_dims &d) { return (d.B + BM - 1) / BM; }
 extern "C" int cat_lstm_abi_version(void) { return CAT_LSTM_ABI_VERSION; }
 extern "C" const char *cat_lstm_last_error(void) { return g_err; }
 
+extern "C" int cat_lstm_blocks(const cat_lstm_dims *d) { return d && dims_ok(*d) ? blocks_of(*d) : CAT_LSTM_ERR_BAD_ARG; }
+
 extern "C" size_t cat_lstm_saved_acts_bytes(const cat_lstm_dims *d)
 {
     return d && dims_ok(*d) ? (size_t)d->T * d->G * blocks_of(*d) * NW * 8 * LANES * 4 * 2 : 0;
@@ -275,7 +302,8 @@ extern "C" int cat_lstm_seq_forward(const cat_lstm_fwd *a, void *stream)
         return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_forward: saved_acts and saved_cell go together");
     if (!aligned(a->w_hh, 16) || (a->sw_g % 8) || !aligned(a->xproj, 8) || (a->sx_g % 4) || (a->sx_t % 4) || (a->sx_b % 4) ||
         !aligned(a->out, 8) || (a->so_g % 4) || (a->so_t % 4) || (a->so_b % 4) || !aligned(a->h0, 8) || !aligned(a->c0, 8) ||
-        !aligned(a->h_last, 8) || !aligned(a->c_last, 8) || !aligned(a->h_in, 8) || !aligned(a->saved_acts, 8) || !aligned(a->saved_cell, 8))
+        !aligned(a->h_last, 8) || !aligned(a->c_last, 8) || !aligned(a->h_in, 8) || !aligned(a->saved_acts, 8) || !aligned(a->saved_cell, 8) ||
+        !aligned(a->bias, 8) || (a->bias && (a->sb_g % 4)))
         return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_forward: misaligned buffer or stride");
     hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(blocks_of(a->d), a->d.G), dim3(NW * LANES), 0, (hipStream_t)stream, *a);
     const hipError_t e = hipGetLastError();
@@ -289,7 +317,7 @@ extern "C" int cat_lstm_seq_backward(const cat_lstm_bwd *a, void *stream)
         return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_backward: a required buffer is NULL");
     if (!aligned(a->w_hh, 2) || !aligned(a->d_xproj, 8) || (a->sx_g % 4) || (a->sx_t % 4) || (a->sx_b % 4) || !aligned(a->d_out, 8) ||
         (a->d_out && ((a->so_g % 4) || (a->so_t % 4) || (a->so_b % 4))) || !aligned(a->d_h_last, 8) || !aligned(a->d_c_last, 8) ||
-        !aligned(a->d_h0, 8) || !aligned(a->d_c0, 8) || !aligned(a->saved_acts, 8) || !aligned(a->saved_cell, 8))
+        !aligned(a->d_h0, 8) || !aligned(a->d_c0, 8) || !aligned(a->saved_acts, 8) || !aligned(a->saved_cell, 8) || !aligned(a->part_dbias, 16))
         return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_backward: misaligned buffer or stride");
     hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(blocks_of(a->d), a->d.G), dim3(NW * LANES), 0, (hipStream_t)stream, *a);
     const hipError_t e = hipGetLastError();

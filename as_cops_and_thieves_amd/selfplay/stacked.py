@@ -65,7 +65,8 @@ def _cell_bwd(dh: torch.Tensor, dc: Optional[torch.Tensor], c: torch.Tensor, cy:
 
 class _LSTMSeq(torch.autograd.Function):
     """h_t, c_t = cell(xproj[:, t] + h_{t-1} W_hh^T, c_{t-1}) for t = 0..T-1, with the state zeroed where ``keep[t]`` is 0
-    (an episode starts at step t).  xproj [G, T, B, 4H]; w_hh [G, 4H, H]; h0, c0 [G, B, H]; keep fp32 [T, B] or None.
+    (an episode starts at step t).  xproj [G, T, B, 4H]; w_hh [G, 4H, H]; bias [G, 4H] added to every step's gate
+    pre-activations (kernel path only; None = already inside xproj); h0, c0 [G, B, H]; keep fp32 [T, B] or None.
     Returns out [G, T, B, H], h_T, c_T.
 
     bf16 on a GPU: the whole window is ONE launch of ``libcat_learn.so`` per direction (``csrc/cat_lstm.hip``: W_hh
@@ -73,18 +74,20 @@ class _LSTMSeq(torch.autograd.Function):
     CPU (the parity tests, ``compute_bf16=False``): the same recurrence step by step in torch."""
 
     @staticmethod
-    def forward(ctx, xproj, w_hh, h0, c0, keep):
+    def forward(ctx, xproj, w_hh, bias, h0, c0, keep):
         G, T, B, _ = xproj.shape
         train = any(ctx.needs_input_grad)          # a rollout tick (no_grad) keeps nothing
         ctx.has_keep = keep is not None
         ctx.set_materialize_grads(False)           # unused final-state gradients arrive as None, not as zero tensors
         ctx.native = xproj.is_cuda and xproj.dtype == torch.bfloat16
         if ctx.native:
-            out, hT, cT, (h_in, acts, cell) = _learn_native.seq_forward(xproj, w_hh, h0, c0, keep, save=train)
+            out, hT, cT, (h_in, acts, cell) = _learn_native.seq_forward(xproj, w_hh, bias, h0, c0, keep, save=train)
+            ctx.has_bias = bias is not None
             if train:
                 ctx.save_for_backward(w_hh, h_in, acts, cell, keep if keep is not None else torch.empty(0))
                 ctx.dims = (G, T, B)
             return out, hT, cT
+        assert bias is None, "the step-by-step path takes the bias inside xproj"
         w_t = w_hh.transpose(1, 2)
         h, c = h0, c0
         hs, cs, cys, wss, outs = [], [], [], [], []
@@ -106,12 +109,16 @@ class _LSTMSeq(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out, d_hT, d_cT):
+        d_bias = None
         if ctx.native:
             w_hh, h_in, acts, cell, keep = ctx.saved_tensors
             G, T, B = ctx.dims
-            want_state = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
-            dg_all, dh, dc = _learn_native.seq_backward(d_out, d_hT, d_cT, w_hh, keep if ctx.has_keep else None, acts, cell,
-                                                       ctx.dims, want_state)
+            want_state = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+            dg_all, dh, dc, part = _learn_native.seq_backward(d_out, d_hT, d_cT, w_hh, keep if ctx.has_keep else None, acts, cell,
+                                                             ctx.dims, want_state, want_bias_grad=ctx.has_bias)
+            if part is not None:   # add the workgroups' partial sums up (a GEMM with a row of ones, see _Lin)
+                ones = torch.ones(G, 1, part.shape[1], dtype=torch.float32, device=part.device)
+                d_bias = torch.bmm(ones, part).squeeze(1).to(w_hh.dtype)
         else:
             w_hh, h_in, cs, cys, wss, keep = ctx.saved_tensors
             G, T, B = h_in.shape[:3]
@@ -130,7 +137,7 @@ class _LSTMSeq(torch.autograd.Function):
             dg_all = torch.stack(dgs, 1)                                          # [G, T, B, 4H] = d xproj
         a = dg_all.reshape(G, T * B, dg_all.shape[3])
         d_w = torch.bmm(a.transpose(1, 2), h_in.reshape(G, T * B, h_in.shape[3]))   # one GEMM over all steps
-        return dg_all, d_w, dh, dc, None
+        return dg_all, d_w, d_bias, dh, dc, None
 
 
 # ---------------------------------------------------------------------------------------------- flat parameters
@@ -225,6 +232,35 @@ class _Lin(torch.autograd.Function):
         ones = torch.ones(go.shape[0], 1, go.shape[1], dtype=go.dtype, device=go.device)
         db = torch.bmm(ones, go).squeeze(1)
         return dx, dw, db
+
+
+class _LinAct(torch.autograd.Function):
+    """act(x @ w^T + b) for G stacked layers in bf16 on the GPU: the product is a library GEMM, the bias broadcast and
+    the activation one in-place pass over its result, the activation's derivative and the bias gradient (column sums)
+    one pass over the incoming gradient (``csrc/cat_dense.hip``).  act: 0 none, 1 ReLU, 2 tanh."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        y = _learn_native.dense_bias_act_(torch.bmm(x, w.transpose(1, 2)), b, act)
+        ctx.save_for_backward(x, w, y)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        x, w, y = ctx.saved_tensors
+        g, db = _learn_native.dense_act_grad(go, y, ctx.act)
+        dx = torch.bmm(g, w) if ctx.needs_input_grad[0] else None
+        dw = torch.bmm(g.transpose(1, 2), x)
+        return dx, dw, db.to(w.dtype), None
+
+
+def _lin_act(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: int) -> torch.Tensor:
+    """act(x [G, M, in] @ w[G, out, in]^T + b[G, out]); act 0 none, 1 ReLU, 2 tanh."""
+    if x.is_cuda and x.dtype == torch.bfloat16:
+        return _LinAct.apply(x, w, b, act)
+    y = _Lin.apply(x, w, b)
+    return torch.relu(y) if act == 1 else torch.tanh(y) if act == 2 else y
 
 
 def _lin(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -343,22 +379,25 @@ class StackedNet:
                 b = _Expand.apply(self.w(name + ".bias"), b_idx, b_back)
                 z = torch.relu(_lin(z, w, b))                                                    # [G, N, l_out * c_out], (l, c)
         wfc = self.w("trunk.features.5.weight").view(G, 256, 32, self.L2).transpose(2, 3).reshape(G, 256, self.L2 * 32)
-        f = torch.tanh(_lin(z, wfc, self.w("trunk.features.5.bias")))                            # [G, T*B, 256]
+        f = _lin_act(z, wfc, self.w("trunk.features.5.bias"), 2)                                 # [G, T*B, 256], tanh
         h0, c0 = state
         kp = None if keep is None else keep.to(torch.float32).contiguous()
+        native = f.is_cuda and dt == torch.bfloat16
         inp = f
         hs, cs = [], []
         for l in range(self.layers):
             bias = self.w(f"trunk.lstm.bias_ih_l{l}") + self.w(f"trunk.lstm.bias_hh_l{l}")
-            xp = _lin(inp, self.w(f"trunk.lstm.weight_ih_l{l}"), bias).view(G, T, B, 4 * HIDDEN)
-            out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), h0[l].to(dt), c0[l].to(dt), kp)
+            w_ih = self.w(f"trunk.lstm.weight_ih_l{l}")
+            if native:   # the recurrence kernel adds the bias and returns its gradient: the projection is a bare GEMM
+                xp = torch.bmm(inp, w_ih.transpose(1, 2)).view(G, T, B, 4 * HIDDEN)
+            else:
+                xp, bias = _lin(inp, w_ih, bias).view(G, T, B, 4 * HIDDEN), None
+            out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), bias, h0[l].to(dt), c0[l].to(dt), kp)
             hs.append(hT); cs.append(cT)
             inp = out.reshape(G, N, HIDDEN)
         y = inp
         for j in range(self.n_head):
-            y = _lin(y, self.w(f"head.{2 * j}.weight"), self.w(f"head.{2 * j}.bias"))
-            if j < self.n_head - 1:
-                y = torch.relu(y)
+            y = _lin_act(y, self.w(f"head.{2 * j}.weight"), self.w(f"head.{2 * j}.bias"), 1 if j < self.n_head - 1 else 0)
         return y.view(G, T, B, -1), (torch.stack(hs, 0), torch.stack(cs, 0))
 
 

@@ -1,0 +1,48 @@
+/*
+ * cat_dense.h -- C ABI of libcat_learn.so, part 4: the epilogues of the learner's dense layers (SURVEY.md section 8(f),
+ * rank 2).  A layer of the G stacked networks is y = act(x W^T + b) (torch.nn.Linear + ReLU / Tanh in the reference's
+ * models, src/models/lstm_policy_net.py:36-53, src/models/lstm_value_net.py:54-75).  The product stays a library GEMM; what
+ * surrounds it -- the bias broadcast, the activation, the activation's derivative and the bias gradient (a column sum
+ * over all rows) -- is one in-place pass forward and one pass backward instead of four library kernels and a GEMM with a
+ * row of ones.  Conventions as in cat_sim.h.
+ */
+#ifndef CAT_DENSE_H
+#define CAT_DENSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAT_DENSE_ABI_VERSION 1
+#define CAT_DENSE_MAX_CHUNKS 256
+#define CAT_DENSE_MAX_OUT 1024
+
+enum { CAT_DENSE_OK = 0, CAT_DENSE_ERR_BAD_ARG = -1, CAT_DENSE_ERR_HIP = -2 };
+enum { CAT_ACT_NONE = 0, CAT_ACT_RELU = 1, CAT_ACT_TANH = 2 };
+
+typedef struct cat_dense_dims {
+    int32_t G;      /* stacked networks */
+    int32_t M;      /* rows per network */
+    int32_t out;    /* columns: 1, or a multiple of 4 up to CAT_DENSE_MAX_OUT */
+    int32_t act;    /* CAT_ACT_* */
+} cat_dense_dims;
+
+/* y[g][m][:] = act(y[g][m][:] + bias[g][:]) in place; y bf16 [G][M][out] contiguous, bias bf16 with row stride sb_g */
+int cat_dense_bias_act(const cat_dense_dims *d, void *y, const void *bias, int64_t sb_g, void *stream);
+
+/* g_out = d_y * act'(y) (from the layer's OUTPUT y; g_out may be NULL when act is CAT_ACT_NONE) and
+   partial[g][chunk][:] = column sums of that over chunk `chunk` of the rows: the caller adds the chunks up for the bias
+   gradient.  d_y, y, g_out bf16 [G][M][out] contiguous; partial fp32 [G][chunks][out]. */
+int cat_dense_act_grad(const cat_dense_dims *d, const void *d_y, const void *y, void *g_out, float *partial, int32_t chunks,
+                       void *stream);
+
+int cat_dense_abi_version(void);
+const char *cat_dense_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -42,13 +42,16 @@ typedef struct cat_lstm_dims {
 
 /* Bytes of the three "saved for backward" buffers cat_lstm_seq_forward fills when they are non-NULL (a layout only
    cat_lstm_seq_backward reads).  acts: the four activated gates; cell: c entering each step and tanh(c) leaving it. */
+int cat_lstm_blocks(const cat_lstm_dims *d);       /* workgroups per network = ceil(B / CAT_LSTM_ROWS_PER_BLOCK) */
 size_t cat_lstm_saved_acts_bytes(const cat_lstm_dims *d);
 size_t cat_lstm_saved_cell_bytes(const cat_lstm_dims *d);
 
 typedef struct cat_lstm_fwd {
     cat_lstm_dims d;
-    const void *xproj;          /* bf16 [G][T][B][4H]: x_t W_ih^T + b_ih + b_hh */
+    const void *xproj;          /* bf16 [G][T][B][4H]: x_t W_ih^T (+ b_ih + b_hh when bias is NULL) */
     int64_t sx_g, sx_t, sx_b;
+    const void *bias;           /* bf16 [G][4H] = b_ih + b_hh, added to every step's pre-activations; or NULL */
+    int64_t sb_g;
     const void *w_hh;           /* bf16 [G][4H][H] */
     int64_t sw_g;
     const void *h0, *c0;        /* bf16 [G][B][H], contiguous */
@@ -73,6 +76,8 @@ typedef struct cat_lstm_bwd {
     void *d_xproj;              /* bf16 [G][T][B][4H]: gradient of the summed gate pre-activations */
     int64_t sx_g, sx_t, sx_b;
     void *d_h0, *d_c0;          /* bf16 [G][B][H] contiguous, or NULL (not wanted) */
+    float *part_dbias;          /* fp32 [G][cat_lstm_blocks()][4H] or NULL: per-workgroup sums of d_xproj over its rows and all
+                                   steps (the bias gradient once the caller has added the workgroups up) */
 } cat_lstm_bwd;
 
 int cat_lstm_abi_version(void);

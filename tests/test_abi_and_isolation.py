@@ -48,6 +48,35 @@ def test_lstm_library_exports_every_declared_symbol_and_struct_layouts_match():
     assert L.cat_lstm_seq_forward(C.byref(bad), None) == -1 and b"dimensions" in L.cat_lstm_last_error()
 
 
+@pytest.mark.parametrize("header,prefix,symbols,structs", [
+    ("cat_trunk.h", "cat_trunk_", "TRUNK_SYMBOLS", {"cat_trunk_dims": "TrunkDims", "cat_trunk_params": "TrunkParams", "cat_trunk_fwd": "TrunkFwd",
+                                                    "cat_trunk_bwd": "TrunkBwd"}),
+    ("cat_ppo.h", "cat_ppo_", "PPO_SYMBOLS", {"cat_ppo_loss": "PpoLoss", "cat_ppo_adam": "PpoAdam"}),
+    ("cat_dense.h", "cat_dense_", "DENSE_SYMBOLS", {"cat_dense_dims": "DenseDims"})])
+def test_learner_kernel_headers_match_the_library_and_the_ctypes_mirror(header, prefix, symbols, structs):
+    from as_cops_and_thieves_amd import _learn_native as ln
+    ln.build()
+    L = ln.lib()
+    code = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / header).read_text(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(%s[a-z_0-9]+)\s*\(" % prefix, code)))
+    assert set(declared) == set(getattr(ln, symbols)) and all(hasattr(L, s) for s in declared)
+    for struct, cls in structs.items():
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), code, re.S).group(1)
+        names = [n for decl in body.split(";") for n in re.findall(r"\b([A-Za-z_0-9]+)\s*(?=,|$)", decl.strip())]
+        assert names == [f[0] for f in getattr(ln, cls)._fields_], (struct, names)
+
+
+def test_learner_kernels_reject_bad_arguments_before_touching_a_device():
+    from as_cops_and_thieves_amd import _learn_native as ln
+    L = ln.lib()
+    d = ln.TrunkDims(3, 1000, 4, 64)
+    assert L.cat_trunk_out_positions(C.byref(d)) == 9 and L.cat_trunk_supported(C.byref(d)) == 1
+    assert L.cat_trunk_supported(C.byref(ln.TrunkDims(3, 1000, 4, 90))) == 0          # R = 90 does not fit the LDS (dense path)
+    assert L.cat_trunk_forward(C.byref(ln.TrunkFwd()), None) == -1 and b"dimensions" in L.cat_trunk_last_error()
+    assert L.cat_ppo_loss_grad(C.byref(ln.PpoLoss()), None) == -1 and L.cat_ppo_adam_step(C.byref(ln.PpoAdam()), None) == -1
+    assert L.cat_dense_bias_act(C.byref(ln.DenseDims(1, 1, 3, 0)), None, None, 0, None) == -1        # out = 3: neither 1 nor 4 k
+
+
 def test_struct_layouts_match_header_field_order():
     from as_cops_and_thieves_amd import _native
     text = (ROOT / "include" / "cat_sim.h").read_text()

@@ -1,0 +1,28 @@
+"""GPU: the dense-layer epilogue kernels of libcat_learn.so (include/cat_dense.h) against plain PyTorch fp32: act(y + b)
+in place, and d_y * act'(y) with its column sums (the bias gradient).  Tolerances: bf16 storage (2^-8 relative) on the
+elementwise results, 1e-3 relative on the fp32 column sums of the bf16-rounded products."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("G,M,out,act", [(3, 16384, 512, 0), (3, 16384, 256, 2), (3, 5000, 128, 1), (2, 777, 64, 1), (3, 4096, 4, 0),
+                                         (3, 4096, 1, 0), (1, 100, 12, 2)])
+def test_bias_act_and_its_gradient_match_torch(G, M, out, act):
+    import torch
+    from as_cops_and_thieves_amd import _learn_native as ln
+    gen = torch.Generator(device="cuda").manual_seed(out * 10 + act)
+    pre = torch.randn(G, M, out, generator=gen, device="cuda").to(torch.bfloat16)
+    flat = torch.randn(G, out + 24, generator=gen, device="cuda").to(torch.bfloat16)
+    bias = flat[:, 8:8 + out]                                             # a row-strided view, as a FlatParams parameter
+    f = {0: lambda t: t, 1: torch.relu, 2: torch.tanh}[act]
+    want = f(pre.float() + bias.float().unsqueeze(1))
+    y = ln.dense_bias_act_(pre.clone(), bias, act)
+    assert torch.allclose(y.float(), want, rtol=2 ** -7, atol=2e-3)
+    d_y = torch.randn(G, M, out, generator=gen, device="cuda").to(torch.bfloat16)
+    g, db = ln.dense_act_grad(d_y, y, act)
+    der = {0: torch.ones_like(want), 1: (y.float() > 0).float(), 2: 1 - y.float() ** 2}[act]
+    g_want = d_y.float() * der
+    torch.cuda.synchronize()
+    assert torch.allclose(g.float(), g_want, rtol=2 ** -7, atol=1e-6)
+    assert torch.allclose(db, g.float().sum(1), rtol=1e-3, atol=1e-2)

@@ -62,20 +62,24 @@ def test_forward_and_backward_match_the_fp32_reference(G, T, B, with_keep, strid
     r_out = torch.randn(G, T, B, H, generator=gen, device="cuda")
     r_h, r_c = torch.randn(G, B, H, generator=gen, device="cuda"), torch.randn(G, B, H, generator=gen, device="cuda")
 
+    bias = (0.3 * torch.randn(G, 4 * H, generator=gen, device="cuda")).to(torch.bfloat16) if B != 48 else None   # one case without
     leaves = [t.detach().clone().requires_grad_(True) for t in (xproj, w_hh, h0, c0)]
-    out, hT, cT = _LSTMSeq.apply(leaves[0], leaves[1], leaves[2], leaves[3], keep)
+    b_leaf = None if bias is None else bias.detach().clone().requires_grad_(True)
+    out, hT, cT = _LSTMSeq.apply(leaves[0], leaves[1], b_leaf, leaves[2], leaves[3], keep)
     assert out.dtype == torch.bfloat16 and out.shape == (G, T, B, H)
     loss = (out.float() * r_out).sum() + (hT.float() * r_h).sum() + (cT.float() * r_c).sum()
     loss.backward()
 
     ref_leaves = [t.detach().float().clone().requires_grad_(True) for t in (xproj, w_hh, h0, c0)]
-    ro, rh, rc = _reference(*ref_leaves, keep)
+    rb = None if bias is None else bias.detach().float().clone().requires_grad_(True)
+    ro, rh, rc = _reference(ref_leaves[0] if rb is None else ref_leaves[0] + rb.view(G, 1, 1, -1), *ref_leaves[1:], keep)
     ((ro * r_out).sum() + (rh * r_h).sum() + (rc * r_c).sum()).backward()
     torch.cuda.synchronize()
 
     assert float((out.detach().float() - ro.detach()).abs().max()) <= 2e-2
     assert float((hT.detach().float() - rh.detach()).abs().max()) <= 2e-2 and float((cT.detach().float() - rc.detach()).abs().max()) <= 4e-2
-    for name, got, want in zip(("d_xproj", "d_w_hh", "d_h0", "d_c0"), leaves, ref_leaves):
+    pairs = list(zip(("d_xproj", "d_w_hh", "d_h0", "d_c0"), leaves, ref_leaves)) + ([] if bias is None else [("d_bias", b_leaf, rb)])
+    for name, got, want in pairs:
         err, cos = _rel(got.grad, want.grad)
         assert err <= 2e-2 and cos >= 0.999, (name, err, cos)
 
@@ -86,9 +90,9 @@ def test_inference_call_keeps_nothing_and_equals_the_training_forward():
     from as_cops_and_thieves_amd.selfplay.stacked import _LSTMSeq
     xproj, w_hh, h0, c0, keep = _case(3, 1, 4096, True, seed=3)
     with torch.no_grad():
-        o1, h1, c1 = _LSTMSeq.apply(xproj, w_hh, h0, c0, keep)
+        o1, h1, c1 = _LSTMSeq.apply(xproj, w_hh, None, h0, c0, keep)
     leaves = [t.detach().clone().requires_grad_(True) for t in (xproj, w_hh, h0, c0)]
-    o2, h2, c2 = _LSTMSeq.apply(*leaves, keep)
+    o2, h2, c2 = _LSTMSeq.apply(leaves[0], leaves[1], None, leaves[2], leaves[3], keep)
     torch.cuda.synchronize()
     assert torch.equal(o1, o2) and torch.equal(h1, h2) and torch.equal(c1, c2) and torch.equal(o1[:, 0], h1)
 
@@ -102,7 +106,7 @@ def test_one_launch_per_direction_inside_a_hip_graph():
     ws = w_hh.detach().clone().requires_grad_(True)
 
     def step():
-        out, hT, cT = _LSTMSeq.apply(xs, ws, h0, c0, keep)
+        out, hT, cT = _LSTMSeq.apply(xs, ws, None, h0, c0, keep)
         gx, gw = torch.autograd.grad(out.float().square().sum(), (xs, ws))
         return out, gx, gw
     s = torch.cuda.Stream()
