@@ -61,7 +61,7 @@ class TrunkBwd(C.Structure):
                 ("part_dw1", C.c_void_p), ("part_db1", C.c_void_p), ("part_dw2", C.c_void_p), ("part_db2", C.c_void_p)]
 
 
-DENSE_SYMBOLS = ("cat_dense_abi_version", "cat_dense_last_error", "cat_dense_bias_act", "cat_dense_act_grad")
+DENSE_SYMBOLS = ("cat_dense_abi_version", "cat_dense_last_error", "cat_dense_bias_act", "cat_dense_act_grad", "cat_dense_sum_chunks")
 PPO_SYMBOLS = ("cat_ppo_abi_version", "cat_ppo_last_error", "cat_ppo_loss_grad", "cat_ppo_adam_step")
 
 
@@ -146,6 +146,9 @@ def lib() -> C.CDLL:
         L.cat_dense_bias_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.cat_dense_act_grad.restype = C.c_int
         L.cat_dense_act_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.cat_dense_sum_chunks.restype = C.c_int
+        L.cat_dense_sum_chunks.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                           C.c_int32, C.c_void_p]
         assert L.cat_dense_abi_version() == 1
         _lib = L
     return _lib
@@ -297,8 +300,7 @@ def ppo_loss_grad(logits, values, actions, old_logp, adv, ret, ratio_clip: float
     a = PpoLoss(G, M, PPO_CHUNKS, 0, logits.data_ptr(), values.data_ptr(), actions.data_ptr(), old_logp.data_ptr(), adv.data_ptr(),
                 ret.data_ptr(), ratio_clip, value_scale, entropy_scale, 0.0, d_logits.data_ptr(), d_values.data_ptr(), partial.data_ptr())
     _check(lib().cat_ppo_loss_grad(C.byref(a), _stream()), "cat_ppo_loss_grad")
-    ones = torch.ones(G, 1, PPO_CHUNKS, dtype=torch.float32, device=logits.device)
-    return torch.bmm(ones, partial).squeeze(1), d_logits, d_values
+    return torch.bmm(ones_row(G, PPO_CHUNKS, logits.device), partial).squeeze(1), d_logits, d_values
 
 
 def ppo_adam_step(ar, col_train, epoch_active, m, v, steps, master, lp, kl_out, scratch, lr, beta1, beta2, eps, grad_norm_clip,
@@ -336,16 +338,44 @@ def dense_bias_act_(y, bias, act: int):
 
 
 def dense_act_grad(d_y, y, act: int):
-    """(d_y * act'(y), fp32 column sums [G, out] of it).  With ACT_NONE the first result is d_y itself."""
+    """(d_y * act'(y), fp32 per-chunk column sums [G, chunks, out] of it: ``sum_chunks`` adds them up).  With ACT_NONE the
+    first result is d_y itself."""
     import torch
     G, M, out = d_y.shape
     d_y = d_y.contiguous()
     assert d_y.dtype == torch.bfloat16 and (act == ACT_NONE or (y.shape == d_y.shape and y.is_contiguous()))
     g_out = torch.empty_like(d_y) if act != ACT_NONE else None
-    chunks = max(1, min(DENSE_CHUNKS, M // 64))
+    chunks = max(1, min(256, M // 32))
     partial = torch.empty(G, chunks, out, dtype=torch.float32, device=d_y.device)
     d = DenseDims(G, M, out, act)
     _check(lib().cat_dense_act_grad(C.byref(d), d_y.data_ptr(), _ptr(y) if act != ACT_NONE else 0, _ptr(g_out), partial.data_ptr(), chunks,
                                     _stream()), "cat_dense_act_grad")
-    ones = torch.ones(G, 1, chunks, dtype=torch.float32, device=d_y.device)
-    return (g_out if g_out is not None else d_y), torch.bmm(ones, partial).squeeze(1)
+    return (g_out if g_out is not None else d_y), partial
+
+
+def sum_chunks(partial, dst=None, dst2=None, accumulate: bool = False):
+    """partial fp32 [G, chunks, ...] -> bf16 [G, ...] sums over the chunks: into ``dst`` (and ``dst2``), each [G, n] with
+    contiguous rows and any row stride, optionally added to what they hold; a new tensor when ``dst`` is None."""
+    import torch
+    G, chunks = partial.shape[:2]
+    n = partial[0, 0].numel()
+    assert partial.dtype == torch.float32 and partial.is_contiguous()
+    if dst is None:
+        dst = torch.empty((G,) + tuple(partial.shape[2:]), dtype=torch.bfloat16, device=partial.device)
+    for t in (dst, dst2):
+        assert t is None or (t.dtype == torch.bfloat16 and t.shape[0] == G and t[0].numel() == n and t[0].is_contiguous())
+    _check(lib().cat_dense_sum_chunks(partial.data_ptr(), G, chunks, n, dst.data_ptr(), dst.stride(0), _ptr(dst2),
+                                      0 if dst2 is None else dst2.stride(0), 1 if accumulate else 0, _stream()), "cat_dense_sum_chunks")
+    return dst
+
+
+_ONES = {}
+
+
+def ones_row(G: int, n: int, device):
+    """cached fp32 [G, 1, n] of ones (the left operand of the "add the slabs up" GEMMs)"""
+    import torch
+    key = (G, n, str(device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones(G, 1, n, dtype=torch.float32, device=device)
+    return _ONES[key]

@@ -105,6 +105,33 @@ __global__ __launch_bounds__(BLOCK) void act_grad_kernel(cat_dense_dims d, const
     }
 }
 
+// block = 32 columns x 8 chunk lanes: a column's chunks are read by eight threads in parallel (32 loads each at 256
+// chunks) and added up through LDS
+__global__ __launch_bounds__(BLOCK) void sum_chunks_kernel(const float *partial, int chunks, int n, __bf16 *dst0, int64_t sd0, __bf16 *dst1,
+                                                           int64_t sd1, int accumulate)
+{
+    __shared__ float lds[BLOCK];
+    const int g = blockIdx.y, cl = threadIdx.x & 31, lane = threadIdx.x >> 5, j = blockIdx.x * 32 + cl;
+    float s = 0.0f;
+    if (j < n) {
+        const float *p = partial + (size_t)g * chunks * n + j;
+        for (int c = lane; c < chunks; c += 8) s += p[(size_t)c * n];
+    }
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && j < n) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s += lds[32 * k + cl];
+        if (accumulate) {
+            dst0[(size_t)g * sd0 + j] = (__bf16)(s + (float)dst0[(size_t)g * sd0 + j]);
+            if (dst1) dst1[(size_t)g * sd1 + j] = (__bf16)(s + (float)dst1[(size_t)g * sd1 + j]);
+        } else {
+            dst0[(size_t)g * sd0 + j] = (__bf16)s;
+            if (dst1) dst1[(size_t)g * sd1 + j] = (__bf16)s;
+        }
+    }
+}
+
 thread_local char g_err[256] = "";
 int fail(int code, const char *msg)
 {
@@ -145,6 +172,17 @@ extern "C" int cat_dense_act_grad(const cat_dense_dims *d, const void *d_y, cons
     const int gy = (groups + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(act_grad_kernel, dim3(chunks, gy, d->G), dim3(BLOCK), 0, (hipStream_t)stream, *d, (const __bf16 *)d_y,
                        (const __bf16 *)y, (__bf16 *)g_out, partial);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_DENSE_OK : fail(CAT_DENSE_ERR_HIP, hipGetErrorString(e));
+}
+
+extern "C" int cat_dense_sum_chunks(const float *partial, int32_t G, int32_t chunks, int32_t n, void *dst0, int64_t sd0_g, void *dst1,
+                                    int64_t sd1_g, int32_t accumulate, void *stream)
+{
+    if (!partial || !dst0 || G <= 0 || G > 65535 || chunks <= 0 || n <= 0)
+        return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_sum_chunks: bad dimensions or NULL buffer");
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3((n + 31) / 32, G), dim3(BLOCK), 0, (hipStream_t)stream, partial, chunks, n,
+                       (__bf16 *)dst0, sd0_g, (__bf16 *)dst1, sd1_g, accumulate);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAT_DENSE_OK : fail(CAT_DENSE_ERR_HIP, hipGetErrorString(e));
 }

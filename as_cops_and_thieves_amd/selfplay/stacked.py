@@ -63,31 +63,41 @@ def _cell_bwd(dh: torch.Tensor, dc: Optional[torch.Tensor], c: torch.Tensor, cy:
     return dg, dct * f
 
 
+def _grad_slot(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The pre-assigned gradient view of a FlatParams leaf (``FlatParams.views``), else None."""
+    if p is None or not (p.is_leaf and p.requires_grad) or p.grad is None:
+        return None
+    return p.grad
+
+
 class _LSTMSeq(torch.autograd.Function):
     """h_t, c_t = cell(xproj[:, t] + h_{t-1} W_hh^T, c_{t-1}) for t = 0..T-1, with the state zeroed where ``keep[t]`` is 0
-    (an episode starts at step t).  xproj [G, T, B, 4H]; w_hh [G, 4H, H]; bias [G, 4H] added to every step's gate
-    pre-activations (kernel path only; None = already inside xproj); h0, c0 [G, B, H]; keep fp32 [T, B] or None.
-    Returns out [G, T, B, H], h_T, c_T.
+    (an episode starts at step t).  xproj [G, T, B, 4H]; w_hh [G, 4H, H]; b_ih, b_hh [G, 4H]: their sum is added to every
+    step's gate pre-activations (kernel path only; None = already inside xproj); h0, c0 [G, B, H]; keep fp32 [T, B] or
+    None.  Returns out [G, T, B, H], h_T, c_T.  Parameters that are FlatParams leaves get their gradient ADDED straight
+    into their slot of the flat gradient buffer by backward (which then returns None for them): no AccumulateGrad pass.
 
     bf16 on a GPU: the whole window is ONE launch of ``libcat_learn.so`` per direction (``csrc/cat_lstm.hip``: W_hh
     resident in registers, the products on the matrix cores, the cell in fp32) -- no other path exists there.  fp32 /
     CPU (the parity tests, ``compute_bf16=False``): the same recurrence step by step in torch."""
 
     @staticmethod
-    def forward(ctx, xproj, w_hh, bias, h0, c0, keep):
+    def forward(ctx, xproj, w_hh, b_ih, b_hh, h0, c0, keep):
         G, T, B, _ = xproj.shape
         train = any(ctx.needs_input_grad)          # a rollout tick (no_grad) keeps nothing
         ctx.has_keep = keep is not None
         ctx.set_materialize_grads(False)           # unused final-state gradients arrive as None, not as zero tensors
         ctx.native = xproj.is_cuda and xproj.dtype == torch.bfloat16
         if ctx.native:
+            bias = b_ih if (b_ih is None or b_hh is None) else b_ih + b_hh
             out, hT, cT, (h_in, acts, cell) = _learn_native.seq_forward(xproj, w_hh, bias, h0, c0, keep, save=train)
             ctx.has_bias = bias is not None
+            ctx.slots = (_grad_slot(w_hh), _grad_slot(b_ih), _grad_slot(b_hh))
             if train:
                 ctx.save_for_backward(w_hh, h_in, acts, cell, keep if keep is not None else torch.empty(0))
                 ctx.dims = (G, T, B)
             return out, hT, cT
-        assert bias is None, "the step-by-step path takes the bias inside xproj"
+        assert b_ih is None and b_hh is None, "the step-by-step path takes the bias inside xproj"
         w_t = w_hh.transpose(1, 2)
         h, c = h0, c0
         hs, cs, cys, wss, outs = [], [], [], [], []
@@ -109,16 +119,21 @@ class _LSTMSeq(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out, d_hT, d_cT):
-        d_bias = None
+        d_bih = d_bhh = None
+        w_slot = None
         if ctx.native:
             w_hh, h_in, acts, cell, keep = ctx.saved_tensors
             G, T, B = ctx.dims
-            want_state = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+            want_state = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
             dg_all, dh, dc, part = _learn_native.seq_backward(d_out, d_hT, d_cT, w_hh, keep if ctx.has_keep else None, acts, cell,
                                                              ctx.dims, want_state, want_bias_grad=ctx.has_bias)
-            if part is not None:   # add the workgroups' partial sums up (a GEMM with a row of ones, see _Lin)
-                ones = torch.ones(G, 1, part.shape[1], dtype=torch.float32, device=part.device)
-                d_bias = torch.bmm(ones, part).squeeze(1).to(w_hh.dtype)
+            w_slot, ih_slot, hh_slot = ctx.slots
+            if part is not None:   # add the workgroups' partial sums up
+                if ih_slot is not None and (hh_slot is not None or not ctx.needs_input_grad[3]):
+                    _learn_native.sum_chunks(part, ih_slot, hh_slot, accumulate=True)
+                else:
+                    d_bih = _learn_native.sum_chunks(part)
+                    d_bhh = d_bih if ctx.needs_input_grad[3] else None
         else:
             w_hh, h_in, cs, cys, wss, keep = ctx.saved_tensors
             G, T, B = h_in.shape[:3]
@@ -136,8 +151,13 @@ class _LSTMSeq(torch.autograd.Function):
                 dgs[t] = dg
             dg_all = torch.stack(dgs, 1)                                          # [G, T, B, 4H] = d xproj
         a = dg_all.reshape(G, T * B, dg_all.shape[3])
-        d_w = torch.bmm(a.transpose(1, 2), h_in.reshape(G, T * B, h_in.shape[3]))   # one GEMM over all steps
-        return dg_all, d_w, d_bias, dh, dc, None
+        hin = h_in.reshape(G, T * B, h_in.shape[3])
+        if w_slot is not None:
+            w_slot.baddbmm_(a.transpose(1, 2), hin)                                   # one GEMM over all steps, into the slot
+            d_w = None
+        else:
+            d_w = torch.bmm(a.transpose(1, 2), hin)
+        return dg_all, d_w, d_bih, d_bhh, dh, dc, None
 
 
 # ---------------------------------------------------------------------------------------------- flat parameters
@@ -237,25 +257,40 @@ class _Lin(torch.autograd.Function):
 class _LinAct(torch.autograd.Function):
     """act(x @ w^T + b) for G stacked layers in bf16 on the GPU: the product is a library GEMM, the bias broadcast and
     the activation one in-place pass over its result, the activation's derivative and the bias gradient (column sums)
-    one pass over the incoming gradient (``csrc/cat_dense.hip``).  act: 0 none, 1 ReLU, 2 tanh."""
+    one pass over the incoming gradient (``csrc/cat_dense.hip``).  act: 0 none, 1 ReLU, 2 tanh; b None = a bare product.
+    Gradients of FlatParams leaves are added straight into their slots of the flat gradient buffer (see _LSTMSeq)."""
 
     @staticmethod
     def forward(ctx, x, w, b, act):
-        y = _learn_native.dense_bias_act_(torch.bmm(x, w.transpose(1, 2)), b, act)
-        ctx.save_for_backward(x, w, y)
-        ctx.act = act
+        y = torch.bmm(x, w.transpose(1, 2))
+        if b is not None:
+            _learn_native.dense_bias_act_(y, b, act)
+        ctx.save_for_backward(x, w, y if act != 0 else None)
+        ctx.act, ctx.has_bias = act, b is not None
+        ctx.slots = (_grad_slot(w), _grad_slot(b))
         return y
 
     @staticmethod
     def backward(ctx, go):
         x, w, y = ctx.saved_tensors
-        g, db = _learn_native.dense_act_grad(go, y, ctx.act)
+        w_slot, b_slot = ctx.slots
+        g, db = go.contiguous(), None
+        if ctx.has_bias:
+            g, part = _learn_native.dense_act_grad(g, y, ctx.act)
+            if b_slot is not None:
+                _learn_native.sum_chunks(part, b_slot, accumulate=True)
+            else:
+                db = _learn_native.sum_chunks(part)
         dx = torch.bmm(g, w) if ctx.needs_input_grad[0] else None
-        dw = torch.bmm(g.transpose(1, 2), x)
-        return dx, dw, db.to(w.dtype), None
+        if w_slot is not None:
+            w_slot.baddbmm_(g.transpose(1, 2), x)
+            dw = None
+        else:
+            dw = torch.bmm(g.transpose(1, 2), x)
+        return dx, dw, db, None
 
 
-def _lin_act(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, act: int) -> torch.Tensor:
+def _lin_act(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int) -> torch.Tensor:
     """act(x [G, M, in] @ w[G, out, in]^T + b[G, out]); act 0 none, 1 ReLU, 2 tanh."""
     if x.is_cuda and x.dtype == torch.bfloat16:
         return _LinAct.apply(x, w, b, act)
@@ -307,7 +342,7 @@ class _ConvTrunk(torch.autograd.Function):
         G, C = w1.shape[0], w1.shape[2]
         parts = _learn_native.trunk_backward(x, w1, b1, w2, b2, out, go, ctx.R)
         nb = parts[0].shape[1]
-        ones = torch.ones(G, 1, nb, dtype=torch.float32, device=go.device)
+        ones = _learn_native.ones_row(G, nb, go.device)
         dw1, db1, dw2, db2 = (torch.bmm(ones, p.view(G, nb, -1)).squeeze(1) for p in parts)      # add the slabs up
         dw1 = dw1.view(G, 64, 32)[:, :, :5 * C].reshape(G, 64, 5, C).transpose(2, 3)              # column kk * C + c
         dw2 = dw2.view(G, 32, 5, 64).transpose(2, 3)                                             # column kk * 64 + c_in
@@ -386,13 +421,12 @@ class StackedNet:
         inp = f
         hs, cs = [], []
         for l in range(self.layers):
-            bias = self.w(f"trunk.lstm.bias_ih_l{l}") + self.w(f"trunk.lstm.bias_hh_l{l}")
-            w_ih = self.w(f"trunk.lstm.weight_ih_l{l}")
-            if native:   # the recurrence kernel adds the bias and returns its gradient: the projection is a bare GEMM
-                xp = torch.bmm(inp, w_ih.transpose(1, 2)).view(G, T, B, 4 * HIDDEN)
+            w_ih, b_ih, b_hh = (self.w(f"trunk.lstm.{n}_l{l}") for n in ("weight_ih", "bias_ih", "bias_hh"))
+            if native:   # the recurrence kernel adds the biases and returns their gradient: the projection is a bare GEMM
+                xp = _LinAct.apply(inp, w_ih, None, 0).view(G, T, B, 4 * HIDDEN)
             else:
-                xp, bias = _lin(inp, w_ih, bias).view(G, T, B, 4 * HIDDEN), None
-            out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), bias, h0[l].to(dt), c0[l].to(dt), kp)
+                xp, b_ih, b_hh = _lin(inp, w_ih, b_ih + b_hh).view(G, T, B, 4 * HIDDEN), None, None
+            out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), b_ih, b_hh, h0[l].to(dt), c0[l].to(dt), kp)
             hs.append(hT); cs.append(cT)
             inp = out.reshape(G, N, HIDDEN)
         y = inp

@@ -39,6 +39,11 @@ int cat_dense_bias_act(const cat_dense_dims *d, void *y, const void *bias, int64
 int cat_dense_act_grad(const cat_dense_dims *d, const void *d_y, const void *y, void *g_out, float *partial, int32_t chunks,
                        void *stream);
 
+/* dst[g][j] (+)= sum over c < chunks of partial[g][c][j], j < n, stored as bf16: the second stage of the column sums above
+   and of the other per-workgroup partial sums of this library.  dst1 may be NULL; accumulate != 0 adds to what dst holds. */
+int cat_dense_sum_chunks(const float *partial, int32_t G, int32_t chunks, int32_t n, void *dst0, int64_t sd0_g, void *dst1,
+                         int64_t sd1_g, int32_t accumulate, void *stream);
+
 int cat_dense_abi_version(void);
 const char *cat_dense_last_error(void);
 

@@ -65,7 +65,7 @@ def test_forward_and_backward_match_the_fp32_reference(G, T, B, with_keep, strid
     bias = (0.3 * torch.randn(G, 4 * H, generator=gen, device="cuda")).to(torch.bfloat16) if B != 48 else None   # one case without
     leaves = [t.detach().clone().requires_grad_(True) for t in (xproj, w_hh, h0, c0)]
     b_leaf = None if bias is None else bias.detach().clone().requires_grad_(True)
-    out, hT, cT = _LSTMSeq.apply(leaves[0], leaves[1], b_leaf, leaves[2], leaves[3], keep)
+    out, hT, cT = _LSTMSeq.apply(leaves[0], leaves[1], b_leaf, None, leaves[2], leaves[3], keep)
     assert out.dtype == torch.bfloat16 and out.shape == (G, T, B, H)
     loss = (out.float() * r_out).sum() + (hT.float() * r_h).sum() + (cT.float() * r_c).sum()
     loss.backward()
@@ -90,9 +90,9 @@ def test_inference_call_keeps_nothing_and_equals_the_training_forward():
     from as_cops_and_thieves_amd.selfplay.stacked import _LSTMSeq
     xproj, w_hh, h0, c0, keep = _case(3, 1, 4096, True, seed=3)
     with torch.no_grad():
-        o1, h1, c1 = _LSTMSeq.apply(xproj, w_hh, None, h0, c0, keep)
+        o1, h1, c1 = _LSTMSeq.apply(xproj, w_hh, None, None, h0, c0, keep)
     leaves = [t.detach().clone().requires_grad_(True) for t in (xproj, w_hh, h0, c0)]
-    o2, h2, c2 = _LSTMSeq.apply(leaves[0], leaves[1], None, leaves[2], leaves[3], keep)
+    o2, h2, c2 = _LSTMSeq.apply(leaves[0], leaves[1], None, None, leaves[2], leaves[3], keep)
     torch.cuda.synchronize()
     assert torch.equal(o1, o2) and torch.equal(h1, h2) and torch.equal(c1, c2) and torch.equal(o1[:, 0], h1)
 
@@ -106,7 +106,7 @@ def test_one_launch_per_direction_inside_a_hip_graph():
     ws = w_hh.detach().clone().requires_grad_(True)
 
     def step():
-        out, hT, cT = _LSTMSeq.apply(xs, ws, None, h0, c0, keep)
+        out, hT, cT = _LSTMSeq.apply(xs, ws, None, None, h0, c0, keep)
         gx, gw = torch.autograd.grad(out.float().square().sum(), (xs, ws))
         return out, gx, gw
     s = torch.cuda.Stream()
