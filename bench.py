@@ -7,7 +7,8 @@ with the tick, ONE tick_kernel launch.  Workload =
 BASELINE.json configs[1]: 2 cops vs 1 thief, labyrinth map, 4096 envs per GPU, 64 rays/agent.
 Env slots shard across GPUs with no data-path collective (weak scaling); only the timing uses a
 barrier + MAX all-reduce.  Prints ONE JSON line on rank 0; at N = 1 it also carries `extra`: the other
-BASELINE shapes measured in the same run (kernel_ms each), the headline stays configs[1].
+BASELINE shapes measured in the same run (kernel_ms each) and the learner's collect + update rate on the headline workload
+(SURVEY 8f rank 2); the headline stays configs[1].
 """
 from __future__ import annotations
 
@@ -146,6 +147,36 @@ def timed_steps(sim, steps: int, warmup: int, fence, hip: "HipEvents"):
     return elapsed, sum(hip.elapsed_ms(a, b) for a, b in ev.values()) / len(ev), len(ev)
 
 
+def learner_throughput(map_name: str, n_envs: int, rays: int) -> dict:
+    """SURVEY 8(f) rank 2 beside the headline: env-steps/s of the MAPPO trainer on the same env workload -- rollout
+    collection (env tick + the six stacked LSTM networks per tick) plus the PPO update of ``CFG_AGENT`` (4 epochs x 4
+    minibatches), both as replayed HIP graphs over libcat_learn.so.  3 untimed rollout+update rounds (the graphs are
+    captured there), then 5 timed ones.  A failure is reported, not raised: the headline does not depend on it."""
+    import time
+    import torch
+    try:
+        from as_cops_and_thieves_amd import VecCopsEnv, load_preset
+        from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, TrainerConfig
+        env = VecCopsEnv(load_preset(map_name), num_envs=n_envs, num_rays=rays, max_step_count=400)
+        tr = MAPPOTrainer(env, None, TrainerConfig(), seed=0)
+        for _ in range(3):
+            tr.collect(); tr.update()
+        torch.cuda.synchronize()
+        rounds, tc, tu = 5, 0.0, 0.0
+        for _ in range(rounds):
+            t0 = time.perf_counter(); tr.collect(); torch.cuda.synchronize(); t1 = time.perf_counter()
+            tr.update(); torch.cuda.synchronize(); t2 = time.perf_counter()
+            tc += t1 - t0; tu += t2 - t1
+        steps = rounds * tr.tcfg.horizon * n_envs
+        out = {"value": steps / (tc + tu), "unit": "env-steps/s", "rounds": rounds, "horizon": tr.tcfg.horizon,
+               "collect_ms": 1e3 * tc / rounds, "update_ms": 1e3 * tu / rounds, "dtype": "bf16",
+               "graphs": bool(tr._graph is not None and all(rl._graphs for rl in tr.roles.values()))}
+        env.close()
+        return out
+    except Exception as exc:   # noqa: BLE001
+        return {"value": None, "error": repr(exc)[:200]}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +272,7 @@ def main() -> None:
                             "ms_per_step": 1e3 * e2 / k_steps, "kernel_ms": k2,
                             "roofline_frac": bytes2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
             s2.close()
+        extra["learner_collect_plus_update"] = learner_throughput(args.map, cfg.n_envs, args.rays)
     if rank == 0:
         A, R = cfg.n_agents, cfg.n_rays
         bytes_launch = algorithmic_bytes_per_env_step(A, R) * cfg.n_envs
