@@ -61,7 +61,8 @@ class TrunkBwd(C.Structure):
                 ("part_dw1", C.c_void_p), ("part_db1", C.c_void_p), ("part_dw2", C.c_void_p), ("part_db2", C.c_void_p)]
 
 
-DENSE_SYMBOLS = ("cat_dense_abi_version", "cat_dense_last_error", "cat_dense_bias_act", "cat_dense_act_grad", "cat_dense_sum_chunks")
+DENSE_SYMBOLS = ("cat_dense_abi_version", "cat_dense_last_error", "cat_dense_bias_act", "cat_dense_act_grad", "cat_dense_sum_chunks",
+                 "cat_dense_wgrad_splits", "cat_dense_wgrad")
 PPO_SYMBOLS = ("cat_ppo_abi_version", "cat_ppo_last_error", "cat_ppo_loss_grad", "cat_ppo_adam_step")
 
 
@@ -149,6 +150,10 @@ def lib() -> C.CDLL:
         L.cat_dense_sum_chunks.restype = C.c_int
         L.cat_dense_sum_chunks.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                            C.c_int32, C.c_void_p]
+        L.cat_dense_wgrad_splits.restype = C.c_int
+        L.cat_dense_wgrad_splits.argtypes = [C.c_int32] * 4
+        L.cat_dense_wgrad.restype = C.c_int
+        L.cat_dense_wgrad.argtypes = [C.c_void_p, C.c_void_p]
         assert L.cat_dense_abi_version() == 1
         _lib = L
     return _lib
@@ -367,6 +372,34 @@ def sum_chunks(partial, dst=None, dst2=None, accumulate: bool = False):
     _check(lib().cat_dense_sum_chunks(partial.data_ptr(), G, chunks, n, dst.data_ptr(), dst.stride(0), _ptr(dst2),
                                       0 if dst2 is None else dst2.stride(0), 1 if accumulate else 0, _stream()), "cat_dense_sum_chunks")
     return dst
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("G", C.c_int32), ("K", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p),
+                ("partial", C.c_void_p), ("splits", C.c_int32), ("pad", C.c_int32)]
+
+
+def wgrad_supported(g, x) -> bool:
+    return g.shape[2] % 8 == 0 and x.shape[2] % 8 == 0 and g.shape[1] >= 512
+
+
+def dense_wgrad(g, x, slot=None):
+    """g bf16 [G, K, M] (gradient of a layer's pre-activations), x bf16 [G, K, N] (its input) -> sum_k g[k, m] x[k, n] as
+    bf16 [G, M, N]: ADDED into ``slot`` (a [G, M, N] view whose [M, N] blocks are contiguous) when given, else returned."""
+    import torch
+    G, K, M = g.shape
+    N = x.shape[2]
+    g, x = g.contiguous(), x.contiguous()
+    assert g.dtype == x.dtype == torch.bfloat16 and x.shape[:2] == (G, K)
+    S = lib().cat_dense_wgrad_splits(G, K, M, N)
+    partial = torch.empty(G, S, M * N, dtype=torch.float32, device=g.device)
+    a = WgradArgs(G, K, M, N, g.data_ptr(), x.data_ptr(), partial.data_ptr(), S, 0)
+    _check(lib().cat_dense_wgrad(C.byref(a), _stream()), "cat_dense_wgrad")
+    if slot is not None:
+        assert slot.shape == (G, M, N) and slot[0].is_contiguous()
+        sum_chunks(partial, slot.view(G, M * N) if slot.is_contiguous() else slot.as_strided((G, M * N), (slot.stride(0), 1)), accumulate=True)
+        return None
+    return sum_chunks(partial).view(G, M, N)
 
 
 _ONES = {}

@@ -132,6 +132,97 @@ __global__ __launch_bounds__(BLOCK) void sum_chunks_kernel(const float *partial,
     }
 }
 
+// ---- weight gradient: C[m][n] = sum_k A[k][m] B[k][n], both operands stored with the reduction index k as the ROW.
+// 128 x 128 output tile per workgroup, 4 waves of 64 x 64 (16 accumulator tiles), the K rows split over blockIdx.y.
+// The operands go global -> LDS as they lie (coalesced 16-byte runs of a row) and come back as MFMA fragments through
+// ds_read_b64_tr_b16, the hardware transposed read: a 16-lane group reads a 4-row x 16-column block and each lane
+// receives one COLUMN of it -- the four k values of its m (or n).  A fragment's eight k's are rows {4q..4q+3} and
+// {16+4q..16+4q+3} of the 32-row step (the same permutation for A and B, so the product is unchanged): with a row
+// stride of 288 B the two groups of a 32-lane half then sit in disjoint banks.
+constexpr int WG_BM = 128, WG_BN = 128, WG_BK = 32, WG_LD = 144;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16 *tile, int row0, int col0)
+{
+    // this lane supplies the address of row (row0 + (i >> 2)), columns col0 + 4 (i & 3), i = lane % 16
+    const int i = threadIdx.x & 15;
+    const __bf16 *p0 = tile + (row0 + (i >> 2)) * WG_LD + col0 + 4 * (i & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0 + 16 * WG_LD));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(BLOCK) void wgrad_kernel(const cat_dense_wgrad_args a)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 sa[2][WG_BK * WG_LD], sb[2][WG_BK * WG_LD];
+    const int tiles_n = (a.N + WG_BN - 1) / WG_BN;
+    const int m0 = (blockIdx.x / tiles_n) * WG_BM, n0 = (blockIdx.x % tiles_n) * WG_BN, split = blockIdx.y, g = blockIdx.z;
+    const int rows_per = ((a.K + a.splits - 1) / a.splits + WG_BK - 1) / WG_BK * WG_BK;
+    const int k0 = split * rows_per, k1 = min(a.K, k0 + rows_per);
+    const int lr = threadIdx.x >> 4, lc = threadIdx.x & 15;
+    const __bf16 *A = (const __bf16 *)a.a + (size_t)g * a.K * a.M, *B = (const __bf16 *)a.b + (size_t)g * a.K * a.N;
+    const bf16x8 z8 = {};
+    bf16x8 ra[2], rb[2];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = kb + lr + 16 * h;
+            ra[h] = (row < k1 && m0 + 8 * lc < a.M) ? *(const bf16x8 *)(A + (size_t)row * a.M + m0 + 8 * lc) : z8;
+            rb[h] = (row < k1 && n0 + 8 * lc < a.N) ? *(const bf16x8 *)(B + (size_t)row * a.N + n0 + 8 * lc) : z8;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *(bf16x8 *)&sa[buf][(lr + 16 * h) * WG_LD + 8 * lc] = ra[h];
+            *(bf16x8 *)&sb[buf][(lr + 16 * h) * WG_LD + 8 * lc] = rb[h];
+        }
+    };
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, r = l & 15, wm = w >> 1, wn = w & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = (k1 - k0 + WG_BK - 1) / WG_BK;        // <= 0 for an empty split: the slab is written as zeros
+    if (nk > 0) {
+        gload(k0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nk) gload(k0 + WG_BK * (it + 1));
+        bf16x8 af[4], bf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            af[t] = tr_frag(sa[buf], 4 * q, wm * 64 + 16 * t);
+            bf[t] = tr_frag(sb[buf], 4 * q, wn * 64 + 16 * t);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if (it + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    float *out = a.partial + ((size_t)g * a.splits + split) * a.M * a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + wm * 64 + 16 * i + 4 * q + e;
+            if (m < a.M)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + 16 * j + r;
+                    if (n < a.N) out[(size_t)m * a.N + n] = acc[i][j][e];
+                }
+        }
+}
+
 thread_local char g_err[256] = "";
 int fail(int code, const char *msg)
 {
@@ -183,6 +274,30 @@ extern "C" int cat_dense_sum_chunks(const float *partial, int32_t G, int32_t chu
         return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_sum_chunks: bad dimensions or NULL buffer");
     hipLaunchKernelGGL(sum_chunks_kernel, dim3((n + 31) / 32, G), dim3(BLOCK), 0, (hipStream_t)stream, partial, chunks, n,
                        (__bf16 *)dst0, sd0_g, (__bf16 *)dst1, sd1_g, accumulate);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_DENSE_OK : fail(CAT_DENSE_ERR_HIP, hipGetErrorString(e));
+}
+
+extern "C" int cat_dense_wgrad_splits(int32_t G, int32_t K, int32_t M, int32_t N)
+{
+    if (G <= 0 || K <= 0 || M <= 0 || N <= 0) return CAT_DENSE_ERR_BAD_ARG;
+    const int tiles = G * ((M + WG_BM - 1) / WG_BM) * ((N + WG_BN - 1) / WG_BN);
+    int s = (512 + tiles - 1) / tiles;                     // about two workgroups per CU
+    const int by_rows = K / 128 > 0 ? K / 128 : 1;         // at least four 32-row steps per split
+    if (s > by_rows) s = by_rows;
+    if (s > CAT_DENSE_MAX_CHUNKS) s = CAT_DENSE_MAX_CHUNKS;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int cat_dense_wgrad(const cat_dense_wgrad_args *a, void *stream)
+{
+    if (!a || a->G <= 0 || a->G > 65535 || a->K <= 0 || a->M <= 0 || a->N <= 0 || (a->M % 8) || (a->N % 8) || a->splits <= 0 ||
+        a->splits > CAT_DENSE_MAX_CHUNKS)
+        return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_wgrad: bad dimensions (M and N must be multiples of 8)");
+    if (!a->a || !a->b || !a->partial || ((uintptr_t)a->a % 16) || ((uintptr_t)a->b % 16))
+        return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_wgrad: NULL or misaligned buffer");
+    const int tiles = ((a->M + WG_BM - 1) / WG_BM) * ((a->N + WG_BN - 1) / WG_BN);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, a->splits, a->G), dim3(BLOCK), 0, (hipStream_t)stream, *a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAT_DENSE_OK : fail(CAT_DENSE_ERR_HIP, hipGetErrorString(e));
 }

@@ -70,6 +70,18 @@ def _grad_slot(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return p.grad
 
 
+def _weight_grad(g: torch.Tensor, x: torch.Tensor, slot: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """sum over the rows of g[:, k, :]^T x[:, k, :] for the G stacked layers (bf16 on the GPU): added into ``slot`` (returns
+    None) or returned.  The reduction runs over tens of thousands of rows into a small matrix: ``csrc/cat_dense.hip``'s
+    split-K kernel where its tiling applies, the library GEMM otherwise (tiny heads)."""
+    if _learn_native.wgrad_supported(g, x):
+        return _learn_native.dense_wgrad(g, x, slot)
+    if slot is not None:
+        slot.baddbmm_(g.transpose(1, 2), x)
+        return None
+    return torch.bmm(g.transpose(1, 2), x)
+
+
 class _LSTMSeq(torch.autograd.Function):
     """h_t, c_t = cell(xproj[:, t] + h_{t-1} W_hh^T, c_{t-1}) for t = 0..T-1, with the state zeroed where ``keep[t]`` is 0
     (an episode starts at step t).  xproj [G, T, B, 4H]; w_hh [G, 4H, H]; b_ih, b_hh [G, 4H]: their sum is added to every
@@ -152,11 +164,7 @@ class _LSTMSeq(torch.autograd.Function):
             dg_all = torch.stack(dgs, 1)                                          # [G, T, B, 4H] = d xproj
         a = dg_all.reshape(G, T * B, dg_all.shape[3])
         hin = h_in.reshape(G, T * B, h_in.shape[3])
-        if w_slot is not None:
-            w_slot.baddbmm_(a.transpose(1, 2), hin)                                   # one GEMM over all steps, into the slot
-            d_w = None
-        else:
-            d_w = torch.bmm(a.transpose(1, 2), hin)
+        d_w = _weight_grad(a, hin, w_slot) if ctx.native else torch.bmm(a.transpose(1, 2), hin)   # one product over all steps
         return dg_all, d_w, d_bih, d_bhh, dh, dc, None
 
 
@@ -282,12 +290,7 @@ class _LinAct(torch.autograd.Function):
             else:
                 db = _learn_native.sum_chunks(part)
         dx = torch.bmm(g, w) if ctx.needs_input_grad[0] else None
-        if w_slot is not None:
-            w_slot.baddbmm_(g.transpose(1, 2), x)
-            dw = None
-        else:
-            dw = torch.bmm(g.transpose(1, 2), x)
-        return dx, dw, db, None
+        return dx, _weight_grad(g, x, w_slot), db, None
 
 
 def _lin_act(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int) -> torch.Tensor:

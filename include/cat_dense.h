@@ -44,6 +44,19 @@ int cat_dense_act_grad(const cat_dense_dims *d, const void *d_y, const void *y, 
 int cat_dense_sum_chunks(const float *partial, int32_t G, int32_t chunks, int32_t n, void *dst0, int64_t sd0_g, void *dst1,
                          int64_t sd1_g, int32_t accumulate, void *stream);
 
+/* The weight gradient of a dense layer: partial[g][s][m][n] = sum over the rows k of split s of a[g][k][m] * b[g][k][n]
+   (a = the gradient w.r.t. the layer's pre-activations [G][K][M], b = the layer's input [G][K][N], both bf16 contiguous,
+   M and N multiples of 8); fp32 slabs, one per split of the K rows, which cat_dense_sum_chunks adds up (into the bf16
+   gradient).  splits = cat_dense_wgrad_splits(...) (enough workgroups to fill the device), at most CAT_DENSE_MAX_CHUNKS. */
+typedef struct cat_dense_wgrad_args {
+    int32_t G, K, M, N;
+    const void *a, *b;
+    float *partial;             /* [G][splits][M][N] */
+    int32_t splits, pad;
+} cat_dense_wgrad_args;
+int cat_dense_wgrad_splits(int32_t G, int32_t K, int32_t M, int32_t N);
+int cat_dense_wgrad(const cat_dense_wgrad_args *a, void *stream);
+
 int cat_dense_abi_version(void);
 const char *cat_dense_last_error(void);
 

@@ -30,3 +30,25 @@ def test_bias_act_and_its_gradient_match_torch(G, M, out, act):
     assert torch.allclose(g.float(), g_want, rtol=2 ** -7, atol=1e-6)
     assert torch.allclose(db, g.float().sum(1), rtol=2 ** -7, atol=2e-2)
     assert torch.allclose(slot[:, 4:4 + out].float(), 1 + g.float().sum(1), rtol=2 ** -7, atol=2e-2) and bool((slot[:, :4] == 1).all())
+
+
+@pytest.mark.parametrize("G,K,M,N", [(3, 16384, 512, 256), (3, 16384, 256, 288), (2, 5000, 64, 128), (1, 777, 128, 64), (3, 16384, 512, 128),
+                                     (2, 1000, 8, 8), (3, 4096, 136, 72)])
+def test_weight_gradient_kernel_matches_a_gemm_in_fp32(G, K, M, N):
+    """sum_k g[k, m] x[k, n] through the split-K MFMA kernel (transposed LDS reads) against torch.bmm in fp32 on the same
+    bf16 inputs; asymmetric random data, ragged tiles (M, N not multiples of 128; K not a multiple of 32).  The result is
+    stored as bf16: 2^-8 relative + the fp32 accumulation-order difference."""
+    import torch
+    from as_cops_and_thieves_amd import _learn_native as ln
+    gen = torch.Generator(device="cuda").manual_seed(K + M)
+    g = torch.randn(G, K, M, generator=gen, device="cuda").to(torch.bfloat16)
+    x = (torch.randn(G, K, N, generator=gen, device="cuda") + 0.5).to(torch.bfloat16)
+    want = torch.bmm(g.float().transpose(1, 2), x.float())
+    got = ln.dense_wgrad(g, x)
+    scale = float(want.abs().max())
+    assert got.shape == (G, M, N) and float((got.float() - want).abs().max()) <= 2 ** -7 * scale
+    flat = torch.ones(G, M * N + 16, device="cuda", dtype=torch.bfloat16)          # accumulate into a row-strided slot
+    slot = flat[:, 8:8 + M * N].view(G, M, N)
+    assert ln.dense_wgrad(g, x, slot) is None
+    torch.cuda.synchronize()
+    assert float((slot.float() - (1 + want)).abs().max()) <= 2 ** -6 * scale and bool((flat[:, :8] == 1).all())
