@@ -380,7 +380,7 @@ class WgradArgs(C.Structure):
 
 
 def wgrad_supported(g, x) -> bool:
-    return g.shape[2] % 8 == 0 and x.shape[2] % 8 == 0 and g.shape[1] >= 512
+    return g.shape[1] >= 512
 
 
 def dense_wgrad(g, x, slot=None):

@@ -165,12 +165,21 @@ __global__ __launch_bounds__(BLOCK) void wgrad_kernel(const cat_dense_wgrad_args
     const __bf16 *A = (const __bf16 *)a.a + (size_t)g * a.K * a.M, *B = (const __bf16 *)a.b + (size_t)g * a.K * a.N;
     const bf16x8 z8 = {};
     bf16x8 ra[2], rb[2];
+    const bool vec_a = a.M % 8 == 0, vec_b = a.N % 8 == 0;     // rows of 16-byte runs; else (tiny heads) element by element
+    auto row_run = [&](const __bf16 *base, int width, int col, bool vec) -> bf16x8 {
+        if (vec) return col < width ? *(const bf16x8 *)(base + col) : z8;
+        bf16x8 v = z8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (col + j < width) v[j] = base[col + j];
+        return v;
+    };
     auto gload = [&](int kb) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int row = kb + lr + 16 * h;
-            ra[h] = (row < k1 && m0 + 8 * lc < a.M) ? *(const bf16x8 *)(A + (size_t)row * a.M + m0 + 8 * lc) : z8;
-            rb[h] = (row < k1 && n0 + 8 * lc < a.N) ? *(const bf16x8 *)(B + (size_t)row * a.N + n0 + 8 * lc) : z8;
+            ra[h] = row < k1 ? row_run(A + (size_t)row * a.M, a.M, m0 + 8 * lc, vec_a) : z8;
+            rb[h] = row < k1 ? row_run(B + (size_t)row * a.N, a.N, n0 + 8 * lc, vec_b) : z8;
         }
     };
     auto lstore = [&](int buf) {
@@ -291,10 +300,9 @@ extern "C" int cat_dense_wgrad_splits(int32_t G, int32_t K, int32_t M, int32_t N
 
 extern "C" int cat_dense_wgrad(const cat_dense_wgrad_args *a, void *stream)
 {
-    if (!a || a->G <= 0 || a->G > 65535 || a->K <= 0 || a->M <= 0 || a->N <= 0 || (a->M % 8) || (a->N % 8) || a->splits <= 0 ||
-        a->splits > CAT_DENSE_MAX_CHUNKS)
-        return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_wgrad: bad dimensions (M and N must be multiples of 8)");
-    if (!a->a || !a->b || !a->partial || ((uintptr_t)a->a % 16) || ((uintptr_t)a->b % 16))
+    if (!a || a->G <= 0 || a->G > 65535 || a->K <= 0 || a->M <= 0 || a->N <= 0 || a->splits <= 0 || a->splits > CAT_DENSE_MAX_CHUNKS)
+        return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_wgrad: bad dimensions");
+    if (!a->a || !a->b || !a->partial || ((a->M % 8 == 0) && ((uintptr_t)a->a % 16)) || ((a->N % 8 == 0) && ((uintptr_t)a->b % 16)))
         return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_wgrad: NULL or misaligned buffer");
     const int tiles = ((a->M + WG_BM - 1) / WG_BM) * ((a->N + WG_BN - 1) / WG_BN);
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, a->splits, a->G), dim3(BLOCK), 0, (hipStream_t)stream, *a);

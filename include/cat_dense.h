@@ -45,8 +45,8 @@ int cat_dense_sum_chunks(const float *partial, int32_t G, int32_t chunks, int32_
                          int64_t sd1_g, int32_t accumulate, void *stream);
 
 /* The weight gradient of a dense layer: partial[g][s][m][n] = sum over the rows k of split s of a[g][k][m] * b[g][k][n]
-   (a = the gradient w.r.t. the layer's pre-activations [G][K][M], b = the layer's input [G][K][N], both bf16 contiguous,
-   M and N multiples of 8); fp32 slabs, one per split of the K rows, which cat_dense_sum_chunks adds up (into the bf16
+   (a = the gradient w.r.t. the layer's pre-activations [G][K][M], b = the layer's input [G][K][N], both bf16 contiguous;
+   16-byte aligned when their width is a multiple of 8, else read element by element); fp32 slabs, one per split of the K rows, which cat_dense_sum_chunks adds up (into the bf16
    gradient).  splits = cat_dense_wgrad_splits(...) (enough workgroups to fill the device), at most CAT_DENSE_MAX_CHUNKS. */
 typedef struct cat_dense_wgrad_args {
     int32_t G, K, M, N;

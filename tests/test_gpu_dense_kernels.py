@@ -33,7 +33,7 @@ def test_bias_act_and_its_gradient_match_torch(G, M, out, act):
 
 
 @pytest.mark.parametrize("G,K,M,N", [(3, 16384, 512, 256), (3, 16384, 256, 288), (2, 5000, 64, 128), (1, 777, 128, 64), (3, 16384, 512, 128),
-                                     (2, 1000, 8, 8), (3, 4096, 136, 72)])
+                                     (2, 1000, 8, 8), (3, 4096, 136, 72), (3, 16384, 4, 64), (3, 16384, 1, 64), (2, 3000, 5, 12)])
 def test_weight_gradient_kernel_matches_a_gemm_in_fp32(G, K, M, N):
     """sum_k g[k, m] x[k, n] through the split-K MFMA kernel (transposed LDS reads) against torch.bmm in fp32 on the same
     bf16 inputs; asymmetric random data, ragged tiles (M, N not multiples of 128; K not a multiple of 32).  The result is
