@@ -11,8 +11,8 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 LIB_PATH = PKG / "libcat_learn.so"
-SOURCES = tuple(PKG / "csrc" / f"cat_{n}.hip" for n in ("lstm", "trunk", "ppo", "dense"))
-HEADERS = tuple(ROOT / "include" / f"cat_{n}.h" for n in ("lstm", "trunk", "ppo", "dense"))
+SOURCES = tuple(PKG / "csrc" / f"cat_{n}.hip" for n in ("lstm", "trunk", "ppo", "dense", "rollout"))
+HEADERS = tuple(ROOT / "include" / f"cat_{n}.h" for n in ("lstm", "trunk", "ppo", "dense", "rollout"))
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared"]
 HIDDEN = 128
 EXPORTED_SYMBOLS = ("cat_lstm_abi_version", "cat_lstm_last_error", "cat_lstm_blocks", "cat_lstm_saved_acts_bytes", "cat_lstm_saved_cell_bytes",
@@ -61,6 +61,7 @@ class TrunkBwd(C.Structure):
                 ("part_dw1", C.c_void_p), ("part_db1", C.c_void_p), ("part_dw2", C.c_void_p), ("part_db2", C.c_void_p)]
 
 
+ROLLOUT_SYMBOLS = ("cat_rollout_abi_version", "cat_rollout_last_error", "cat_rollout_pack", "cat_rollout_sample")
 DENSE_SYMBOLS = ("cat_dense_abi_version", "cat_dense_last_error", "cat_dense_bias_act", "cat_dense_act_grad", "cat_dense_sum_chunks",
                  "cat_dense_wgrad_splits", "cat_dense_wgrad")
 PPO_SYMBOLS = ("cat_ppo_abi_version", "cat_ppo_last_error", "cat_ppo_loss_grad", "cat_ppo_adam_step")
@@ -155,6 +156,12 @@ def lib() -> C.CDLL:
         L.cat_dense_wgrad.restype = C.c_int
         L.cat_dense_wgrad.argtypes = [C.c_void_p, C.c_void_p]
         assert L.cat_dense_abi_version() == 1
+        L.cat_rollout_abi_version.restype = C.c_int
+        L.cat_rollout_last_error.restype = C.c_char_p
+        for n in ("cat_rollout_pack", "cat_rollout_sample"):
+            getattr(L, n).restype = C.c_int
+            getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
+        assert L.cat_rollout_abi_version() == 1
         _lib = L
     return _lib
 
@@ -162,7 +169,8 @@ def lib() -> C.CDLL:
 def _check(rc: int, what: str) -> None:
     if rc != 0:
         err = (lib().cat_trunk_last_error() if "trunk" in what else lib().cat_ppo_last_error() if "ppo" in what
-               else lib().cat_dense_last_error() if "dense" in what else lib().cat_lstm_last_error())
+               else lib().cat_dense_last_error() if "dense" in what else lib().cat_rollout_last_error() if "rollout" in what
+               else lib().cat_lstm_last_error())
         raise RuntimeError(f"{what} failed ({rc}): {err.decode()}")
 
 
@@ -412,3 +420,50 @@ def ones_row(G: int, n: int, device):
     if key not in _ONES:
         _ONES[key] = torch.ones(G, 1, n, dtype=torch.float32, device=device)
     return _ONES[key]
+
+
+# ---------------------------------------------------------------------------------------------- rollout tick glue
+class PackArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("A", C.c_int32), ("R", C.c_int32), ("G", C.c_int32), ("agent", C.c_int32 * 8),
+                ("n_cops", C.c_int32), ("first_agent_state", C.c_int32), ("distance_scale", C.c_float), ("type_scale", C.c_float),
+                ("obs_distance", C.c_void_p), ("obs_type", C.c_void_p), ("shared_distance", C.c_void_p), ("shared_type", C.c_void_p),
+                ("policy_in", C.c_void_p), ("sp_g", C.c_int64), ("sp_n", C.c_int64),
+                ("value_in", C.c_void_p), ("sv_g", C.c_int64), ("sv_n", C.c_int64)]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("A", C.c_int32), ("G", C.c_int32), ("pad", C.c_int32), ("agent", C.c_int32 * 8),
+                ("logits", C.c_void_p), ("uniform", C.c_void_p), ("values", C.c_void_p),
+                ("act_out", C.c_void_p), ("logp_out", C.c_void_p), ("value_out", C.c_void_p), ("sa_g", C.c_int64), ("sl_g", C.c_int64),
+                ("actions", C.c_void_p)]
+
+
+def rollout_pack(raw, agent_indices, n_cops: int, first_agent_state: bool, distance_scale: float, type_scale: float, policy_in, value_in):
+    """raw = the env core's output buffers (``VecCopsEnv.raw_outputs()``) -> policy_in bf16 [G, N, 2R], value_in bf16
+    [G, N, 4R] (views with contiguous rows and any outer strides)."""
+    import torch
+    od, ot, sd, st = raw["obs_distance"], raw["obs_type"], raw["shared_distance"], raw["shared_type"]
+    N, A, R = od.shape
+    G = len(agent_indices)
+    assert od.dtype == torch.float16 and ot.dtype == torch.uint8 and all(t.is_contiguous() for t in (od, ot, sd, st))
+    for t, w in ((policy_in, 2 * R), (value_in, 4 * R)):
+        assert t.dtype == torch.bfloat16 and t.shape == (G, N, w) and t.stride(2) == 1
+    a = PackArgs(N, A, R, G, (C.c_int32 * 8)(*agent_indices), n_cops, 1 if first_agent_state else 0, distance_scale, type_scale,
+                 od.data_ptr(), ot.data_ptr(), sd.data_ptr(), st.data_ptr(), policy_in.data_ptr(), policy_in.stride(0), policy_in.stride(1),
+                 value_in.data_ptr(), value_in.stride(0), value_in.stride(1))
+    _check(lib().cat_rollout_pack(C.byref(a), _stream()), "cat_rollout_pack")
+
+
+def rollout_sample(logits, uniform, values, act_out, logp_out, value_out, actions, agent_indices) -> None:
+    """logits bf16 [G, N, 4]; uniform fp32 [G, N]; values bf16 [G, N] or None; act_out int64 / logp_out, value_out fp32
+    [G, N] row-strided views; actions int32 [N, A]: column ``agent_indices[g]`` receives agent g's draw."""
+    import torch
+    G, N, _ = logits.shape
+    assert logits.dtype == torch.bfloat16 and logits.is_contiguous() and uniform.dtype == torch.float32 and uniform.is_contiguous()
+    assert act_out.dtype == torch.int64 and act_out.stride(1) == 1 and logp_out.dtype == torch.float32 and logp_out.stride(1) == 1
+    assert actions.dtype == torch.int32 and actions.is_contiguous() and actions.shape[0] == N
+    if value_out is not None:
+        assert values.dtype == torch.bfloat16 and values.is_contiguous() and value_out.stride(0) == logp_out.stride(0) and value_out.stride(1) == 1
+    a = SampleArgs(N, actions.shape[1], G, 0, (C.c_int32 * 8)(*agent_indices), logits.data_ptr(), uniform.data_ptr(), _ptr(values),
+                   act_out.data_ptr(), logp_out.data_ptr(), _ptr(value_out), act_out.stride(0), logp_out.stride(0), actions.data_ptr())
+    _check(lib().cat_rollout_sample(C.byref(a), _stream()), "cat_rollout_sample")

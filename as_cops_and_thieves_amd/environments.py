@@ -359,6 +359,12 @@ class VecCopsEnv:
                         "team_positions": o["team_positions"][:, sl]}
         return res
 
+    def raw_outputs(self) -> Dict[str, torch.Tensor]:
+        """The env core's output buffers as they lie on the device (``include/cat_sim.h`` ``cat_outputs``: f16 distances,
+        u8 types, [N, A, R] / [N, 2, R]): what ``_obs()`` / ``state()`` slice per agent, for callers that pack the model
+        inputs themselves (``include/cat_rollout.h``)."""
+        return self._sim.out
+
     def random_actions(self, tick: int) -> torch.Tensor:
         return self._sim.random_actions(tick, out=self._actions)
 

@@ -178,7 +178,8 @@ class RoleLearner:
         B = S // cfg.mini_batches
         self.B = B
         self.idx = torch.zeros(B, dtype=torch.long, device=device)
-        self.buf = {"pin": torch.zeros(G, T, N, 2 * R, **f32), "vin": torch.zeros(G, T, N, 4 * R, **f32),
+        in_dt = dict(dtype=compute_dtype if self.native else torch.float32, device=device)   # the networks cast to it anyway
+        self.buf = {"pin": torch.zeros(G, T, N, 2 * R, **in_dt), "vin": torch.zeros(G, T, N, 4 * R, **in_dt),
                     "act": torch.zeros(G, T, N, dtype=torch.long, device=device), "logp": torch.zeros(G, T, N, **f32),
                     "val": torch.zeros(G, T, N, **f32), "rew": torch.zeros(G, T, N, **f32),
                     "adv": torch.zeros(G, T, N, **f32), "ret": torch.zeros(G, T, N, **f32)}
@@ -402,13 +403,25 @@ class MAPPOTrainer:
         self._done_buf = torch.zeros(T, self.N, dtype=torch.bool, device=self.device)
         self._start_buf = torch.zeros(T, self.N, dtype=torch.bool, device=self.device)
         self._actions = torch.zeros(self.N, len(self.agents), dtype=torch.int32, device=self.device)
+        self._native_io = on_gpu and hasattr(env, "raw_outputs")   # cat_rollout.h: packing and sampling in one launch each
         self._graph = None
         self._eager_rollouts = 0
         self.stats: Dict[str, float] = {}
         self.use_graphs = on_gpu
 
     # ------------------------------------------------------------------ model inputs (packing.py layouts)
+    def _pack_native(self, rl: RoleLearner, pin: torch.Tensor, vin: torch.Tensor) -> None:
+        """The same rows as ``_inputs`` straight from the env core's buffers into bf16 ``pin`` / ``vin`` (one launch)."""
+        d, t = (1.0 / 400.0, 0.25) if self.tcfg.normalize_inputs else (1.0, 1.0)
+        _learn_native.rollout_pack(self.env.raw_outputs(), rl.indices, sum(a.startswith("cop") for a in self.agents),
+                                   self.tcfg.reference_q11, d, t, pin, vin)
+
     def _inputs(self, rl: RoleLearner, obs, state) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._native_io and rl.native:
+            pin = torch.empty(rl.G, self.N, 2 * self.R, dtype=torch.bfloat16, device=self.device)
+            vin = torch.empty(rl.G, self.N, 4 * self.R, dtype=torch.bfloat16, device=self.device)
+            self._pack_native(rl, pin, vin)
+            return pin, vin
         pin = torch.stack([packing.pack_policy_input(obs[a]) for a in rl.agents])                       # [G, N, 2R]
         first = sorted(state)[0]
         vin = torch.stack([packing.pack_agent_state(state[first if self.tcfg.reference_q11 else a])[:, :4 * self.R]
@@ -430,11 +443,22 @@ class MAPPOTrainer:
                 if t % rl.bptt == 0:                # the recurrent state at the start of a BPTT window is kept
                     for dst, src in zip(rl.p0w + rl.v0w, rl.p_state + rl.v_state):
                         dst[t // rl.bptt].copy_(src)
-                pin, vin = self._inputs(rl, self._obs, state)
+                b = rl.buf
+                fused = self._native_io and rl.native and not random_actions and rl.random_rows is None
+                if fused:   # rows packed straight into the rollout buffers; the networks read them there
+                    pin, vin = b["pin"][:, t], b["vin"][:, t]
+                    self._pack_native(rl, pin, vin)
+                else:
+                    pin, vin = self._inputs(rl, self._obs, state)
                 logits, p_new = rl.policy.forward(pin.unsqueeze(1), rl.p_state, keep)
                 val, v_new = rl.value.forward(vin.unsqueeze(1), rl.v_state, keep)
                 for old, new in zip(rl.p_state + rl.v_state, p_new + v_new):
                     old.copy_(new)
+                if fused:   # draw, log-probability, value and the env's action columns in one launch
+                    u = torch.rand(rl.G, N, device=self.device)
+                    _learn_native.rollout_sample(logits[:, 0].contiguous(), u, val[:, 0, :, 0].contiguous(), b["act"][:, t], b["logp"][:, t],
+                                                 b["val"][:, t], self._actions, rl.indices)
+                    continue
                 logp_all = torch.log_softmax(logits[:, 0].float(), dim=-1)                               # [G, N, 4]
                 if random_actions:
                     act = torch.randint(0, 4, (rl.G, N), generator=self._gen).to(self.device)
@@ -442,7 +466,6 @@ class MAPPOTrainer:
                     act = _sample(logp_all)
                     if rl.random_rows is not None:   # rows of the roles in TrainerConfig.random_action_roles
                         act = torch.where(rl.random_rows, torch.randint(0, 4, (rl.G, N), device=self.device), act)
-                b = rl.buf
                 b["pin"][:, t].copy_(pin); b["vin"][:, t].copy_(vin); b["act"][:, t].copy_(act)
                 b["logp"][:, t].copy_(logp_all.gather(-1, act.unsqueeze(-1)).squeeze(-1))
                 b["val"][:, t].copy_(val[:, 0, :, 0].float())

@@ -52,6 +52,7 @@ def test_lstm_library_exports_every_declared_symbol_and_struct_layouts_match():
     ("cat_trunk.h", "cat_trunk_", "TRUNK_SYMBOLS", {"cat_trunk_dims": "TrunkDims", "cat_trunk_params": "TrunkParams", "cat_trunk_fwd": "TrunkFwd",
                                                     "cat_trunk_bwd": "TrunkBwd"}),
     ("cat_ppo.h", "cat_ppo_", "PPO_SYMBOLS", {"cat_ppo_loss": "PpoLoss", "cat_ppo_adam": "PpoAdam"}),
+    ("cat_rollout.h", "cat_rollout_", "ROLLOUT_SYMBOLS", {"cat_rollout_pack_args": "PackArgs", "cat_rollout_sample_args": "SampleArgs"}),
     ("cat_dense.h", "cat_dense_", "DENSE_SYMBOLS", {"cat_dense_dims": "DenseDims", "cat_dense_wgrad_args": "WgradArgs"})])
 def test_learner_kernel_headers_match_the_library_and_the_ctypes_mirror(header, prefix, symbols, structs):
     from as_cops_and_thieves_amd import _learn_native as ln
@@ -62,6 +63,7 @@ def test_learner_kernel_headers_match_the_library_and_the_ctypes_mirror(header, 
     assert set(declared) == set(getattr(ln, symbols)) and all(hasattr(L, s) for s in declared)
     for struct, cls in structs.items():
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), code, re.S).group(1)
+        body = re.sub(r"\[[^\]]*\]", "", body)                                  # array extents
         names = [n for decl in body.split(";") for n in re.findall(r"\b([A-Za-z_0-9]+)\s*(?=,|$)", decl.strip())]
         assert names == [f[0] for f in getattr(ln, cls)._fields_], (struct, names)
 
