@@ -96,15 +96,28 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_fwd_kernel(const cat_lstm_
     }
     __syncthreads();
 
+    // the input-side pre-activations and the keep flag of step t + 1 are fetched while step t computes: the recurrence
+    // is a chain of T dependent steps, and a global-memory round trip at the head of each would be most of its length
+    bf16x4 xn[4][2];
+    float kn_next = 1.0f;
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                xn[gt][hh] = (row_ok && t < T) ? *(const bf16x4 *)(xg + (size_t)t * a.sx_t + gt * H + hid0 + 16 * hh) : zero4();
+        kn_next = (a.keep && row_ok && t + 1 < T) ? a.keep[(size_t)(t + 1) * B + b] : 1.0f;
+    };
+    fetch(0);
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
         f32x4 acc[4][2];
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-                acc[gt][hh] = widen(row_ok ? *(const bf16x4 *)(xg + (size_t)t * a.sx_t + gt * H + hid0 + 16 * hh) : zero4()) + bias[gt][hh];
-        const float kn = (a.keep && row_ok && t + 1 < T) ? a.keep[(size_t)(t + 1) * B + b] : 1.0f;
+            for (int hh = 0; hh < 2; ++hh) acc[gt][hh] = widen(xn[gt][hh]) + bias[gt][hh];
+        const float kn = kn_next;
+        fetch(t + 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 hb = *(const bf16x8 *)&hbuf[cur][r][32 * ks + 8 * q];
@@ -189,20 +202,37 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_
         dc[hh] = widen((a.d_c_last && row_ok) ? *(const bf16x4 *)((const __bf16 *)a.d_c_last + state_row + hid) : zero4());
     }
 
+    // what step t - 1 reads from global memory is fetched while step t computes (see the forward kernel)
+    bf16x4 pd[2], pa[4][2], pc[2][2];
+    float kt_next = 1.0f;
+    auto fetch = [&](int t) {
+        const bool in = t >= 0;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            pd[hh] = (in && og && row_ok) ? *(const bf16x4 *)(og + (size_t)t * a.so_t + hid0 + 16 * hh) : zero4();
+#pragma unroll
+            for (int gt = 0; gt < 4; ++gt) pa[gt][hh] = in ? *(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 2 * gt + hh, l)) : zero4();
+            pc[0][hh] = in ? *(const bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 0, hh, l)) : zero4();
+            pc[1][hh] = in ? *(const bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 1, hh, l)) : zero4();
+        }
+        kt_next = (in && a.keep && row_ok) ? a.keep[(size_t)t * B + b] : 1.0f;
+    };
+    fetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         const int buf = t & 1;
-        const float kt = (a.keep && row_ok) ? a.keep[(size_t)t * B + b] : 1.0f;
+        const float kt = kt_next;
+        f32x4 d2[2], gi2[2], gf2[2], gg2[2], go2[2], cin2[2], tc2[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            d2[hh] = dh[hh] + widen(pd[hh]);
+            gi2[hh] = widen(pa[0][hh]); gf2[hh] = widen(pa[1][hh]); gg2[hh] = widen(pa[2][hh]); go2[hh] = widen(pa[3][hh]);
+            cin2[hh] = widen(pc[0][hh]); tc2[hh] = widen(pc[1][hh]);
+        }
+        fetch(t - 1);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int hid = hid0 + 16 * hh;
-            f32x4 d = dh[hh];
-            if (og && row_ok) d += widen(*(const bf16x4 *)(og + (size_t)t * a.so_t + hid));
-            const f32x4 gi = widen(*(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 0 + hh, l)));
-            const f32x4 gf = widen(*(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 2 + hh, l)));
-            const f32x4 gg = widen(*(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 4 + hh, l)));
-            const f32x4 go = widen(*(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 6 + hh, l)));
-            const f32x4 cin = widen(*(const bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 0, hh, l)));
-            const f32x4 tc = widen(*(const bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 1, hh, l)));
+            const f32x4 d = d2[hh], gi = gi2[hh], gf = gf2[hh], gg = gg2[hh], go = go2[hh], cin = cin2[hh], tc = tc2[hh];
             f32x4 di, df, dg, d_o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
