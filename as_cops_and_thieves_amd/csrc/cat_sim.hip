@@ -36,11 +36,20 @@ namespace {
 constexpr int kMaxWaves = 16;       // waves (= env slots) per workgroup: Params::wpb in {1, 2, 4, 8, 16}
 constexpr int kLanes = 64;          // gfx950 wavefront
 constexpr int kK = CAT_WALL_CACHE;
+#ifndef CAT_P32_FLOATS
+#define CAT_P32_FLOATS 12
+#endif
+#ifndef CAT_BB_DOUBLES
+#define CAT_BB_DOUBLES 6
+#endif
+constexpr int kBB = CAT_BB_DOUBLES;     // doubles per wall bb record in LDS: 4 used (l b r t); 6 (48 B) for the same reason
+constexpr int kP32F = CAT_P32_FLOATS;   // floats per f32 plane record: 8 used; 12 (48 B) spreads 16 lanes' b128 reads over all 64 banks
+constexpr int kGeoPerPlane = 8 + kP32F / 2;   // doubles of LDS geometry per plane: the f64 record + the f32 record
 constexpr unsigned kBlobMagic = 0x31544143u;
 
 struct MapDesc {
     int S, P, A, n_regions;
-    int f64_off;   // into geo_f64: [bb 4S][planes 8P][planes32 4P][start 2A][regions 4Rg]
+    int f64_off;   // into geo_f64: [bb 4S][planes 8P][planes32 (kP32F/2) P][start 2A][regions 4Rg]
     int i32_off;   // into geo_i32: [first S][count S][region_off A+1]
     float cmax;    // max over the planes of |dot(v0, n) + wall radius + ray radius| (error bound of the f32 pre-classification)
     int pad1;
@@ -264,7 +273,7 @@ __device__ __forceinline__ double u53(unsigned a, unsigned b)
 struct Lds {
     const double *bb;      // [S][4]            workgroup-shared
     const double *planes;  // [P][8]
-    const float *p32;      // [P][8]  f32 copy for the conservative pre-classification: n.x n.y c dtMin | dtMax v0.x v0.y -
+    const float *p32;      // [P][kP32F] f32 copy for the conservative pre-classification: n.x n.y c dtMin | dtMax v0.x v0.y - | pad
     const int *fc;         // [S] first plane | plane count << 16
     // per env slot
     double *pos, *vel, *vb, *tc, *leaf;  // [A][2] x4, [A][4]
@@ -478,8 +487,8 @@ __device__ __forceinline__ void poly_query_feat(const Lds &L, float cmax, bool w
     unsigned pm = 0u, vm = wall ? 0u : 1u;
     const double *pl0 = L.planes + 8 * first;
     {
-        const float *q = L.p32 + 8 * first;
-        for (int i = 0; i < count; i++, q += 8) {
+        const float *q = L.p32 + kP32F * first;
+        for (int i = 0; i < count; i++, q += kP32F) {
             const float4 q0 = *reinterpret_cast<const float4 *>(q);       // n.x n.y c dtMin
             const float4 q1 = *reinterpret_cast<const float4 *>(q + 4);   // dtMax v0.x v0.y -
             const float d = __builtin_fmaf(ayf, q0.y, axf * q0.x) - q0.z;
@@ -638,7 +647,7 @@ __device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, i
         if (pi < A && pq < 7 && pq < n_i) {
             sh = (int)((row >> (8 * (pq + 1))) & 0xFF);
             const double ax = L.fpos[2 * pi], ay = L.fpos[2 * pi + 1];
-            const double *bb = L.bb + 4 * sh;
+            const double *bb = L.bb + kBB * sh;
             const double m = r2 + 1e-6;
             if ((bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m))
                 near = poly_point_distance(L, sh, p.wall_r, ax, ay) <= r2;  // [CP cpShapeSegmentQuery] alpha = 0 rule
@@ -668,7 +677,7 @@ __device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, i
             int sh = 0;
             if (e < c1) {
                 sh = G(p.cgrid_ent)[gd.cent_base + e];
-                const double *bb = L.bb + 4 * sh;
+                const double *bb = L.bb + kBB * sh;
                 const double m = r2 + 1e-6;
                 if ((bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m))
                     near = poly_point_distance(L, sh, p.wall_r, ax, ay) <= r2;
@@ -800,7 +809,7 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
                     }
                     // the BBTree gate value, by the ray's own lane.  A candidate whose t_bb is not below the
                     // ray's best alpha NOW can never be visited (best only decreases): it gets no item.
-                    if (gate) tbb = bb_segment_query((id < S) ? (L.bb + 4 * id) : (L.fleaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy);
+                    if (gate) tbb = bb_segment_query((id < S) ? (L.bb + kBB * id) : (L.fleaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy);
                 }
                 const bool live = has && tbb < best_a;
                 const unsigned long long m = __ballot(live);
@@ -996,7 +1005,7 @@ __device__ int termination_captured(const Lds &L, const Params &p, int S, int la
                 bool hit = false;
                 if (s < S) {
                     bool visit = true;
-                    if (p.gate) visit = bb_segment_query(L.bb + 4 * s, ax, ay, dx, dy, idx, idy) < 1.0;
+                    if (p.gate) visit = bb_segment_query(L.bb + kBB * s, ax, ay, dx, dy, idx, idy) < 1.0;
                     if (visit) {
                         SegInfo info = {0, 1.0, bx, by};
                         if (poly_point_distance(L, s, p.wall_r, ax, ay) <= 0.0) { info.hit = 1; info.alpha = 0.0; }
@@ -1132,7 +1141,7 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
     for (int q = 0; q < CAT_MAX_SHAPES / kLanes; q++) {
         const int s = q * kLanes + lane;
         if (s < S) {
-            const double *sb = L.bb + 4 * s;  // [CP cpBBIntersects]
+            const double *sb = L.bb + kBB * s;  // [CP cpBBIntersects]
             const double s0 = sb[0], s1 = sb[1], s2 = sb[2], s3 = sb[3];
             for (int i = 0; i < A; i++) {
                 const double cx = L.tc[2 * i], cy = L.tc[2 * i + 1];
@@ -1331,9 +1340,9 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     Lds L;
     const int S = md.S, P = md.P, W = p.wpb;
     L.bb = reinterpret_cast<const double *>(smem);
-    L.planes = L.bb + 4 * S;
+    L.planes = L.bb + kBB * S;
     L.p32 = reinterpret_cast<const float *>(L.planes + 8 * P);
-    L.fc = reinterpret_cast<const int *>(L.planes + 12 * P);
+    L.fc = reinterpret_cast<const int *>(L.planes + kGeoPerPlane * P);
     L.rayd = reinterpret_cast<const double *>(smem + p.lds_map_bytes - 16 * D::R(p));
     L.ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
     char *w = smem + p.lds_map_bytes + 16 * W + slot * p.lds_env_bytes;
@@ -1377,13 +1386,18 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
 template <class D>
 __device__ __forceinline__ void stage_map(const Params &p, char *smem, const MapDesc &md)
 {
-    const int nf = 4 * md.S + 12 * md.P;
+    const int nrest = kGeoPerPlane * md.P, nf = kBB * md.S + nrest;      // doubles of geometry in LDS
     double *dst = reinterpret_cast<double *>(smem);
     GAS const double *src = G(p.geo_f64) + md.f64_off;
-    {   // 16-byte copies, four in flight per thread (every map base is 16-byte aligned, nf is even)
+    {   // wall bbs: 32-byte records in memory, kBB doubles apart in LDS (16-byte copies)
         GAS const f64x2 *s2 = (GAS const f64x2 *)src;
-        f64x2 *d2 = reinterpret_cast<f64x2 *>(dst);
-        const int n2 = nf / 2, T = blockDim.x;
+        for (int i = threadIdx.x; i < 2 * md.S; i += blockDim.x)
+            *reinterpret_cast<f64x2 *>(dst + kBB * (i >> 1) + 2 * (i & 1)) = s2[i];
+    }
+    {   // the rest as it lies: 16-byte copies, four in flight per thread (every map base is 16-byte aligned, sizes even)
+        GAS const f64x2 *s2 = (GAS const f64x2 *)(src + 4 * md.S);
+        f64x2 *d2 = reinterpret_cast<f64x2 *>(dst + kBB * md.S);
+        const int n2 = nrest / 2, T = blockDim.x;
         for (int i = threadIdx.x; i < n2; i += 4 * T) {
             f64x2 v0 = s2[i], v1, v2, v3;
             const bool h1 = i + T < n2, h2 = i + 2 * T < n2, h3 = i + 3 * T < n2;
@@ -1734,7 +1748,7 @@ __device__ __forceinline__ void spawn_and_reset(const Lds &L, const Params &p, c
                                                 int env, unsigned rc, int lane)
 {
     const int S = md.S, A = D::A(p);
-    GAS const double *start = G(p.geo_f64) + md.f64_off + 4 * md.S + 12 * md.P;
+    GAS const double *start = G(p.geo_f64) + md.f64_off + 4 * md.S + kGeoPerPlane * md.P;
     GAS const double *regions = start + 2 * md.A;
     GAS const int *region_off = G(p.geo_i32) + md.i32_off + 2 * md.S;
 
@@ -1767,7 +1781,7 @@ __device__ __forceinline__ void spawn_and_reset(const Lds &L, const Params &p, c
                         const int s = base + lane;
                         bool hit = false;
                         if (s < S) {
-                            const double *bb = L.bb + 4 * s;
+                            const double *bb = L.bb + kBB * s;
                             const double m = p.rc + 1e-6;
                             if ((bb[0] - m <= x) && (x <= bb[2] + m) && (bb[1] - m <= y) && (y <= bb[3] + m))
                                 hit = poly_point_distance(L, s, p.wall_r, x, y) < p.rc;
@@ -1964,7 +1978,7 @@ static LdsSizes lds_sizes(int A, int R, int maxS, int maxP)
     auto up = [](int x, int a) { return (x + a - 1) / a * a; };
     const int NP = A * (A - 1) / 2, NPs = NP > 0 ? NP : 1, maxc = A * kK + NP;
     LdsSizes z;
-    z.map = up((4 * maxS + 12 * maxP) * 8 + maxS * 4, 16) + 16 * R;
+    z.map = up((kBB * maxS + kGeoPerPlane * maxP) * 8 + maxS * 4, 16) + 16 * R;
     const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
     const int fan_bytes = 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;
     z.uni = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 16);
@@ -2075,18 +2089,18 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         {   // f32 copy of the plane records for the ray fan's conservative pre-classification (poly_query_feat)
             const double rsum = cfg->wall_radius + cfg->ray_radius;
             const double *pl = f.data() + 2 + 4 * (size_t)d.S;
-            std::vector<float> p32(8 * (size_t)d.P, 0.0f);
+            std::vector<float> p32(kP32F * (size_t)d.P, 0.0f);
             float cmax = 0.0f;
             for (int q = 0; q < d.P; q++) {
                 const double *r = pl + 8 * (size_t)q;   // n.x n.y v0.x v0.y dot(v0,n) dtMin dtMax -
-                float *o = p32.data() + 8 * (size_t)q;
+                float *o = p32.data() + kP32F * (size_t)q;
                 o[0] = (float)r[0]; o[1] = (float)r[1]; o[2] = (float)(r[4] + rsum); o[3] = (float)r[5];
                 o[4] = (float)r[6]; o[5] = (float)r[2]; o[6] = (float)r[3];
                 cmax = std::fmax(cmax, std::fabs(o[2]));
             }
             d.cmax = cmax;
             const size_t at = geo_f.size();
-            geo_f.resize(at + 4 * (size_t)d.P);
+            geo_f.resize(at + (kP32F / 2) * (size_t)d.P);
             memcpy(geo_f.data() + at, p32.data(), p32.size() * sizeof(float));
         }
         geo_f.insert(geo_f.end(), f.begin() + 2 + n_geo, f.end());        // [start][regions]
@@ -2177,7 +2191,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     std::vector<char> rec0((size_t)N * p.rec_bytes, 0);
     for (int e = 0; e < N; e++) {
         const MapDesc &d = descs[slot[e]];
-        const double *start = geo_f.data() + d.f64_off + 4 * d.S + 12 * d.P;
+        const double *start = geo_f.data() + d.f64_off + 4 * d.S + kGeoPerPlane * d.P;
         double *rd = reinterpret_cast<double *>(rec0.data() + (size_t)e * p.rec_bytes);
         int *ri = reinterpret_cast<int *>(rec0.data() + (size_t)e * p.rec_bytes + p.hot_bytes + (A * kK + NPs_rec) * 8);   // cold ints
         for (int i = 0; i < A; i++) {
