@@ -166,3 +166,24 @@ def test_self_play_protocol_on_baseline_config_3(tmp_path):
     for role in ("cops", "thieves"):
         data = json.loads((tmp_path / role / "win_rates.json").read_text())
         assert len(data) == 3 and all(v["games"] >= 1 and len(v["recent_outcomes"]) <= 20 for v in data.values())
+
+
+@pytest.mark.parametrize("rays", [32, 90])
+def test_trainer_runs_with_other_ray_counts(rays):
+    """R = 32 goes through the fused convolutional trunk (14 and 4 positions); R = 90 (the reference's default sensor) does
+    not fit its LDS images and takes the dense-GEMM trunk: both train through the captured graphs with finite weights."""
+    import torch
+    from as_cops_and_thieves_amd import VecCopsEnv, load_preset
+    from as_cops_and_thieves_amd import _learn_native as ln
+    from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, RoleConfig, TrainerConfig
+    assert ln.trunk_supported(3, 1024, 4, rays) == (rays == 32)
+    env = VecCopsEnv(load_preset("squarinth"), 128, num_rays=rays, max_step_count=60, seed=2)
+    rc = RoleConfig(learning_epochs=1, mini_batches=2, random_timesteps=0, learning_starts=0)
+    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0), seed=1)
+    before = {r: rl.fp.master.clone() for r, rl in tr.roles.items()}
+    for _ in range(4):
+        tr.collect(); tr.update()
+    torch.cuda.synchronize()
+    for r, rl in tr.roles.items():
+        assert torch.isfinite(rl.fp.master).all() and not torch.equal(rl.fp.master, before[r]) and rl._graphs
+    env.close()
