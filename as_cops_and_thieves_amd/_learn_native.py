@@ -18,7 +18,7 @@ HIDDEN = 128
 EXPORTED_SYMBOLS = ("cat_lstm_abi_version", "cat_lstm_last_error", "cat_lstm_blocks", "cat_lstm_saved_acts_bytes", "cat_lstm_saved_cell_bytes",
                     "cat_lstm_seq_forward", "cat_lstm_seq_backward")
 TRUNK_SYMBOLS = ("cat_trunk_abi_version", "cat_trunk_last_error", "cat_trunk_out_positions", "cat_trunk_supported",
-                 "cat_trunk_backward_blocks", "cat_trunk_forward", "cat_trunk_backward")
+                 "cat_trunk_backward_blocks", "cat_trunk_forward", "cat_trunk_backward", "cat_trunk_grad_finish")
 
 
 class Dims(C.Structure):
@@ -84,6 +84,13 @@ class PpoAdam(C.Structure):
                 ("grad_norm_clip", C.c_float), ("kl_threshold", C.c_float)]
 
 
+class TrunkFinish(C.Structure):
+    _fields_ = [("d", TrunkDims), ("blocks", C.c_int32), ("accumulate", C.c_int32),
+                ("part_dw1", C.c_void_p), ("part_db1", C.c_void_p), ("part_dw2", C.c_void_p), ("part_db2", C.c_void_p),
+                ("dw1", C.c_void_p), ("db1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
+                ("sw1_g", C.c_int64), ("sb1_g", C.c_int64), ("sw2_g", C.c_int64), ("sb2_g", C.c_int64)]
+
+
 class NativeLibraryMissing(RuntimeError):
     pass
 
@@ -132,7 +139,7 @@ def lib() -> C.CDLL:
         for n in ("cat_trunk_out_positions", "cat_trunk_supported", "cat_trunk_backward_blocks"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p]
-        for n in ("cat_trunk_forward", "cat_trunk_backward"):
+        for n in ("cat_trunk_forward", "cat_trunk_backward", "cat_trunk_grad_finish"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
         assert L.cat_trunk_abi_version() == 1
@@ -292,6 +299,26 @@ def trunk_backward(x, w1, b1, w2, b2, out, d_out, R: int):
                  out.stride(0), out.stride(1), pw1.data_ptr(), pb1.data_ptr(), pw2.data_ptr(), pb2.data_ptr())
     _check(lib().cat_trunk_backward(C.byref(a), _stream()), "cat_trunk_backward")
     return pw1, pb1, pw2, pb2
+
+
+def trunk_grad_finish(parts, C_in: int, R: int, slots=None):
+    """The four slab buffers of ``trunk_backward`` -> the parameter gradients in the parameters' own shapes (bf16): ADDED into
+    ``slots`` = (dw1, db1, dw2, db2) views (returns None) or returned as new tensors."""
+    import torch
+    pw1, pb1, pw2, pb2 = parts
+    G, nb = pw1.shape[:2]
+    acc = slots is not None
+    if not acc:
+        dev = pw1.device
+        slots = (torch.empty(G, 64, C_in, 5, dtype=torch.bfloat16, device=dev), torch.empty(G, 64, dtype=torch.bfloat16, device=dev),
+                 torch.empty(G, 32, 64, 5, dtype=torch.bfloat16, device=dev), torch.empty(G, 32, dtype=torch.bfloat16, device=dev))
+    for t in slots:
+        assert t.dtype == torch.bfloat16 and t[0].is_contiguous()
+    a = TrunkFinish(TrunkDims(G, 16, C_in, R), nb, 1 if acc else 0, pw1.data_ptr(), pb1.data_ptr(), pw2.data_ptr(), pb2.data_ptr(),
+                    slots[0].data_ptr(), slots[1].data_ptr(), slots[2].data_ptr(), slots[3].data_ptr(),
+                    slots[0].stride(0), slots[1].stride(0), slots[2].stride(0), slots[3].stride(0))
+    _check(lib().cat_trunk_grad_finish(C.byref(a), _stream()), "cat_trunk_grad_finish")
+    return None if acc else slots
 
 
 # ---------------------------------------------------------------------------------------------- PPO loss / optimiser step

@@ -364,6 +364,45 @@ __global__ __launch_bounds__(NWB *LANES) void trunk_bwd_kernel(const cat_trunk_b
     }
 }
 
+// second stage of the parameter gradients: one thread per slab element, summed over the slabs, stored where the parameter
+// keeps that element (w1: column kk * C + c -> [ch][c][kk]; w2: column kk * 64 + ci -> [co][ci][kk])
+__global__ __launch_bounds__(256) void trunk_finish_kernel(const cat_trunk_finish_args a)
+{
+    const int g = blockIdx.y, C = a.d.C, B = a.blocks;
+    const int n1 = C1 * KW * C, nb1 = C1, n2 = C2 * WIN2, nb2 = C2;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const float *src;
+    __bf16 *dst;
+    size_t slab;
+    if (j < n1) {
+        const int ch = j / (KW * C), col = j - ch * (KW * C), kk = col / C, c = col - kk * C;
+        src = a.part_dw1 + (size_t)g * B * C1 * 32 + ch * 32 + col; slab = (size_t)C1 * 32;
+        dst = (__bf16 *)a.dw1 + (size_t)g * a.sw1_g + (ch * C + c) * KW + kk;
+    } else if (j < n1 + nb1) {
+        const int ch = j - n1;
+        src = a.part_db1 + (size_t)g * B * C1 + ch; slab = C1;
+        dst = (__bf16 *)a.db1 + (size_t)g * a.sb1_g + ch;
+    } else if (j < n1 + nb1 + n2) {
+        const int k = j - n1 - nb1, co = k / WIN2, col = k - co * WIN2, kk = col >> 6, ci = col & 63;
+        src = a.part_dw2 + (size_t)g * B * C2 * WIN2 + k; slab = (size_t)C2 * WIN2;
+        dst = (__bf16 *)a.dw2 + (size_t)g * a.sw2_g + (co * C1 + ci) * KW + kk;
+    } else if (j < n1 + nb1 + n2 + nb2) {
+        const int co = j - n1 - nb1 - n2;
+        src = a.part_db2 + (size_t)g * B * C2 + co; slab = C2;
+        dst = (__bf16 *)a.db2 + (size_t)g * a.sb2_g + co;
+    } else {
+        return;
+    }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= B; b += 4) {
+        s0 += src[(size_t)b * slab]; s1 += src[(size_t)(b + 1) * slab]; s2 += src[(size_t)(b + 2) * slab]; s3 += src[(size_t)(b + 3) * slab];
+    }
+    for (; b < B; ++b) s0 += src[(size_t)b * slab];
+    const float s = (s0 + s1) + (s2 + s3);
+    *dst = (__bf16)(a.accumulate ? s + (float)*dst : s);
+}
+
 thread_local char g_err[256] = "";
 int fail(int code, const char *msg)
 {
@@ -455,6 +494,17 @@ extern "C" int cat_trunk_backward(const cat_trunk_bwd *a, void *stream)
         lds_set = lds;
     }
     hipLaunchKernelGGL(trunk_bwd_kernel, dim3(bwd_blocks(a->d), a->d.G), dim3(NWB * LANES), lds, (hipStream_t)stream, *a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_TRUNK_OK : fail(CAT_TRUNK_ERR_HIP, hipGetErrorString(e));
+}
+
+extern "C" int cat_trunk_grad_finish(const cat_trunk_finish_args *a, void *stream)
+{
+    if (!a || !dims_ok(a->d) || a->blocks <= 0) return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_grad_finish: bad dimensions");
+    if (!a->part_dw1 || !a->part_db1 || !a->part_dw2 || !a->part_db2 || !a->dw1 || !a->db1 || !a->dw2 || !a->db2)
+        return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_grad_finish: a required buffer is NULL");
+    const int n = C1 * KW * a->d.C + C1 + C2 * WIN2 + C2;
+    hipLaunchKernelGGL(trunk_finish_kernel, dim3((n + 255) / 256, a->d.G), dim3(256), 0, (hipStream_t)stream, *a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAT_TRUNK_OK : fail(CAT_TRUNK_ERR_HIP, hipGetErrorString(e));
 }

@@ -337,20 +337,18 @@ class _ConvTrunk(torch.autograd.Function):
         out = _learn_native.trunk_forward(x, w1, b1, w2, b2, R)
         ctx.save_for_backward(x, w1, b1, w2, b2, out)
         ctx.R = R
+        ctx.slots = tuple(_grad_slot(p) for p in (w1, b1, w2, b2))
         return out
 
     @staticmethod
     def backward(ctx, go):
         x, w1, b1, w2, b2, out = ctx.saved_tensors
-        G, C = w1.shape[0], w1.shape[2]
         parts = _learn_native.trunk_backward(x, w1, b1, w2, b2, out, go, ctx.R)
-        nb = parts[0].shape[1]
-        ones = _learn_native.ones_row(G, nb, go.device)
-        dw1, db1, dw2, db2 = (torch.bmm(ones, p.view(G, nb, -1)).squeeze(1) for p in parts)      # add the slabs up
-        dw1 = dw1.view(G, 64, 32)[:, :, :5 * C].reshape(G, 64, 5, C).transpose(2, 3)              # column kk * C + c
-        dw2 = dw2.view(G, 32, 5, 64).transpose(2, 3)                                             # column kk * 64 + c_in
-        dt = w1.dtype
-        return None, dw1.to(dt), db1.to(dt), dw2.to(dt), db2.to(dt), None
+        if all(s is not None for s in ctx.slots):   # slabs added up straight into the flat gradient buffer
+            _learn_native.trunk_grad_finish(parts, w1.shape[2], ctx.R, ctx.slots)
+            return None, None, None, None, None, None
+        dw1, db1, dw2, db2 = _learn_native.trunk_grad_finish(parts, w1.shape[2], ctx.R)
+        return None, dw1, db1, dw2, db2, None
 
 
 def _conv_as_dense_indices(c_out: int, c_in: int, k: int, stride: int, l_in: int, in_layout: str, device):

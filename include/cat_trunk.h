@@ -75,6 +75,17 @@ typedef struct cat_trunk_bwd {
     float *part_db2;    /* [G][B][32] */
 } cat_trunk_bwd;
 
+/* Second stage of cat_trunk_backward: adds the B per-workgroup slabs up, puts the columns back into the parameters' own
+   order and stores bf16 -- dst (+)= sum.  Each dst is [G][...] with the parameter's shape per network and row stride s*_g. */
+typedef struct cat_trunk_finish_args {
+    cat_trunk_dims d;
+    int32_t blocks, accumulate;
+    const float *part_dw1, *part_db1, *part_dw2, *part_db2;
+    void *dw1, *db1, *dw2, *db2;        /* bf16 [G][64][C][5], [G][64], [G][32][64][5], [G][32] */
+    int64_t sw1_g, sb1_g, sw2_g, sb2_g;
+} cat_trunk_finish_args;
+int cat_trunk_grad_finish(const cat_trunk_finish_args *a, void *stream);
+
 int cat_trunk_abi_version(void);
 const char *cat_trunk_last_error(void);
 int cat_trunk_forward(const cat_trunk_fwd *a, void *stream);

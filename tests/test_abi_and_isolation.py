@@ -50,7 +50,7 @@ def test_lstm_library_exports_every_declared_symbol_and_struct_layouts_match():
 
 @pytest.mark.parametrize("header,prefix,symbols,structs", [
     ("cat_trunk.h", "cat_trunk_", "TRUNK_SYMBOLS", {"cat_trunk_dims": "TrunkDims", "cat_trunk_params": "TrunkParams", "cat_trunk_fwd": "TrunkFwd",
-                                                    "cat_trunk_bwd": "TrunkBwd"}),
+                                                    "cat_trunk_bwd": "TrunkBwd", "cat_trunk_finish_args": "TrunkFinish"}),
     ("cat_ppo.h", "cat_ppo_", "PPO_SYMBOLS", {"cat_ppo_loss": "PpoLoss", "cat_ppo_adam": "PpoAdam"}),
     ("cat_rollout.h", "cat_rollout_", "ROLLOUT_SYMBOLS", {"cat_rollout_pack_args": "PackArgs", "cat_rollout_sample_args": "SampleArgs"}),
     ("cat_dense.h", "cat_dense_", "DENSE_SYMBOLS", {"cat_dense_dims": "DenseDims", "cat_dense_wgrad_args": "WgradArgs"})])

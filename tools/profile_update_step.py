@@ -27,4 +27,9 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     for _ in range(3):
         rl._step_forward_backward(); rl._step_apply()
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=50, max_shapes_column_width=90))
+rows = [e for e in prof.key_averages() if e.key.startswith("aten::") or e.key.startswith("_")]
+rows.sort(key=lambda e: -e.count)
+print("aten / custom ops by call count over 3 steps:")
+for e in rows[:45]:
+    print(f"{e.count:5d} x  {e.key:45s} cpu {e.self_cpu_time_total / 1e3:8.2f} ms   device {e.self_device_time_total / 1e3:8.2f} ms")
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=30, max_name_column_width=60))
