@@ -139,8 +139,14 @@ class _GradsOf(torch.autograd.Function):
 
 
 def _dist_ready() -> bool:
+    """True when the optimiser step must all-reduce: a process group of more than one rank -- or of ONE rank with
+    CAT_FORCE_ALLREDUCE=1, which sends the gradient buffer through the collective library anyway (the one-GPU test of the
+    RCCL launch between the two step graphs)."""
+    import os
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("CAT_FORCE_ALLREDUCE") == "1"
 
 
 class RoleLearner:
