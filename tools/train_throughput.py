@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: env-steps/s of the MAPPO trainer on the device env -- rollout collection (env tick +
 the stacked policies and critics per tick, one HIP graph) and the PPO update (HIP-graph minibatch steps) -- beside the
-bare env rate of bench.py.  Usage: python tools/train_throughput.py [envs] [rollouts] [map] [horizon]"""
+bare env rate of bench.py.  Usage: python tools/train_throughput.py [envs] [rollouts] [map] [horizon] [cops] [thieves]"""
 import sys, time, faulthandler
 import os
 faulthandler.dump_traceback_later(int(os.environ.get("CAT_WATCHDOG_S", "100")), exit=True)    # a hang shows where
@@ -15,7 +15,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 name = sys.argv[3] if len(sys.argv) > 3 else "labyrinth"
 H = int(sys.argv[4]) if len(sys.argv) > 4 else 16     # ticks per rollout (BPTT window stays 16)
-env = VecCopsEnv(load_preset(name), num_envs=N, num_rays=64, max_step_count=400)
+roster = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (None, None)
+env = VecCopsEnv(load_preset(name, *roster), num_envs=N, num_rays=64, max_step_count=400)
 tr = MAPPOTrainer(env, None, TrainerConfig(horizon=H), seed=0)      # CFG_AGENT for both roles, as the reference's driver
 for _ in range(3):                                         # eager warm-up, then the graph captures
     tr.collect(); tr.update()
