@@ -1,5 +1,6 @@
 """GPU: the convolutional-trunk kernels of libcat_learn.so (include/cat_trunk.h, csrc/cat_trunk.hip) against a plain
-PyTorch fp32 reference of the same four layers (torch.nn.functional.conv1d, as the reference's nn.Conv1d modules).
+PyTorch fp32 reference of the same four layers (Conv1d written out as unfold + einsum and checked against
+torch.nn.functional.conv1d: the reference's nn.Conv1d modules).
 
 Tolerances: operands, the LDS-resident intermediate and the stored result are bf16, accumulation is fp32; the reference
 runs in fp32 from the SAME bf16-rounded inputs and weights and rounds its intermediate to bf16 too (otherwise the ReLU
@@ -8,20 +9,37 @@ sum of random-sign terms shows as sqrt(0.1 %) = 3 % relative error).  Forward: |
 (sums over thousands of samples): relative L2 error <= 2 %, cosine >= 0.999."""
 import pytest
 
+torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
+
+
+def _conv1d(x, w, b, stride):
+    """torch.nn.Conv1d's arithmetic written out (windows by unfold, one einsum): the same sums as F.conv1d, in fp32,
+    without MIOpen's kernel search (tens of seconds per new shape on a fresh box); checked against F.conv1d below."""
+    win = x.unfold(2, w.shape[2], stride)                                    # [N, C_in, L_out, K]
+    return torch.einsum("nclk,ock->nol", win, w) + b.view(1, -1, 1)
 
 
 def _reference(x, w1, b1, w2, b2, C, R):
     """x [G, N, C*R] (channel, ray) fp32 -> [G, N, L2*32] (position, channel)."""
-    import torch
-    import torch.nn.functional as F
     outs = []
     for g in range(x.shape[0]):
-        z = F.relu(F.conv1d(x[g].view(-1, C, R), w1[g], b1[g], stride=2))
+        z = torch.relu(_conv1d(x[g].view(-1, C, R), w1[g], b1[g], 2))
         z = z.to(torch.bfloat16).float()        # the kernels keep the intermediate in bf16 (as a bf16 torch model would)
-        z = F.relu(F.conv1d(z, w2[g], b2[g], stride=3))                     # [N, 32, L2]
+        z = torch.relu(_conv1d(z, w2[g], b2[g], 3))                          # [N, 32, L2]
         outs.append(z.transpose(1, 2).reshape(z.shape[0], -1))
     return torch.stack(outs, 0)
+
+
+def test_the_reference_formulation_is_conv1d():
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(50, 4, 64, generator=gen, device="cuda")
+    w, b = torch.randn(64, 4, 5, generator=gen, device="cuda"), torch.randn(64, generator=gen, device="cuda")
+    assert torch.allclose(_conv1d(x, w, b, 2), F.conv1d(x, w, b, stride=2), atol=1e-4, rtol=1e-4)
+    z = torch.randn(50, 64, 30, generator=gen, device="cuda")
+    w2, b2 = torch.randn(32, 64, 5, generator=gen, device="cuda"), torch.randn(32, generator=gen, device="cuda")
+    assert torch.allclose(_conv1d(z, w2, b2, 3), F.conv1d(z, w2, b2, stride=3), atol=1e-3, rtol=1e-4)
 
 
 def _case(G, N, C, R, seed):
