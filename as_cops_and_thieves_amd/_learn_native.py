@@ -195,7 +195,7 @@ def saved_sizes(G: int, T: int, B: int):
     return lib().cat_lstm_saved_acts_bytes(C.byref(d)), lib().cat_lstm_saved_cell_bytes(C.byref(d))
 
 
-def seq_forward(xproj, w_hh, bias, h0, c0, keep, save: bool):
+def seq_forward(xproj, w_hh, bias, h0, c0, keep, save: bool, state_out=None):
     """xproj bf16 [G, T, B, 4H] (any outer strides), w_hh bf16 [G, 4H, H] (rows contiguous), bias bf16 [G, 4H] or None,
     h0/c0 bf16 [G, B, H], keep fp32 [T, B] or None.  Returns out [G, T, B, H], h_T, c_T and, with ``save``, (h_in, acts, cell) for backward."""
     import torch
@@ -208,7 +208,11 @@ def seq_forward(xproj, w_hh, bias, h0, c0, keep, save: bool):
         assert keep.shape == (T, B) and keep.dtype == torch.float32 and keep.is_contiguous()
     dev = xproj.device
     out = torch.empty(G, T, B, HIDDEN, dtype=torch.bfloat16, device=dev)
-    hT, cT = torch.empty_like(h0), torch.empty_like(c0)
+    if state_out is not None:   # written where the caller keeps the state (may be h0 / c0 themselves: a workgroup reads its
+        hT, cT = state_out      # rows of the initial state before it writes the final one)
+        assert hT.shape == h0.shape and cT.shape == h0.shape and hT.dtype == cT.dtype == torch.bfloat16 and hT.is_contiguous() and cT.is_contiguous()
+    else:
+        hT, cT = torch.empty_like(h0), torch.empty_like(c0)
     h_in = acts = cell = None
     if save:
         na, nc = saved_sizes(G, T, B)

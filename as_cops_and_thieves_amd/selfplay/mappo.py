@@ -456,10 +456,11 @@ class MAPPOTrainer:
                     self._pack_native(rl, pin, vin)
                 else:
                     pin, vin = self._inputs(rl, self._obs, state)
-                logits, p_new = rl.policy.forward(pin.unsqueeze(1), rl.p_state, keep)
-                val, v_new = rl.value.forward(vin.unsqueeze(1), rl.v_state, keep)
+                logits, p_new = rl.policy.forward(pin.unsqueeze(1), rl.p_state, keep, update_state=True)
+                val, v_new = rl.value.forward(vin.unsqueeze(1), rl.v_state, keep, update_state=True)
                 for old, new in zip(rl.p_state + rl.v_state, p_new + v_new):
-                    old.copy_(new)
+                    if old is not new:           # the kernel path has already written the new state in place
+                        old.copy_(new)
                 if fused:   # draw, log-probability, value and the env's action columns in one launch
                     u = torch.rand(rl.G, N, device=self.device)
                     _learn_native.rollout_sample(logits[:, 0].contiguous(), u, val[:, 0, :, 0].contiguous(), b["act"][:, t], b["logp"][:, t],

@@ -94,7 +94,7 @@ class _LSTMSeq(torch.autograd.Function):
     CPU (the parity tests, ``compute_bf16=False``): the same recurrence step by step in torch."""
 
     @staticmethod
-    def forward(ctx, xproj, w_hh, b_ih, b_hh, h0, c0, keep):
+    def forward(ctx, xproj, w_hh, b_ih, b_hh, h0, c0, keep, state_out=None):
         G, T, B, _ = xproj.shape
         train = any(ctx.needs_input_grad)          # a rollout tick (no_grad) keeps nothing
         ctx.has_keep = keep is not None
@@ -102,7 +102,7 @@ class _LSTMSeq(torch.autograd.Function):
         ctx.native = xproj.is_cuda and xproj.dtype == torch.bfloat16
         if ctx.native:
             bias = b_ih if (b_ih is None or b_hh is None) else b_ih + b_hh
-            out, hT, cT, (h_in, acts, cell) = _learn_native.seq_forward(xproj, w_hh, bias, h0, c0, keep, save=train)
+            out, hT, cT, (h_in, acts, cell) = _learn_native.seq_forward(xproj, w_hh, bias, h0, c0, keep, save=train, state_out=state_out)
             ctx.has_bias = bias is not None
             ctx.slots = (_grad_slot(w_hh), _grad_slot(b_ih), _grad_slot(b_hh))
             if train:
@@ -165,7 +165,7 @@ class _LSTMSeq(torch.autograd.Function):
         a = dg_all.reshape(G, T * B, dg_all.shape[3])
         hin = h_in.reshape(G, T * B, h_in.shape[3])
         d_w = _weight_grad(a, hin, w_slot) if ctx.native else torch.bmm(a.transpose(1, 2), hin)   # one product over all steps
-        return dg_all, d_w, d_bih, d_bhh, dh, dc, None
+        return dg_all, d_w, d_bih, d_bhh, dh, dc, None, None
 
 
 # ---------------------------------------------------------------------------------------------- flat parameters
@@ -398,9 +398,10 @@ class StackedNet:
         z = torch.zeros(self.layers, self.fp.G, B, HIDDEN, device=self.fp.master.device, dtype=self.fp.compute_dtype)
         return z, z.clone()
 
-    def forward(self, x: torch.Tensor, state, keep: Optional[torch.Tensor]):
+    def forward(self, x: torch.Tensor, state, keep: Optional[torch.Tensor], update_state: bool = False):
         """x: [G, T, B, C*R] (time-major); state: (h, c) each [layers, G, B, H]; keep: [T, B] (1 = carry the state
-        into step t, 0 = an episode starts there) or None.  Returns (out [G, T, B, n_out], new state)."""
+        into step t, 0 = an episode starts there) or None.  Returns (out [G, T, B, n_out], new state).  ``update_state``
+        (rollouts, no_grad, kernel path): the recurrence kernels write the new state INTO ``state`` and that is returned."""
         G, T, B, _ = x.shape
         dt = self.fp.compute_dtype
         N = T * B
@@ -427,12 +428,16 @@ class StackedNet:
                 xp = _LinAct.apply(inp, w_ih, None, 0).view(G, T, B, 4 * HIDDEN)
             else:
                 xp, b_ih, b_hh = _lin(inp, w_ih, b_ih + b_hh).view(G, T, B, 4 * HIDDEN), None, None
-            out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), b_ih, b_hh, h0[l].to(dt), c0[l].to(dt), kp)
+            in_place = update_state and native and not torch.is_grad_enabled() and h0.dtype == dt
+            out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), b_ih, b_hh, h0[l].to(dt), c0[l].to(dt), kp,
+                                         (h0[l], c0[l]) if in_place else None)
             hs.append(hT); cs.append(cT)
             inp = out.reshape(G, N, HIDDEN)
         y = inp
         for j in range(self.n_head):
             y = _lin_act(y, self.w(f"head.{2 * j}.weight"), self.w(f"head.{2 * j}.bias"), 1 if j < self.n_head - 1 else 0)
+        if update_state and native and not torch.is_grad_enabled() and h0.dtype == dt:
+            return y.view(G, T, B, -1), state
         return y.view(G, T, B, -1), (torch.stack(hs, 0), torch.stack(cs, 0))
 
 
