@@ -61,7 +61,7 @@ class TrunkBwd(C.Structure):
                 ("part_dw1", C.c_void_p), ("part_db1", C.c_void_p), ("part_dw2", C.c_void_p), ("part_db2", C.c_void_p)]
 
 
-ROLLOUT_SYMBOLS = ("cat_rollout_abi_version", "cat_rollout_last_error", "cat_rollout_pack", "cat_rollout_sample")
+ROLLOUT_SYMBOLS = ("cat_rollout_abi_version", "cat_rollout_last_error", "cat_rollout_pack", "cat_rollout_sample", "cat_rollout_post")
 DENSE_SYMBOLS = ("cat_dense_abi_version", "cat_dense_last_error", "cat_dense_bias_act", "cat_dense_act_grad", "cat_dense_sum_chunks",
                  "cat_dense_wgrad_splits", "cat_dense_wgrad")
 PPO_SYMBOLS = ("cat_ppo_abi_version", "cat_ppo_last_error", "cat_ppo_loss_grad", "cat_ppo_adam_step")
@@ -165,7 +165,7 @@ def lib() -> C.CDLL:
         assert L.cat_dense_abi_version() == 1
         L.cat_rollout_abi_version.restype = C.c_int
         L.cat_rollout_last_error.restype = C.c_char_p
-        for n in ("cat_rollout_pack", "cat_rollout_sample"):
+        for n in ("cat_rollout_pack", "cat_rollout_sample", "cat_rollout_post"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
         assert L.cat_rollout_abi_version() == 1
@@ -498,3 +498,24 @@ def rollout_sample(logits, uniform, values, act_out, logp_out, value_out, action
     a = SampleArgs(N, actions.shape[1], G, 0, (C.c_int32 * 8)(*agent_indices), logits.data_ptr(), uniform.data_ptr(), _ptr(values),
                    act_out.data_ptr(), logp_out.data_ptr(), _ptr(value_out), act_out.stride(0), logp_out.stride(0), actions.data_ptr())
     _check(lib().cat_rollout_sample(C.byref(a), _stream()), "cat_rollout_sample")
+
+
+class PostArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("A", C.c_int32), ("G", C.c_int32), ("pad", C.c_int32), ("agent", C.c_int32 * 8),
+                ("reward", C.c_void_p), ("terminated", C.c_void_p), ("reward_out", C.c_void_p), ("sr_g", C.c_int64),
+                ("done_out", C.c_void_p), ("start_out", C.c_void_p), ("keep_out", C.c_void_p)]
+
+
+def rollout_post(raw, agent_indices, reward_out, done_out=None, start_out=None, keep_out=None) -> None:
+    """raw["reward"] fp32 [N, A], raw["terminated"] u8 [N] -> reward_out fp32 [G, N] (row-strided view); done_out / start_out
+    bool [N]; keep_out fp32 [N] = 1 - terminated."""
+    import torch
+    rew, term = raw["reward"], raw["terminated"]
+    N, A = rew.shape
+    assert rew.dtype == torch.float32 and rew.is_contiguous() and term.dtype == torch.uint8 and term.shape == (N,)
+    assert reward_out.dtype == torch.float32 and reward_out.shape == (len(agent_indices), N) and reward_out.stride(1) == 1
+    for t, dt in ((done_out, torch.bool), (start_out, torch.bool), (keep_out, torch.float32)):
+        assert t is None or (t.dtype == dt and t.numel() == N and t.is_contiguous())
+    a = PostArgs(N, A, len(agent_indices), 0, (C.c_int32 * 8)(*agent_indices), rew.data_ptr(), term.data_ptr(), reward_out.data_ptr(),
+                 reward_out.stride(0), _ptr(done_out), _ptr(start_out), _ptr(keep_out))
+    _check(lib().cat_rollout_post(C.byref(a), _stream()), "cat_rollout_post")

@@ -55,6 +55,17 @@ __global__ __launch_bounds__(BLOCK) void sample_kernel(const cat_rollout_sample_
     }
 }
 
+__global__ __launch_bounds__(BLOCK) void post_kernel(const cat_rollout_post_args a)
+{
+    for (int n = blockIdx.x * BLOCK + threadIdx.x; n < a.N; n += gridDim.x * BLOCK) {
+        for (int g = 0; g < a.G; ++g) a.reward_out[(size_t)g * a.sr_g + n] = a.reward[(size_t)n * a.A + a.agent[g]];
+        const uint8_t d = a.terminated[n] ? 1 : 0;
+        if (a.done_out) a.done_out[n] = d;
+        if (a.start_out) a.start_out[n] = d;
+        if (a.keep_out) a.keep_out[n] = d ? 0.0f : 1.0f;
+    }
+}
+
 thread_local char g_err[256] = "";
 int fail(int code, const char *msg)
 {
@@ -94,6 +105,20 @@ extern "C" int cat_rollout_sample(const cat_rollout_sample_args *a, void *stream
     int blocks = (a->N + BLOCK - 1) / BLOCK;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(sample_kernel, dim3(blocks, a->G), dim3(BLOCK), 0, (hipStream_t)stream, *a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_ROLLOUT_OK : fail(CAT_ROLLOUT_ERR_HIP, hipGetErrorString(e));
+}
+
+extern "C" int cat_rollout_post(const cat_rollout_post_args *a, void *stream)
+{
+    if (!a || a->N <= 0 || a->A <= 0 || a->A > CAT_ROLLOUT_MAX_AGENTS || a->G <= 0 || a->G > CAT_ROLLOUT_MAX_AGENTS)
+        return fail(CAT_ROLLOUT_ERR_BAD_ARG, "cat_rollout_post: bad dimensions");
+    for (int g = 0; g < a->G; ++g)
+        if (a->agent[g] < 0 || a->agent[g] >= a->A) return fail(CAT_ROLLOUT_ERR_BAD_ARG, "cat_rollout_post: agent index out of range");
+    if (!a->reward || !a->terminated || !a->reward_out) return fail(CAT_ROLLOUT_ERR_BAD_ARG, "cat_rollout_post: a required buffer is NULL");
+    int blocks = (a->N + BLOCK - 1) / BLOCK;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(post_kernel, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, *a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAT_ROLLOUT_OK : fail(CAT_ROLLOUT_ERR_HIP, hipGetErrorString(e));
 }

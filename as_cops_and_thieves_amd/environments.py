@@ -359,6 +359,15 @@ class VecCopsEnv:
                         "team_positions": o["team_positions"][:, sl]}
         return res
 
+    def observations(self) -> Dict[str, Dict[str, torch.Tensor]]:
+        """The per-agent observation dictionaries over the current output buffers (what ``step`` / ``reset`` return)."""
+        return self._obs()
+
+    def step_raw(self, actions: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """``step`` without the per-agent dictionaries: one launch (tick + auto-reset), returns the output buffers
+        themselves (``raw_outputs()``): reward fp32 [N, A], terminated / truncated u8 [N], winner, observations."""
+        return self._sim.step_fused(actions, auto_reset=self.auto_reset)
+
     def raw_outputs(self) -> Dict[str, torch.Tensor]:
         """The env core's output buffers as they lie on the device (``include/cat_sim.h`` ``cat_outputs``: f16 distances,
         u8 types, [N, A, R] / [N, 2, R]): what ``_obs()`` / ``state()`` slice per agent, for callers that pack the model

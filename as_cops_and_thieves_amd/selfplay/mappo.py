@@ -405,11 +405,13 @@ class MAPPOTrainer:
         self.timestep = 0
         self._obs, _ = env.reset()
         self._starts = torch.ones(self.N, dtype=torch.bool, device=self.device)
+        self._keep32 = torch.zeros(1, self.N, dtype=torch.float32, device=self.device)   # = ~_starts, as the networks take it
         T = self.tcfg.horizon
         self._done_buf = torch.zeros(T, self.N, dtype=torch.bool, device=self.device)
         self._start_buf = torch.zeros(T, self.N, dtype=torch.bool, device=self.device)
         self._actions = torch.zeros(self.N, len(self.agents), dtype=torch.int32, device=self.device)
-        self._native_io = on_gpu and hasattr(env, "raw_outputs")   # cat_rollout.h: packing and sampling in one launch each
+        self._native_io = on_gpu and hasattr(env, "raw_outputs")
+        self._native_post = self._native_io and hasattr(env, "step_raw")   # cat_rollout_post: rewards and flags of the raw step   # cat_rollout.h: packing and sampling in one launch each
         self._graph = None
         self._eager_rollouts = 0
         self.stats: Dict[str, float] = {}
@@ -441,9 +443,10 @@ class MAPPOTrainer:
         """T ticks: networks -> actions -> env.step into the preallocated buffers.  In-place updates of persistent
         tensors only and no host synchronisation: the whole loop is captured in one HIP graph and replayed."""
         N, T = self.N, self.tcfg.horizon
+        all_fused = self._native_post and not random_actions and all(rl.native and rl.random_rows is None for rl in self.roles.values())
         for t in range(T):
             state = self.env.state()
-            keep = (~self._starts).view(1, N)
+            keep = self._keep32 if all_fused else (~self._starts).view(1, N)
             self._start_buf[t].copy_(self._starts)
             for rl in self.roles.values():
                 if t % rl.bptt == 0:                # the recurrent state at the start of a BPTT window is kept
@@ -477,12 +480,20 @@ class MAPPOTrainer:
                 b["logp"][:, t].copy_(logp_all.gather(-1, act.unsqueeze(-1)).squeeze(-1))
                 b["val"][:, t].copy_(val[:, 0, :, 0].float())
                 self._actions.index_copy_(1, rl.index_t, act.t().to(torch.int32))    # device index: capturable
+            if all_fused:   # one launch for the tick, one for rewards + episode-end flags (cat_rollout_post)
+                raw = self.env.step_raw(self._actions)
+                for i, rl in enumerate(self.roles.values()):
+                    flags = (self._done_buf[t], self._starts, self._keep32) if i == 0 else (None, None, None)
+                    _learn_native.rollout_post(raw, rl.indices, rl.buf["rew"][:, t], *flags)
+                self._obs = self.env.observations()
+                continue
             self._obs, rewards, terms, truncs, infos = self.env.step(self._actions)
             done = terms[self.agents[0]]
             for rl in self.roles.values():
                 rl.buf["rew"][:, t].copy_(torch.stack([rewards[a].float() for a in rl.agents]))
             self._done_buf[t].copy_(done)
             self._starts.copy_(done)               # the env auto-resets: the next tick starts a new episode
+            self._keep32.copy_((~done).view(1, N))
 
     @torch.no_grad()
     def collect(self, random_actions: bool = False) -> None:
@@ -602,6 +613,7 @@ class MAPPOTrainer:
         """Restart every env slot and the recurrent states (after an evaluation used the same env, or on resume)."""
         self._obs, _ = self.env.reset()
         self._starts.fill_(True)
+        self._keep32.zero_()
         for rl in self.roles.values():
             for s in rl.p_state + rl.v_state:
                 s.zero_()

@@ -21,6 +21,8 @@ class NearestRayRewardEnv:
         self._target = None
 
     def __getattr__(self, name):
+        if name == "step_raw":       # the rewards are replaced in step(): a caller must not step the wrapped env behind it
+            raise AttributeError(name)
         return getattr(self._env, name)
 
     def _targets(self, obs):

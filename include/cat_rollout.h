@@ -58,6 +58,21 @@ typedef struct cat_rollout_sample_args {
     int32_t *actions;                           /* [N][A] */
 } cat_rollout_sample_args;
 
+/* After the env tick: the agents' rewards into the rollout's [G][N] rows, and the episode-end flags (cat_outputs.terminated,
+   u8 [N]) as the rollout keeps them: done_out / start_out (bool = 1 byte) and keep_out = 1 - terminated as fp32 (the recurrent
+   networks' "carry the state" mask of the NEXT tick).  Any of the three flag outputs may be NULL. */
+typedef struct cat_rollout_post_args {
+    int32_t N, A, G, pad;
+    int32_t agent[CAT_ROLLOUT_MAX_AGENTS];
+    const float *reward;                        /* [N][A] (cat_outputs.reward) */
+    const uint8_t *terminated;                  /* [N] */
+    float *reward_out;                          /* [G][N], row stride sr_g */
+    int64_t sr_g;
+    uint8_t *done_out, *start_out;              /* [N] */
+    float *keep_out;                            /* [N] */
+} cat_rollout_post_args;
+int cat_rollout_post(const cat_rollout_post_args *a, void *stream);
+
 int cat_rollout_abi_version(void);
 const char *cat_rollout_last_error(void);
 int cat_rollout_pack(const cat_rollout_pack_args *a, void *stream);

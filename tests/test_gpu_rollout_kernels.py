@@ -59,3 +59,19 @@ def test_sampled_actions_follow_the_inverse_cdf_and_land_in_the_action_matrix():
     assert bool((actions[:, [0, 3]] == 7).all())
     freq = torch.stack([(got == k).float().mean() for k in range(4)])
     assert float((freq - logp_all.exp().mean((0, 1))).abs().max()) < 0.02        # empirical frequencies follow the mean probabilities
+
+
+def test_post_step_rewards_and_flags():
+    import torch
+    from as_cops_and_thieves_amd import _learn_native as ln
+    N, A = 3000, 5
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    raw = {"reward": torch.randn(N, A, generator=gen, device="cuda"), "terminated": (torch.rand(N, generator=gen, device="cuda") < 0.3).to(torch.uint8)}
+    buf = torch.zeros(3, 4, N, device="cuda")
+    done, start = torch.zeros(N, dtype=torch.bool, device="cuda"), torch.ones(N, dtype=torch.bool, device="cuda")
+    keep = torch.full((1, N), 7.0, device="cuda")
+    ln.rollout_post(raw, [4, 0, 2], buf[:, 1], done, start, keep)
+    torch.cuda.synchronize()
+    assert torch.equal(buf[:, 1], raw["reward"].t()[[4, 0, 2]]) and not bool(buf[:, [0, 2, 3]].any())
+    want = raw["terminated"].bool()
+    assert torch.equal(done, want) and torch.equal(start, want) and torch.equal(keep[0], (~want).float())
