@@ -48,13 +48,14 @@ __device__ __forceinline__ size_t cell_index(int t, int g, int G, int nblk, int 
     return (((((size_t)(t * G + g) * nblk + blk) * NW + w) * 2 + which) * 2 + hh) * (LANES * 4) + lane * 4;
 }
 
-__global__ __launch_bounds__(NW *LANES) void lstm_seq_fwd_kernel(const cat_lstm_fwd a)
+// SAVE = training (keeps what backward needs; one workgroup per CU at its register count); !SAVE = inference (rollout
+// ticks: thousands of sequences, nothing kept): compiled to fit two workgroups per CU, which hide each other's latencies
+template <bool SAVE>
+__global__ __launch_bounds__(NW *LANES, SAVE ? 1 : 2) void lstm_seq_fwd_kernel(const cat_lstm_fwd a)
 {
     __shared__ __attribute__((aligned(16))) __bf16 hbuf[2][BM][HPAD];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, r = l & 15;
-    const int g = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x, G = a.d.G, T = a.d.T, B = a.d.B;
-    const int b = blk * BM + r;
-    const bool row_ok = b < B;
+    const int g = blockIdx.y, G = a.d.G, T = a.d.T, B = a.d.B, nblk = (B + BM - 1) / BM;
     const int hid0 = 32 * w + 4 * q;                       // + 16 * hh: this lane's four hidden units of half hh
 
     // W_hh fragments: A[row = gate column n0 + r][k = 32 ks + 8 q + j]
@@ -69,18 +70,21 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_fwd_kernel(const cat_lstm_
                 for (int ks = 0; ks < 4; ++ks)
                     wf[gt][hh][ks] = *(const bf16x8 *)(wg + (size_t)(gt * H + 32 * w + 16 * hh + r) * H + 32 * ks + 8 * q);
     }
-    const __bf16 *xg = (const __bf16 *)a.xproj + (size_t)g * a.sx_g + (size_t)b * a.sx_b;
-    __bf16 *og = (__bf16 *)a.out + (size_t)g * a.so_g + (size_t)b * a.so_b;
-    const size_t state_row = ((size_t)g * B + b) * H;
-    const bool save = a.saved_acts != nullptr;
-
-    f32x4 bias[4][2];
+    constexpr bool save = SAVE;
+    bf16x4 bias[4][2];                                     // kept packed: registers are what limits this kernel to two per CU
 #pragma unroll
     for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
-            bias[gt][hh] = a.bias ? widen(*(const bf16x4 *)((const __bf16 *)a.bias + (size_t)g * a.sb_g + gt * H + hid0 + 16 * hh))
-                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+            bias[gt][hh] = a.bias ? *(const bf16x4 *)((const __bf16 *)a.bias + (size_t)g * a.sb_g + gt * H + hid0 + 16 * hh) : zero4();
+    // a workgroup takes the 16-sequence blocks blk, blk + gridDim.x, ...: one each in training (the grid covers them), several
+    // when there are more blocks than the device holds at once (a rollout tick of thousands of envs) -- W_hh is loaded once
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int b = blk * BM + r;
+    const bool row_ok = b < B;
+    const __bf16 *xg = (const __bf16 *)a.xproj + (size_t)g * a.sx_g + (size_t)b * a.sx_b;
+    __bf16 *og = (__bf16 *)a.out + (size_t)g * a.so_g + (size_t)b * a.so_b;
+    const size_t state_row = ((size_t)g * B + b) * H;
     f32x4 c[2];
     {
         const float k0 = (a.keep && row_ok) ? a.keep[b] : 1.0f;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_fwd_kernel(const cat_lstm_
             c[hh] = widen(row_ok ? *(const bf16x4 *)((const __bf16 *)a.c0 + state_row + hid) : zero4()) * k0;
             const bf16x4 hb = narrow(h);
             *(bf16x4 *)&hbuf[0][r][hid] = hb;
-            if (a.h_in && row_ok) *(bf16x4 *)((__bf16 *)a.h_in + (((size_t)g * T + 0) * B + b) * H + hid) = hb;
+            if (SAVE && a.h_in && row_ok) *(bf16x4 *)((__bf16 *)a.h_in + (((size_t)g * T + 0) * B + b) * H + hid) = hb;
         }
     }
     __syncthreads();
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_fwd_kernel(const cat_lstm_
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) acc[gt][hh] = widen(xn[gt][hh]) + bias[gt][hh];
+            for (int hh = 0; hh < 2; ++hh) acc[gt][hh] = widen(xn[gt][hh]) + widen(bias[gt][hh]);
         const float kn = kn_next;
         fetch(t + 1);
 #pragma unroll
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_fwd_kernel(const cat_lstm_
             if (t + 1 < T) {
                 const bf16x4 hb = narrow(hy * kn);
                 *(bf16x4 *)&hbuf[cur ^ 1][r][hid] = hb;
-                if (a.h_in && row_ok) *(bf16x4 *)((__bf16 *)a.h_in + (((size_t)g * T + t + 1) * B + b) * H + hid) = hb;
+                if (SAVE && a.h_in && row_ok) *(bf16x4 *)((__bf16 *)a.h_in + (((size_t)g * T + t + 1) * B + b) * H + hid) = hb;
                 c[hh] = cy * kn;
             } else if (row_ok) {
                 *(bf16x4 *)((__bf16 *)a.h_last + state_row + hid) = narrow(hy);
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_fwd_kernel(const cat_lstm_
         }
         __syncthreads();
     }
+    }   // blocks of this workgroup
 }
 
 __global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_bwd a)
@@ -335,7 +340,16 @@ extern "C" int cat_lstm_seq_forward(const cat_lstm_fwd *a, void *stream)
         !aligned(a->h_last, 8) || !aligned(a->c_last, 8) || !aligned(a->h_in, 8) || !aligned(a->saved_acts, 8) || !aligned(a->saved_cell, 8) ||
         !aligned(a->bias, 8) || (a->bias && (a->sb_g % 4)))
         return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_forward: misaligned buffer or stride");
-    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(blocks_of(a->d), a->d.G), dim3(NW * LANES), 0, (hipStream_t)stream, *a);
+    // more blocks than one resident round of the device (one workgroup per CU at this register count): fold them
+    const int nb = blocks_of(a->d);
+    if (a->saved_acts) {
+        if (!a->h_in) return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_forward: h_in goes with the saved buffers");
+        const int rounds = (nb * a->d.G + 255) / 256;
+        hipLaunchKernelGGL(lstm_seq_fwd_kernel<true>, dim3((nb + rounds - 1) / rounds, a->d.G), dim3(NW * LANES), 0, (hipStream_t)stream, *a);
+    } else {
+        const int rounds = (nb * a->d.G + 511) / 512;      // two workgroups per CU are resident
+        hipLaunchKernelGGL(lstm_seq_fwd_kernel<false>, dim3((nb + rounds - 1) / rounds, a->d.G), dim3(NW * LANES), 0, (hipStream_t)stream, *a);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAT_LSTM_OK : fail(CAT_LSTM_ERR_HIP, hipGetErrorString(e));
 }

@@ -94,9 +94,11 @@ class _LSTMSeq(torch.autograd.Function):
     CPU (the parity tests, ``compute_bf16=False``): the same recurrence step by step in torch."""
 
     @staticmethod
-    def forward(ctx, xproj, w_hh, b_ih, b_hh, h0, c0, keep, state_out=None):
+    def forward(ctx, xproj, w_hh, b_ih, b_hh, h0, c0, keep, state_out=None, grad_mode=True):
         G, T, B, _ = xproj.shape
-        train = any(ctx.needs_input_grad)          # a rollout tick (no_grad) keeps nothing
+        # ``grad_mode`` = torch.is_grad_enabled() at the CALL (inside a Function's forward it always reads False, and
+        # needs_input_grad stays True for parameters under no_grad): a rollout tick keeps nothing for a backward pass
+        train = grad_mode and any(ctx.needs_input_grad)
         ctx.has_keep = keep is not None
         ctx.set_materialize_grads(False)           # unused final-state gradients arrive as None, not as zero tensors
         ctx.native = xproj.is_cuda and xproj.dtype == torch.bfloat16
@@ -165,7 +167,7 @@ class _LSTMSeq(torch.autograd.Function):
         a = dg_all.reshape(G, T * B, dg_all.shape[3])
         hin = h_in.reshape(G, T * B, h_in.shape[3])
         d_w = _weight_grad(a, hin, w_slot) if ctx.native else torch.bmm(a.transpose(1, 2), hin)   # one product over all steps
-        return dg_all, d_w, d_bih, d_bhh, dh, dc, None, None
+        return dg_all, d_w, d_bih, d_bhh, dh, dc, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------- flat parameters
@@ -430,7 +432,7 @@ class StackedNet:
                 xp, b_ih, b_hh = _lin(inp, w_ih, b_ih + b_hh).view(G, T, B, 4 * HIDDEN), None, None
             in_place = update_state and native and not torch.is_grad_enabled() and h0.dtype == dt
             out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), b_ih, b_hh, h0[l].to(dt), c0[l].to(dt), kp,
-                                         (h0[l], c0[l]) if in_place else None)
+                                         (h0[l], c0[l]) if in_place else None, torch.is_grad_enabled())
             hs.append(hT); cs.append(cT)
             inp = out.reshape(G, N, HIDDEN)
         y = inp

@@ -90,7 +90,7 @@ def test_inference_call_keeps_nothing_and_equals_the_training_forward():
     from as_cops_and_thieves_amd.selfplay.stacked import _LSTMSeq
     xproj, w_hh, h0, c0, keep = _case(3, 1, 4096, True, seed=3)
     with torch.no_grad():
-        o1, h1, c1 = _LSTMSeq.apply(xproj, w_hh, None, None, h0, c0, keep)
+        o1, h1, c1 = _LSTMSeq.apply(xproj, w_hh, None, None, h0, c0, keep, None, torch.is_grad_enabled())   # as StackedNet calls it
     leaves = [t.detach().clone().requires_grad_(True) for t in (xproj, w_hh, h0, c0)]
     o2, h2, c2 = _LSTMSeq.apply(leaves[0], leaves[1], None, None, leaves[2], leaves[3], keep)
     torch.cuda.synchronize()
