@@ -70,6 +70,8 @@ struct GridDesc {
     int row_base, pad1;         // into grid_rows, in rows of Params::row_words words
 };
 
+struct BlockDesc { MapDesc md; GridDesc gd; };   // per workgroup: one load instead of block_map -> maps / grids
+
 struct Params {
     int N, A, n_cops, R, max_step, iterations, persistence, gate, NP, maxc;
     long long env_id_offset;
@@ -88,6 +90,7 @@ struct Params {
     unsigned *err_word;     // device-side error flags (CAT_DEVERR_*), read back by cat_device_errors
     const int *work_env;    // [n_blocks*wpb] env slot or -1
     const int *block_map;   // [n_blocks]
+    const BlockDesc *block_desc;   // [n_blocks]: maps[block_map[b]], grids[block_map[b]]
     // Env state: one contiguous record per env slot (so a wave moves it with 16-byte lanes), in two parts:
     //   HOT  (always moved)   f64  pos[2A] vel[2A] vbias[2A] tc[2A] leaf[4A]   i32  step_count reset_count done cache_live
     //   COLD (arbiter caches) f64  wall_jn[8A] pair_jn[NPs]                    i32  wall_shape[8A] wall_age[8A] pair_age[NPs]
@@ -1627,9 +1630,14 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
 #ifdef CAT_WAVE_SPREAD
     const unsigned long long spread_t0 = __builtin_readcyclecounter();
 #endif
-    const MapDesc md = p.maps[p.block_map[blockIdx.x]];
-    const GridDesc gd = p.grids[p.block_map[blockIdx.x]];
+    // the serial front of the launch is a chain of dependent global round trips (parameters -> descriptors -> geometry,
+    // env id -> state / actions) during which no wave has work: descriptors come with one load per workgroup, and the
+    // agents' actions are requested as soon as the env id is known, beside the state record
     const int env = uni(p.work_env[blockIdx.x * W + wave]);
+    int act_pref = 0;
+    if (la.actions && env >= 0 && lane < D::A(p)) act_pref = la.actions[(size_t)env * D::A(p) + lane];
+    const MapDesc md = p.block_desc[blockIdx.x].md;
+    const GridDesc gd = p.block_desc[blockIdx.x].gd;
     const Lds L = carve<D>(p, smem, md, wave, wave);
     if (lane < 4) L.ctrl[4 * wave + lane] = lane == 3 ? env : 0;   // claimed, done, published, env id
     StateRegs sregs;
@@ -1656,7 +1664,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
             const int i = lane;
             const double m_inv = 1.0 / p.mass;
             int act;
-            if (la.actions) act = la.actions[(size_t)env * A + i];
+            if (la.actions) act = act_pref;
             else { unsigned rnd[4]; philox_env(p, env, (unsigned)la.synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
             if ((unsigned)act > 3u) atomicOr(p.err_word, CAT_DEVERR_BAD_ACTION);   // applied as "no impulse", and flagged
             double jx = 0.0, jy = 0.0;
@@ -2237,6 +2245,14 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     TRY_ALLOC(dev_alloc(s, &p.err_word, 1, nullptr));
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.work_env), work.size(), work.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.block_map), block_map.size(), block_map.data()));
+    {
+        std::vector<BlockDesc> bd(block_map.size());
+        for (size_t b = 0; b < block_map.size(); b++) {
+            bd[b].md = descs[block_map[b]];
+            bd[b].gd = s->grid.desc.empty() ? GridDesc{} : s->grid.desc[block_map[b]];
+        }
+        TRY_ALLOC(dev_alloc(s, const_cast<BlockDesc **>(&p.block_desc), bd.size(), bd.data()));
+    }
     TRY_ALLOC(dev_alloc(s, &p.state, rec0.size(), rec0.data()));
 #undef TRY_ALLOC
     // ---- ray-direction cone parameters: valid when the table is a uniform full circle
