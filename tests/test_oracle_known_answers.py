@@ -298,3 +298,84 @@ def test_single_wall_map_is_gated_like_any_other_wall(tmp_path):
     assert gated["obs_type"][0, 0, 0] == EMPTY                       # this build: the wall is never visited
     ungated = sim_for(cmap, bbtree_gate=0).reset(positions=pos2)
     assert ungated["obs_type"][0, 0, 0] == WALL and ungated["hit_shape"][0, 0, 0] == 0   # what an ungated root reports
+
+
+def short_wall(tmp_path, agents):
+    """One 5 x 40 block: corners (300, 380), (305, 380), (305, 420), (300, 420)."""
+    return make_map(tmp_path, [{"type": "rect", "x": 300, "y": 380, "w": 5, "h": 40}], agents)
+
+
+def test_ray_hits_a_rounded_corner_at_the_computed_distance(tmp_path):
+    """The +x ray (radius 1) from (200, 379.25) passes 0.75 above the corner (300, 380) of a wall of radius 1: outside the
+    face's extent, inside the corner circle of radius 1 + 1, met at x = 300 - sqrt(4 - 0.75^2).  [CP CircleSegmentQuery]
+    reports the swept circle's centre moved one ray radius towards the corner; the observation is the f16 of that
+    point's distance (entity.py:200-215)."""
+    y = 379.25
+    s = sim_for(short_wall(tmp_path, [{"type": "cop", "x": 200, "y": y}, {"type": "thief", "x": 100, "y": 100}]))
+    out = s.reset(positions=np.array([[[200, y], [100, 100]]], float))
+    cx = 300.0 - np.sqrt(4.0 - (380.0 - y) ** 2)                          # swept centre at impact: (cx, y)
+    ux, uy = (cx - 300.0) / 2.0, (y - 380.0) / 2.0                         # unit vector corner -> centre
+    px, py = cx - ux * 1.0, y - uy * 1.0                                   # one ray radius back towards the corner
+    # the reference's pipeline (entity.py:206-210): point and position are float16 BEFORE they are subtracted
+    d16 = np.array([px, py], np.float16) - np.array([200.0, y], np.float16)
+    want = np.hypot(d16[0], d16[1])
+    assert want.dtype == np.float16 and want == np.float16(99.0) and np.float16(np.hypot(px - 200.0, py - y)) == np.float16(99.0625)
+    assert out["obs_type"][0, 0, 0] == WALL and F16(out["obs_distance"])[0, 0, 0] == want
+    if hasattr(s, "segment_query"):
+        sh, alpha, pt = s.segment_query(0, 0, (200, y), (600, y), 1.0)
+        assert sh == 0 and alpha == pytest.approx((cx - 200.0) / 400.0, abs=1e-14) and pt == pytest.approx((px, py), abs=1e-12)
+
+
+@pytest.mark.parametrize("y,gate,hit", [(378.9, True, False), (378.9, False, True), (377.9, False, False)])
+def test_ray_grazing_a_corner_and_the_bbtree_gate(tmp_path, y, gate, hit):
+    """At y = 378.9 the ray's swept circle would touch the corner circle (1.1 < 2 away), but its CENTRE LINE misses the
+    wall's bounding box (inflated by the wall radius only: 379): Chipmunk's BBTree walks the thin segment
+    ([CP cpBBSegmentQuery], the query radius is not applied to the tree), so the wall is never visited -- EMPTY at the full
+    ray length.  With the gate off (every shape visited) the same ray reports the wall; 2.1 away nothing is hit either way."""
+    s = sim_for(short_wall(tmp_path, [{"type": "cop", "x": 200, "y": y}, {"type": "thief", "x": 100, "y": 100}]), bbtree_gate=gate)
+    out = s.reset(positions=np.array([[[200, y], [100, 100]]], float))
+    if hit:
+        assert out["obs_type"][0, 0, 0] == WALL and 98.0 < float(F16(out["obs_distance"])[0, 0, 0]) < 100.0
+    else:
+        assert out["obs_type"][0, 0, 0] == EMPTY and F16(out["obs_distance"])[0, 0, 0] == np.float16(400.0)
+
+
+@pytest.mark.parametrize("gate", [True, False])
+def test_origin_within_the_ray_radius_of_a_wall_reports_the_segment_end(tmp_path, gate):
+    """[CP cpShapeSegmentQuery]: when the query's start point is within the query radius of the shape the hit is at
+    alpha = 0 and Pymunk's SegmentQueryInfo carries the segment END as its point, so the reference's distance
+    (entity.py:200-215: |point - position|) is the full ray length, classified WALL.  Injected position: 0.5 from the
+    wall's surface (an agent of radius 5 cannot get there by itself), i.e. 0.5 OUTSIDE the wall's bounding box: through
+    the BBTree only the rays whose centre line enters the box visit the wall (+x and the two diagonals beside it); with
+    the gate off every ray of the fan reports it.  All eight distances are the ray length (to float16) either way."""
+    s = sim_for(one_wall(tmp_path, [{"type": "cop", "x": 298.5, "y": 400}, {"type": "thief", "x": 100, "y": 100}]), bbtree_gate=gate)
+    out = s.reset(positions=np.array([[[298.5, 400], [100, 100]]], float))
+    assert (np.abs(F16(out["obs_distance"])[0, 0].astype(np.float64) - 400.0) <= 0.25).all()      # float16 end points
+    seen = out["obs_type"][0, 0] == WALL
+    assert seen.tolist() == ([True] * 8 if not gate else [True, True, False, False, False, False, False, True])
+    assert (out["obs_type"][0, 0][~seen] == EMPTY).all() and (out["hit_shape"][0, 0][seen] == 0).all()
+    # 1.5 from the surface (> the ray radius): an ordinary fan again -- the +x ray hits at once, the -x ray sees nothing
+    out = s.reset(positions=np.array([[[297.5, 400], [100, 100]]], float))
+    assert out["obs_type"][0, 0, 0] == WALL and F16(out["obs_distance"])[0, 0, 0] == np.float16(1.5)
+    assert out["obs_type"][0, 0, 4] == EMPTY
+
+
+def test_mirrored_scenes_evolve_as_mirror_images(tmp_path):
+    """Two walls placed symmetrically about x = 640; a cop pushes diagonally into the left wall in env 0 and the mirrored cop
+    into the right wall in env 1 (actions -x <-> +x swapped), 150 ticks of contact, sliding and soft correction.  Every
+    operation of the step is sign-symmetric, but the scenes use different absolute coordinates, so the trajectories agree
+    as mirror images up to rounding: |x0 + x1 - 1280| and |y0 - y1| stay below 1e-9, velocities mirror likewise."""
+    blocks = [{"type": "rect", "x": 300, "y": 0, "w": 5, "h": 800}, {"type": "rect", "x": 975, "y": 0, "w": 5, "h": 800}]
+    cmap = make_map(tmp_path, blocks, [{"type": "cop", "x": 330, "y": 300}, {"type": "thief", "x": 640, "y": 700}])
+    cfg = SimConfig(n_envs=2, n_cops=1, n_thieves=1, n_rays=8, max_step_count=1000)
+    s = make_sim(cfg, [cmap])
+    s.reset(positions=np.array([[[330.0, 300.0], [640.0, 700.0]], [[950.0, 300.0], [640.0, 700.0]]]))
+    for t in range(150):
+        a = (0, 2) if t % 3 else (1, 1)                              # mostly into the wall (-x / +x), every third tick +y
+        s.step(np.array([[a[0], 3], [a[1], 3]], np.int32))
+    st = s.get_state()
+    (x0, y0), (x1, y1) = st["pos"][0, 0], st["pos"][1, 0]
+    assert x0 < 320 and x1 > 960                                     # both reached their wall
+    assert abs(x0 + x1 - 1280.0) < 1e-9 and abs(y0 - y1) < 1e-9
+    assert abs(st["vel"][0, 0, 0] + st["vel"][1, 0, 0]) < 1e-9 and abs(st["vel"][0, 0, 1] - st["vel"][1, 0, 1]) < 1e-9
+    assert y0 > 300.0 + 100.0                                        # it slid along the wall meanwhile (frictionless)
