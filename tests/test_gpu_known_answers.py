@@ -58,7 +58,8 @@ from tests.test_oracle_known_answers import (  # noqa: E402,F401
     test_spawn_sampling_respects_regions_and_falls_back_to_centre, test_termination_is_one_tick_late_and_timeout_semantics,
     test_two_agents_collide_inelastically, test_vertex_region_behind_an_adjacent_edge_is_not_a_contact,
     test_ray_hits_a_rounded_corner_at_the_computed_distance, test_ray_grazing_a_corner_and_the_bbtree_gate,
-    test_origin_within_the_ray_radius_of_a_wall_reports_the_segment_end, test_mirrored_scenes_evolve_as_mirror_images)
+    test_origin_within_the_ray_radius_of_a_wall_reports_the_segment_end, test_mirrored_scenes_evolve_as_mirror_images,
+    test_circle_against_a_hull_corner_loses_exactly_its_normal_velocity)
 
 
 def test_philox_known_answers_through_the_device_action_stream():

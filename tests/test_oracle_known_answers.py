@@ -379,3 +379,34 @@ def test_mirrored_scenes_evolve_as_mirror_images(tmp_path):
     assert abs(x0 + x1 - 1280.0) < 1e-9 and abs(y0 - y1) < 1e-9
     assert abs(st["vel"][0, 0, 0] + st["vel"][1, 0, 0]) < 1e-9 and abs(st["vel"][0, 0, 1] - st["vel"][1, 0, 1]) < 1e-9
     assert y0 > 300.0 + 100.0                                        # it slid along the wall meanwhile (frictionless)
+
+
+def test_circle_against_a_hull_corner_loses_exactly_its_normal_velocity(tmp_path):
+    """An agent driven diagonally at the corner (300, 380) of a wall: [CP ClosestPoints / cpArbiterApplyImpulse] with
+    e = 0 and no friction remove the velocity component along the contact normal -- the unit vector from the corner to
+    the agent's centre at the tick's collision phase (positions are integrated BEFORE the collision phase, so that is
+    the position the tick ends with) -- and leave the tangential component alone."""
+    s = sim_for(short_wall(tmp_path, [{"type": "cop", "x": 288, "y": 370}, {"type": "thief", "x": 100, "y": 100}]))
+    s.reset(positions=np.array([[[288.0, 370.0], [100.0, 100.0]]]))
+    s.set_state(vel=np.array([[[60.0, 50.0], [0.0, 0.0]]]))
+    hit = None
+    for t in range(40):
+        before = s.get_state()["vel"][0, 0].copy()
+        s.step(np.array([[2, 3]], np.int32))                           # keep pushing +x
+        st = s.get_state()
+        if (st["wall_shape"][0, 0] == 0).any() and (st["wall_jn"][0, 0] > 0).any():
+            hit = (t, before, st)
+            break
+    assert hit is not None and hit[0] > 2, "the agent never reached the corner"
+    t, before, st = hit
+    c = st["pos"][0, 0] - np.array([300.0, 380.0])
+    dist = np.hypot(*c)
+    assert 5.0 < dist <= 6.0 + 1e-9 and st["pos"][0, 0, 1] < 380.0           # touching the CORNER (above the face's extent)
+    n, tang = c / dist, np.array([-c[1], c[0]]) / dist
+    v_in = before + np.array([10.0, 0.0])                                      # the tick's impulse is applied first,
+    if np.hypot(*v_in) > 125.0:                                                # then the speed clamp (entity.py:126-134)
+        v_in = v_in / np.hypot(*v_in) * 125.0
+    v_out = st["vel"][0, 0]
+    assert abs(v_out @ n) < 1e-9                                               # no approach velocity left
+    assert v_out @ tang == pytest.approx(v_in @ tang, abs=1e-9)                # frictionless: tangential part untouched
+    assert v_in @ n < -1.0                                                     # it really was approaching
