@@ -127,21 +127,21 @@ def build_sim(map_name: str, cops: int, thieves: int, envs: int, rays: int, rank
     return CatSim(cfg, cmaps, slot, device=dev), cfg, cmap
 
 
-def timed_steps(sim, steps: int, warmup: int, fence, hip: "HipEvents"):
+def timed_steps(sim, steps: int, warmup: int, fence, hip: "HipEvents", first_tick: int = 0):
     """W untimed + K timed rollout steps (cat_step_fused: in-kernel Philox actions + tick + auto-reset, ONE launch per
     step).  Every EVENT_EVERY-th tick_kernel launch of the timed region carries a pair of HIP events attached to the
     dispatch itself (hipExtLaunchKernelGGL start/stop events, on the stream the kernel is launched on), so kernel_ms is
     the kernel's own duration, as in a rocprofv3 kernel trace; events recorded AROUND the call would add the
     inter-kernel dispatch gap (~5 us here).  Returns (seconds of the timed region on this rank, mean kernel ms, launches timed)."""
     for t in range(warmup):
-        sim.step_fused(None, tick=t, auto_reset=True)
+        sim.step_fused(None, tick=first_tick + t, auto_reset=True)
     ev = {k: (hip.create(), hip.create()) for k in range(0, steps, EVENT_EVERY)}
     fence()
     t0 = time.perf_counter()
     for k in range(steps):
         if k in ev:
             sim.arm_kernel_timing(*ev[k])
-        sim.step_fused(None, tick=warmup + k, auto_reset=True)
+        sim.step_fused(None, tick=first_tick + warmup + k, auto_reset=True)
     fence()
     elapsed = time.perf_counter() - t0
     return elapsed, sum(hip.elapsed_ms(a, b) for a, b in ev.values()) / len(ev), len(ev)
@@ -187,6 +187,9 @@ def main() -> None:
     ap.add_argument("--map", default="labyrinth")
     ap.add_argument("--cops", type=int, default=2)
     ap.add_argument("--thieves", type=int, default=1)
+    ap.add_argument("--burn-in", type=int, default=400, help="untimed ticks after the reset and BEFORE the warm-up: one episode length, "
+                    "so that a short timed region (the driver's --steps 20 --warmup 5) does not measure the cold start of 4096 "
+                    "synchronised fresh episodes but the running batch, auto-resets included")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE shapes (the `extra` object)")
     args = ap.parse_args()
@@ -239,7 +242,9 @@ def main() -> None:
     hip = HipEvents()
     sim, cfg, cmap = build_sim(args.map, args.cops, args.thieves, args.envs, args.rays, rank, dev)
     sim.reset()
-    elapsed, tick_ms, n_timed = timed_steps(sim, args.steps, args.warmup, fence, hip)
+    for t in range(args.burn_in):
+        sim.step_fused(None, tick=t, auto_reset=True)
+    elapsed, tick_ms, n_timed = timed_steps(sim, args.steps, args.warmup, fence, hip, first_tick=args.burn_in)
     elapsed = max_over_ranks(elapsed, device=None if rehearse else dev)   # the slowest rank bounds the whole-job rate
     episodes = int(sim.get_state()["reset_count"].sum().item())
     sim.close()
@@ -299,7 +304,7 @@ def main() -> None:
                                    f"{R} rays/agent, dt=1/60, max_step_count=400, Philox random actions, auto-reset",
                        "envs_per_gpu": cfg.n_envs, "rays": R, "agents": A, "map": args.map,
                        "parallelism": f"env-sharded x{world}, no data-path collective",
-                       "episodes_reset_per_gpu": episodes, "env_id_offsets": offsets},
+                       "episodes_reset_per_gpu": episodes, "burn_in_steps": args.burn_in, "env_id_offsets": offsets},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "tick_kernel", "kernel_ms": tick_ms, "kernel_launches_timed": n_timed,
