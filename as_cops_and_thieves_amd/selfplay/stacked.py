@@ -353,24 +353,35 @@ class _ConvTrunk(torch.autograd.Function):
         return None, dw1, db1, dw2, db2, None
 
 
-def _conv_as_dense_indices(c_out: int, c_in: int, k: int, stride: int, l_in: int, in_layout: str, device):
-    """Index tensors for ``_Expand``: the [l_out * c_out, l_in * c_in] matrix of Conv1d(c_in, c_out, k, stride) on an input
-    flattened as (channel, position) [``in_layout`` "cl", the observation vector] or (position, channel) ["lc", the
-    previous stacked layer's output]; outputs are flattened (position, channel).  Also the tiling of the bias."""
+DENSE_PAD = 1     # widths of the dense-trunk layers can be zero-padded to multiples of this (padding did not avoid the fault below)
+DENSE_ROWS = 4096  # and their products run over at most this many rows at a time
+
+
+def _conv_as_dense_indices(c_out: int, c_in: int, k: int, stride: int, l_in: int, in_layout: str, device,
+                           in_width: Optional[int] = None, out_multiple: int = 1):
+    """Index tensors for ``_Expand``: the [rows, cols] matrix of Conv1d(c_in, c_out, k, stride) on an input flattened as
+    (channel, position) [``in_layout`` "cl", the observation vector] or (position, channel) ["lc", the previous stacked
+    layer's output]; outputs are flattened (position, channel).  cols = ``in_width`` >= l_in * c_in and rows = l_out * c_out
+    rounded up to ``out_multiple``: the extra rows / columns are zero weights (and zero biases).  Also the tiling of the
+    bias.  Returns (idx, back, b_idx, b_back, l_out, rows)."""
     l_out = (l_in - k) // stride + 1
     n_w = c_out * c_in * k
-    idx = torch.full((l_out * c_out, l_in * c_in), n_w, dtype=torch.long)
-    back = torch.full((n_w, l_out), l_out * c_out * l_in * c_in, dtype=torch.long)
+    cols = l_in * c_in if in_width is None else in_width
+    rows = -(-(l_out * c_out) // out_multiple) * out_multiple
+    assert cols >= l_in * c_in
+    idx = torch.full((rows, cols), n_w, dtype=torch.long)
+    back = torch.full((n_w, l_out), rows * cols, dtype=torch.long)
     lo, co, ci, kk = torch.meshgrid(torch.arange(l_out), torch.arange(c_out), torch.arange(c_in), torch.arange(k), indexing="ij")
     pos = stride * lo + kk
     col = (ci * l_in + pos) if in_layout == "cl" else (pos * c_in + ci)
     row = lo * c_out + co
     w_id = (co * c_in + ci) * k + kk                                        # flat index into weight [c_out, c_in, k]
     idx[row.reshape(-1), col.reshape(-1)] = w_id.reshape(-1)
-    back[w_id.reshape(-1), lo.reshape(-1)] = (row * (l_in * c_in) + col).reshape(-1)
-    b_idx = torch.arange(c_out).repeat(l_out)                                # bias of output (l, c) = bias[c]
+    back[w_id.reshape(-1), lo.reshape(-1)] = (row * cols + col).reshape(-1)
+    b_idx = torch.full((rows,), c_out, dtype=torch.long)                     # c_out selects the appended zero
+    b_idx[:l_out * c_out] = torch.arange(c_out).repeat(l_out)                # bias of output (l, c) = bias[c]
     b_back = (torch.arange(l_out).unsqueeze(0) * c_out + torch.arange(c_out).unsqueeze(1))   # [c_out, l_out]
-    return idx.reshape(-1).to(device), back.to(device), b_idx.to(device), b_back.to(device), l_out
+    return idx.reshape(-1).to(device), back.to(device), b_idx.to(device), b_back.to(device), l_out, rows
 
 
 class StackedNet:
@@ -389,8 +400,15 @@ class StackedNet:
         # their unfold backward, and GEMMs with a 10..320-wide inner dimension over half a million rows.
         # (bf16 on the GPU with R <= 64 the two convolutions are one kernel instead, ``_ConvTrunk``.)
         self.fused_trunk = os.environ.get("CAT_DENSE_TRUNK", "0") != "1"
-        self.t1 = _conv_as_dense_indices(64, self.C, 5, 2, R, "cl", dev)
-        self.t2 = _conv_as_dense_indices(32, 64, 5, 3, self.L1, "lc", dev)
+        # With R = 90 the BLAS library's batched GEMM of the second layer faulted at training size on this stack (a memory
+        # access fault inside its kernel for [3 x 16384 x 2752] x [2752 x 416], also zero-padded to 2816 / 512; the same call
+        # in isolation passes: it depends on where its operands lie).  Rollout-tick sizes (4096 rows) and the R = 64 widths
+        # have run for hours.  So: at most DENSE_ROWS rows per product (zero-padding the widths to multiples of DENSE_PAD is
+        # available but did not help).
+        up = lambda n: -(-n // DENSE_PAD) * DENSE_PAD
+        self.in1 = up(self.C * R)
+        self.t1 = _conv_as_dense_indices(64, self.C, 5, 2, R, "cl", dev, in_width=self.in1, out_multiple=DENSE_PAD)
+        self.t2 = _conv_as_dense_indices(32, 64, 5, 3, self.L1, "lc", dev, in_width=self.t1[5], out_multiple=DENSE_PAD)
         assert self.t1[4] == self.L1 and self.t2[4] == self.L2
 
     def w(self, name: str) -> torch.Tensor:
@@ -412,12 +430,23 @@ class StackedNet:
             z = _ConvTrunk.apply(z, self.w("trunk.features.0.weight"), self.w("trunk.features.0.bias"),
                                  self.w("trunk.features.2.weight"), self.w("trunk.features.2.bias"), self.R)
         else:   # fp32 / CPU, or a ray count whose intermediate does not fit the LDS (R = 90): dense GEMMs
-            for name, (idx, back, b_idx, b_back, l_out), c_out, width in (("trunk.features.0", self.t1, 64, self.C * self.R),
-                                                                           ("trunk.features.2", self.t2, 32, self.L1 * 64)):
-                w = _Expand.apply(self.w(name + ".weight").reshape(G, -1), idx, back).view(G, l_out * c_out, width)
-                b = _Expand.apply(self.w(name + ".bias"), b_idx, b_back)
-                z = torch.relu(_lin(z, w, b))                                                    # [G, N, l_out * c_out], (l, c)
+            z = torch.nn.functional.pad(z, (0, self.in1 - self.C * self.R))
+            layers = []
+            for name, (idx, back, b_idx, b_back, l_out, rows), width in (("trunk.features.0", self.t1, self.in1),
+                                                                         ("trunk.features.2", self.t2, self.t1[5])):
+                layers.append((_Expand.apply(self.w(name + ".weight").reshape(G, -1), idx, back).view(G, rows, width),
+                               _Expand.apply(self.w(name + ".bias"), b_idx, b_back)))
+            # in row chunks of DENSE_ROWS: the shapes of a rollout tick, which the BLAS library handles (see __init__)
+            outs = []
+            for r0 in range(0, N, DENSE_ROWS):
+                zc = z[:, r0:r0 + DENSE_ROWS]
+                for w, b in layers:
+                    zc = torch.relu(_lin(zc, w, b))                                              # [G, rows, l_out * c_out (+ zeros)], (l, c)
+                outs.append(zc)
+            z = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
         wfc = self.w("trunk.features.5.weight").view(G, 256, 32, self.L2).transpose(2, 3).reshape(G, 256, self.L2 * 32)
+        if z.shape[2] != self.L2 * 32:                                                           # the dense path's zero padding
+            wfc = torch.nn.functional.pad(wfc, (0, z.shape[2] - self.L2 * 32))
         f = _lin_act(z, wfc, self.w("trunk.features.5.bias"), 2)                                 # [G, T*B, 256], tanh
         h0, c0 = state
         kp = None if keep is None else keep.to(torch.float32).contiguous()

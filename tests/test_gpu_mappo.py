@@ -187,3 +187,29 @@ def test_trainer_runs_with_other_ray_counts(rays):
     for r, rl in tr.roles.items():
         assert torch.isfinite(rl.fp.master).all() and not torch.equal(rl.fp.master, before[r]) and rl._graphs
     env.close()
+
+
+def test_reference_default_ray_count_trains_at_full_batch_size(tmp_path):
+    """R = 90 (the reference's default sensor) at 4096 envs: the dense-GEMM trunk in row chunks (``stacked.DENSE_ROWS``).
+    As one [3 x 16384 x 2752] x [2752 x 416] product the BLAS library's kernel ran into a memory access fault on this stack;
+    the run is a child process so that such a fault fails this test and not the whole suite."""
+    import subprocess, sys, textwrap
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent(f"""
+        import sys, torch
+        sys.path.insert(0, {str(root)!r})
+        from as_cops_and_thieves_amd import VecCopsEnv, load_preset
+        from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, TrainerConfig
+        env = VecCopsEnv(load_preset("labyrinth"), 4096, num_rays=90, max_step_count=400)
+        tr = MAPPOTrainer(env, None, TrainerConfig(), seed=0)
+        for _ in range(3):
+            tr.collect(); tr.update()
+        torch.cuda.synchronize()
+        rl = next(iter(tr.roles.values()))
+        assert torch.isfinite(rl.fp.master).all() and rl._graphs and float(rl.steps.max()) > 0
+        print("R90_OK")
+    """))
+    res = subprocess.run([sys.executable, str(child)], cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "R90_OK" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])

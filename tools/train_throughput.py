@@ -16,7 +16,7 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 name = sys.argv[3] if len(sys.argv) > 3 else "labyrinth"
 H = int(sys.argv[4]) if len(sys.argv) > 4 else 16     # ticks per rollout (BPTT window stays 16)
 roster = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (None, None)
-env = VecCopsEnv(load_preset(name, *roster), num_envs=N, num_rays=64, max_step_count=400)
+env = VecCopsEnv(load_preset(name, *roster), num_envs=N, num_rays=int(os.environ.get("CAT_RAYS", "64")), max_step_count=400)
 tr = MAPPOTrainer(env, None, TrainerConfig(horizon=H), seed=0)      # CFG_AGENT for both roles, as the reference's driver
 for _ in range(3):                                         # eager warm-up, then the graph captures
     tr.collect(); tr.update()
