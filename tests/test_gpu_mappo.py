@@ -213,3 +213,22 @@ def test_reference_default_ray_count_trains_at_full_batch_size(tmp_path):
     """))
     res = subprocess.run([sys.executable, str(child)], cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "R90_OK" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
+
+
+def test_fp32_compute_on_the_gpu_still_trains():
+    """``compute_bf16=False``: no bf16 copy, the step-by-step recurrence and the torch loss on the GPU, the optimiser-step
+    kernels on the fp32 master weights only."""
+    import torch
+    from as_cops_and_thieves_amd import VecCopsEnv, load_preset
+    from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, RoleConfig, TrainerConfig
+    env = VecCopsEnv(load_preset("squarinth"), 256, num_rays=64, max_step_count=60, seed=2)
+    rc = RoleConfig(learning_epochs=1, mini_batches=2, random_timesteps=0, learning_starts=0)
+    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0, compute_bf16=False), seed=1)
+    rl = next(iter(tr.roles.values()))
+    before = rl.fp.master.clone()
+    for _ in range(3):
+        tr.collect(); tr.update()
+    torch.cuda.synchronize()
+    assert rl.fp.compute_dtype == torch.float32 and rl.fp.lp is rl.fp.master and not rl.native
+    assert torch.isfinite(rl.fp.master).all() and not torch.equal(before, rl.fp.master)
+    env.close()
