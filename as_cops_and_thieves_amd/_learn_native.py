@@ -310,7 +310,7 @@ def trunk_grad_finish(parts, C_in: int, R: int, slots=None):
     ``slots`` = (dw1, db1, dw2, db2) views (returns None) or returned as new tensors."""
     import torch
     pw1, pb1, pw2, pb2 = parts
-    G, nb = pw1.shape[:2]
+    G, nb = pw2.shape[:2]
     acc = slots is not None
     if not acc:
         dev = pw1.device

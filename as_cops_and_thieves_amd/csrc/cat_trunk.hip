@@ -30,6 +30,7 @@ constexpr int LDS_LIMIT = 160 * 1024;
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ bf16x4 narrow(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
@@ -55,14 +56,16 @@ struct Geo {
     {
         C = d.C; R = d.R; CR = C * R;
         L1 = (R - KW) / 2 + 1; L2 = (L1 - KW) / 3 + 1;
-        XS = CR + 40;                 // input row (ray, channel) + zeroed tail: the last windows read up to 31 past 5 C
+        XS = (CR + 40 + 7) & ~7;      // input row (ray, channel) + zeroed tail (the last windows read up to 31 past 5 C), 16-byte rows
         A1S = L1 * C1 + 8;            // forward's intermediate row (position, channel), 16-byte aligned, bank-skewed
         D2 = L2 * C2; D2S = D2 + 8;
     }
     __device__ __host__ size_t fwd_lds() const { return 2 * ((size_t)TS * XS + (size_t)TS * A1S); }
     __device__ __host__ size_t bwd_lds() const
     {
-        return 2 * ((size_t)TS * XS * 2 + (size_t)L1 * C1 * TS * 2 + (size_t)TS * D2S + (size_t)D2 * TS);
+        const size_t tiles = 2 * ((size_t)TS * XS * 2 + (size_t)L1 * C1 * TS + (size_t)TS * D2S + (size_t)D2 * TS);
+        const size_t reduce = (size_t)CAT_TRUNK_BWD_WAVES * C1 * 32 * sizeof(float);   // the waves' dW1 sums at the end of the kernel
+        return tiles > reduce ? tiles : reduce;
     }
 };
 
@@ -82,6 +85,17 @@ __device__ __forceinline__ void load_w1(const cat_trunk_params &p, int g, int C,
     }
 }
 
+// four rays of one channel; the last run of a row whose ray count is not a multiple of 4 is read ray by ray
+__device__ __forceinline__ bf16x4 load_rays(const __bf16 *chan, int ray0, int R)
+{
+    if (ray0 + 4 <= R) return *(const bf16x4 *)(chan + ray0);
+    bf16x4 v = narrow(f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ray0 + i < R) v[i] = chan[ray0 + i];
+    return v;
+}
+
 // input tile -> LDS in (ray, channel) order (and optionally [column][sample]).  Thread (sample s = t / 16, u = t % 16)
 // takes runs of 4 rays: one 8-byte load per channel, interleaved in registers, written as one run of 4 C elements.
 // Rows past N read as zero; the row tails (columns >= C R) are zeroed once per launch by clear_tails.
@@ -91,10 +105,10 @@ __device__ __forceinline__ void stage_x(const __bf16 *xg, int64_t sx_n, int n0, 
     const bool ok = n0 + s < N;
     const __bf16 *row = xg + (size_t)(n0 + s) * sx_n;
     const bf16x4 z4 = narrow(f32x4{0.f, 0.f, 0.f, 0.f});
-    for (int ch = u; ch < ge.R / 4; ch += 16) {
+    for (int ch = u; 4 * ch < ge.R; ch += 16) {
         bf16x4 v[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = (ok && c < ge.C) ? *(const bf16x4 *)(row + c * ge.R + 4 * ch) : z4;
+        for (int c = 0; c < 4; ++c) v[c] = (ok && c < ge.C) ? load_rays(row + c * ge.R, 4 * ch, ge.R) : z4;
         __bf16 *dst = xs + s * ge.XS + 4 * ch * ge.C;
         if (ge.C == 2) {
             *(bf16x8 *)dst = bf16x8{v[0][0], v[1][0], v[0][1], v[1][1], v[0][2], v[1][2], v[0][3], v[1][3]};
@@ -183,11 +197,11 @@ __global__ __launch_bounds__(NW *LANES) void trunk_fwd_kernel(const cat_trunk_fw
 }
 
 // ---- backward: 8 waves (two per SIMD: the workgroup's LDS fills the CU, so latency is hidden inside the workgroup) ----
-constexpr int NWB = 8;
+constexpr int NWB = CAT_TRUNK_BWD_WAVES;
 
 struct Raw {            // one tile's global data in flight: fetched a tile ahead, committed to LDS at the top of the loop
     bf16x4 x[4];        // thread (sample t / 32, u = t % 32): rays 4 u .. 4 u + 3 of every channel
-    bf16x4 y[3], d[3];  // runs 4 (u + 32 i) .. of the layer's output and of its gradient
+    bf16x4 y[4], d[4];  // runs 4 (u + 32 i) .. of the layer's output and of its gradient
 };
 
 __device__ __forceinline__ void fetch_raw(Raw &rw, const __bf16 *xg, int64_t sx_n, const __bf16 *og, const __bf16 *dg, int64_t so_n,
@@ -198,10 +212,10 @@ __device__ __forceinline__ void fetch_raw(Raw &rw, const __bf16 *xg, int64_t sx_
     const bf16x4 z4 = narrow(f32x4{0.f, 0.f, 0.f, 0.f});
     const __bf16 *row = xg + (size_t)(n0 + s) * sx_n;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) rw.x[c] = (ok && c < ge.C && 4 * u < ge.R) ? *(const bf16x4 *)(row + c * ge.R + 4 * u) : z4;
+    for (int c = 0; c < 4; ++c) rw.x[c] = (ok && c < ge.C && 4 * u < ge.R) ? load_rays(row + c * ge.R, 4 * u, ge.R) : z4;
     const size_t o = (size_t)(n0 + s) * so_n;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const int ch = u + 32 * i;
         const bool in = ok && 4 * ch < ge.D2;
         rw.y[i] = in ? *(const bf16x4 *)(og + o + 4 * ch) : z4;
@@ -229,7 +243,7 @@ __device__ __forceinline__ void commit_raw(const Raw &rw, const Geo &ge, __bf16 
                 if (c < ge.C) t[(i * ge.C + c) * TS] = v[c][i];
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const int ch = u + 32 * i;
         if (4 * ch < ge.D2) {                       // gradient before the second ReLU, row-major and sample-contiguous
             bf16x4 v;
@@ -249,8 +263,7 @@ __global__ __launch_bounds__(NWB *LANES) void trunk_bwd_kernel(const cat_trunk_b
     __bf16 *xs = (__bf16 *)smem;                    // [16][XS]          input rows, (ray, channel)
     __bf16 *xT = xs + TS * ge.XS;                   // [XS][16]          the same, sample-contiguous
     __bf16 *a1T = xT + TS * ge.XS;                  // [L1 * 64][16]     intermediate after ReLU, sample-contiguous
-    __bf16 *dp1T = a1T + ge.L1 * C1 * TS;           // [L1 * 64][16]     gradient before the first ReLU
-    __bf16 *dp2 = dp1T + ge.L1 * C1 * TS;           // [16][D2S]         gradient before the second ReLU
+    __bf16 *dp2 = a1T + ge.L1 * C1 * TS;            // [16][D2S]         gradient before the second ReLU
     __bf16 *dp2T = dp2 + TS * ge.D2S;               // [L2 * 32][16]     the same, sample-contiguous
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, r = l & 15;
     const int g = blockIdx.y, N = a.d.N, ntiles = (N + TS - 1) / TS;
@@ -281,9 +294,15 @@ __global__ __launch_bounds__(NWB *LANES) void trunk_bwd_kernel(const cat_trunk_b
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const bf16x8 zero8 = splat8(0.0f), ones8 = splat8(1.0f);
-    // weight-gradient tiles of this wave: dW2 row tile (w & 1), column tiles (w >> 1) + 4 i; dW1 row tile (w >> 1), column tile (w & 1)
-    const int mt2 = w & 1, ct2 = w >> 1, rt1 = w >> 1, nt1 = w & 1;
-    f32x4 dw2[5] = {zero, zero, zero, zero, zero}, dw1 = zero, db1 = zero, db2 = zero;
+    // weight-gradient tiles of this wave: dW2 row tile (w & 1), column tiles (w >> 1) + 4 i.  dW1 (and db1) is accumulated
+    // by every wave over ITS positions, all 4 x 2 tiles, straight from the accumulators that hold the gradient of the
+    // intermediate (below); the waves' sums are added up at the end of the kernel.
+    const int mt2 = w & 1, ct2 = w >> 1;
+    f32x4 dw2[5] = {zero, zero, zero, zero, zero}, db2 = zero, dw1[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) dw1[mt][0] = dw1[mt][1] = zero;
+    // window column 31 is never a real tap (5 C <= 20): it carries ones, so column 31 of dW1 is the bias gradient
+    const s16x4 ones4 = {0x3F80, 0x3F80, 0x3F80, 0x3F80};       // bf16 1.0
 
     const __bf16 *xg = (const __bf16 *)a.x + (size_t)g * a.sx_g;
     const __bf16 *og = (const __bf16 *)a.out + (size_t)g * a.so_g, *dg = (const __bf16 *)a.d_out + (size_t)g * a.so_g;
@@ -318,17 +337,24 @@ __global__ __launch_bounds__(NWB *LANES) void trunk_bwd_kernel(const cat_trunk_b
                     for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA(db, w2t[kk][mt], acc[mt]);
                 }
             }
+            // dW1[channel][kk * C + c] += sum over the 16 samples of (gradient before the first ReLU) x (input window of p):
+            // the accumulator holds samples 4 q .. 4 q + 3 of channel 16 mt + r -- exactly the A fragment of the K = 16
+            // MFMA (v_mfma_f32_16x16x16_bf16), so it goes from the accumulator into the product with no LDS image
+            s16x4 xw[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) xw[nt] = *(const s16x4 *)(xT + (2 * p * ge.C + 16 * nt + r) * TS + 4 * q);
+            if (r == 15) xw[1] = ones4;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const int at = (p * C1 + 16 * mt + r) * TS + 4 * q;
-                const bf16x4 y = *(const bf16x4 *)(a1T + at);
+                const bf16x4 y = *(const bf16x4 *)(a1T + (p * C1 + 16 * mt + r) * TS + 4 * q);
                 bf16x4 v = narrow(acc[mt]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ((float)y[e] > 0.0f) ? v[e] : (__bf16)0.0f;
-                *(bf16x4 *)(dp1T + at) = v;
+                const s16x4 va = __builtin_bit_cast(s16x4, v);
+                dw1[mt][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, xw[0], dw1[mt][0], 0, 0, 0);
+                dw1[mt][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, xw[1], dw1[mt][1], 0, 0, 0);
             }
         }
-        __syncthreads();
         for (int l0 = 0; l0 < L2; l0 += 2) {         // dW2[out][window column] += sum over (sample, position)
             const int lq = l0 + half;
             const bool ok = lq < L2;
@@ -340,14 +366,6 @@ __global__ __launch_bounds__(NWB *LANES) void trunk_bwd_kernel(const cat_trunk_b
             }
             if (ct2 == 0) db2 = MFMA(af, ones8, db2);
         }
-        for (int p0 = 0; p0 < L1; p0 += 2) {         // dW1[channel][kk * C + c]
-            const int pq = p0 + half;
-            const bool ok = pq < L1;
-            const bf16x8 af = ok ? *(const bf16x8 *)(dp1T + (pq * C1 + 16 * rt1 + r) * TS + sh) : zero8;
-            const bf16x8 bf = ok ? *(const bf16x8 *)(xT + (2 * pq * ge.C + 16 * nt1 + r) * TS + sh) : zero8;
-            dw1 = MFMA(af, bf, dw1);
-            if (nt1 == 0) db1 = MFMA(af, ones8, db1);
-        }
         __syncthreads();
     }
 
@@ -356,11 +374,24 @@ __global__ __launch_bounds__(NWB *LANES) void trunk_bwd_kernel(const cat_trunk_b
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) a.part_dw2[(slab * C2 + 16 * mt2 + 4 * q + e) * WIN2 + 16 * (ct2 + 4 * i) + r] = dw2[i][e];
-        a.part_dw1[(slab * C1 + 16 * rt1 + 4 * q + e) * 32 + 16 * nt1 + r] = dw1[e];
-        if (r == 0) {
-            if (nt1 == 0) a.part_db1[slab * C1 + 16 * rt1 + 4 * q + e] = db1[e];
-            if (ct2 == 0) a.part_db2[slab * C2 + 16 * mt2 + 4 * q + e] = db2[e];
+        if (r == 0 && ct2 == 0) a.part_db2[slab * C2 + 16 * mt2 + 4 * q + e] = db2[e];
+    }
+    // dW1: the eight waves' [64][32] accumulators are added up through LDS (free by now) into the workgroup's slab
+    float *red = (float *)smem;                                            // [8][64][32] fp32 = 64 KB
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(w * C1 + 16 * mt + 4 * q + e) * 32 + r] = dw1[mt][0][e];
+            red[(w * C1 + 16 * mt + 4 * q + e) * 32 + 16 + r] = dw1[mt][1][e];
         }
+    __syncthreads();
+    for (int j = threadIdx.x; j < C1 * 32; j += NWB * LANES) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NWB; ++k) sum += red[k * C1 * 32 + j];
+        a.part_dw1[slab * C1 * 32 + j] = sum;
+        if ((j & 31) == 31) a.part_db1[slab * C1 + (j >> 5)] = sum;          // column 31 = the bias gradient
     }
 }
 
@@ -424,7 +455,7 @@ int compute_units()
 
 bool dims_ok(const cat_trunk_dims &d)
 {
-    return d.G > 0 && d.G <= 65535 && d.N > 0 && (d.C == 2 || d.C == 4) && d.R >= 20 && d.R <= 512 && d.R % 4 == 0;
+    return d.G > 0 && d.G <= 65535 && d.N > 0 && (d.C == 2 || d.C == 4) && d.R >= 20 && d.R <= 512 && d.R % 2 == 0;
 }
 bool aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
 int tiles_of(const cat_trunk_dims &d) { return (d.N + TS - 1) / TS; }

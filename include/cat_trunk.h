@@ -26,6 +26,7 @@ extern "C" {
 #define CAT_TRUNK_C1 64          /* channels after the first convolution */
 #define CAT_TRUNK_C2 32          /* channels after the second */
 #define CAT_TRUNK_TILE 16        /* samples per workgroup pass */
+#define CAT_TRUNK_BWD_WAVES 8    /* waves of a backward workgroup */
 
 enum { CAT_TRUNK_OK = 0, CAT_TRUNK_ERR_BAD_ARG = -1, CAT_TRUNK_ERR_HIP = -2, CAT_TRUNK_ERR_TOO_LARGE = -3 };
 
@@ -33,12 +34,12 @@ typedef struct cat_trunk_dims {
     int32_t G;      /* stacked networks */
     int32_t N;      /* samples per network */
     int32_t C;      /* input channels: 2 or 4 */
-    int32_t R;      /* rays (input positions), R % 4 == 0 */
+    int32_t R;      /* rays (input positions), even */
 } cat_trunk_dims;
 
 /* L1 = (R - 5) / 2 + 1 positions after the first convolution, L2 = (L1 - 5) / 3 + 1 after the second. */
 int cat_trunk_out_positions(const cat_trunk_dims *d);
-/* 1 if the backward pass of these dimensions fits the 160 KB of LDS (R <= 64 for C = 4), else 0. */
+/* 1 if the backward pass of these dimensions fits the 160 KB of LDS (R <= 102 for C = 4), else 0. */
 int cat_trunk_supported(const cat_trunk_dims *d);
 /* Number of workgroups per network the backward launch uses = the leading extent of the partial-sum buffers. */
 int cat_trunk_backward_blocks(const cat_trunk_dims *d);
@@ -69,7 +70,7 @@ typedef struct cat_trunk_bwd {
     const void *d_out;  /* bf16, gradient w.r.t. out; same strides as out */
     int64_t so_g, so_n;
     /* fp32 partial sums, one slab per workgroup: the caller adds the B = cat_trunk_backward_blocks() slabs up */
-    float *part_dw1;    /* [G][B][64][32]: column kk * C + c  (columns >= 5 C are zero) */
+    float *part_dw1;    /* [G][B][64][32]: column kk * C + c  (columns >= 5 C are not weights) */
     float *part_db1;    /* [G][B][64] */
     float *part_dw2;    /* [G][B][32][320]: column kk * 64 + c_in */
     float *part_db2;    /* [G][B][32] */

@@ -73,7 +73,8 @@ def test_learner_kernels_reject_bad_arguments_before_touching_a_device():
     L = ln.lib()
     d = ln.TrunkDims(3, 1000, 4, 64)
     assert L.cat_trunk_out_positions(C.byref(d)) == 9 and L.cat_trunk_supported(C.byref(d)) == 1
-    assert L.cat_trunk_supported(C.byref(ln.TrunkDims(3, 1000, 4, 90))) == 0          # R = 90 does not fit the LDS (dense path)
+    assert L.cat_trunk_supported(C.byref(ln.TrunkDims(3, 1000, 4, 90))) == 1          # the reference's default sensor
+    assert L.cat_trunk_supported(C.byref(ln.TrunkDims(3, 1000, 4, 200))) == 0         # does not fit the LDS (dense path)
     assert L.cat_trunk_forward(C.byref(ln.TrunkFwd()), None) == -1 and b"dimensions" in L.cat_trunk_last_error()
     assert L.cat_ppo_loss_grad(C.byref(ln.PpoLoss()), None) == -1 and L.cat_ppo_adam_step(C.byref(ln.PpoAdam()), None) == -1
     assert L.cat_dense_bias_act(C.byref(ln.DenseDims(1, 1, 3, 0)), None, None, 0, None) == -1        # out = 3: neither 1 nor 4 k

@@ -168,15 +168,15 @@ def test_self_play_protocol_on_baseline_config_3(tmp_path):
         assert len(data) == 3 and all(v["games"] >= 1 and len(v["recent_outcomes"]) <= 20 for v in data.values())
 
 
-@pytest.mark.parametrize("rays", [32, 90])
+@pytest.mark.parametrize("rays", [32, 90, 128])
 def test_trainer_runs_with_other_ray_counts(rays):
-    """R = 32 goes through the fused convolutional trunk (14 and 4 positions); R = 90 (the reference's default sensor) does
-    not fit its LDS images and takes the dense-GEMM trunk: both train through the captured graphs with finite weights."""
+    """R = 32 and R = 90 (the reference's default sensor: 43 and 13 positions) go through the fused convolutional trunk; R = 128
+    does not fit its LDS images and takes the dense-GEMM trunk: all train through the captured graphs with finite weights."""
     import torch
     from as_cops_and_thieves_amd import VecCopsEnv, load_preset
     from as_cops_and_thieves_amd import _learn_native as ln
     from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, RoleConfig, TrainerConfig
-    assert ln.trunk_supported(3, 1024, 4, rays) == (rays == 32)
+    assert ln.trunk_supported(3, 1024, 4, rays) == (rays != 128)
     env = VecCopsEnv(load_preset("squarinth"), 128, num_rays=rays, max_step_count=60, seed=2)
     rc = RoleConfig(learning_epochs=1, mini_batches=2, random_timesteps=0, learning_starts=0)
     tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0), seed=1)
@@ -189,10 +189,12 @@ def test_trainer_runs_with_other_ray_counts(rays):
     env.close()
 
 
-def test_reference_default_ray_count_trains_at_full_batch_size(tmp_path):
-    """R = 90 (the reference's default sensor) at 4096 envs: the dense-GEMM trunk in row chunks (``stacked.DENSE_ROWS``).
-    As one [3 x 16384 x 2752] x [2752 x 416] product the BLAS library's kernel ran into a memory access fault on this stack;
-    the run is a child process so that such a fault fails this test and not the whole suite."""
+@pytest.mark.parametrize("dense", ["0", "1"])
+def test_reference_default_ray_count_trains_at_full_batch_size(tmp_path, dense):
+    """R = 90 (the reference's default sensor) at 4096 envs, through the fused trunk and (CAT_DENSE_TRUNK=1) through the
+    dense-GEMM trunk in row chunks (``stacked.DENSE_ROWS``): as one [3 x 16384 x 2752] x [2752 x 416] product the BLAS
+    library's kernel ran into a memory access fault on this stack; the run is a child process so that such a fault fails
+    this test and not the whole suite."""
     import subprocess, sys, textwrap
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
@@ -211,7 +213,9 @@ def test_reference_default_ray_count_trains_at_full_batch_size(tmp_path):
         assert torch.isfinite(rl.fp.master).all() and rl._graphs and float(rl.steps.max()) > 0
         print("R90_OK")
     """))
-    res = subprocess.run([sys.executable, str(child)], cwd=root, capture_output=True, text=True, timeout=600)
+    import os
+    res = subprocess.run([sys.executable, str(child)], cwd=root, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, CAT_DENSE_TRUNK=dense))
     assert res.returncode == 0 and "R90_OK" in res.stdout, (res.stdout[-500:], res.stderr[-2000:])
 
 

@@ -62,7 +62,8 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-12)), float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-12))
 
 
-@pytest.mark.parametrize("G,N,C,R", [(3, 1000, 2, 64), (3, 4099, 4, 64), (1, 16, 2, 64), (5, 300, 4, 32), (2, 20000, 2, 64)])
+@pytest.mark.parametrize("G,N,C,R", [(3, 1000, 2, 64), (3, 4099, 4, 64), (1, 16, 2, 64), (5, 300, 4, 32), (2, 20000, 2, 64),
+                                     (3, 2000, 4, 90), (2, 1500, 2, 90), (1, 100, 4, 102), (2, 333, 2, 22)])
 def test_forward_and_parameter_gradients_match_conv1d_in_fp32(G, N, C, R):
     import torch
     from as_cops_and_thieves_amd.selfplay.stacked import _ConvTrunk
