@@ -105,6 +105,7 @@ EXTRA_WORKLOADS = (   # the other BASELINE.json shapes, measured in the same run
     ("grandbyrinth 3v2 x8192 (configs[3])", dict(map="grandbyrinth", cops=3, thieves=2, envs=8192)),
     ("five maps mixed 2v1 x16384 (configs[4])", dict(map="mixed", cops=2, thieves=1, envs=16384)),
     ("labyrinth 2v1 x4096, every agent spawned inside the maze", dict(map="labyrinth-inside", cops=2, thieves=1, envs=4096)),
+    ("labyrinth 2v1 x4096 with the reference's own 90-ray sensor (entity.py:86)", dict(map="labyrinth", cops=2, thieves=1, envs=4096, rays=90)),
 )
 
 
@@ -268,7 +269,7 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_extras:   # the other BASELINE shapes, same process, same box
         extra = {}
         for label, w in EXTRA_WORKLOADS:
-            s2, c2, m2 = build_sim(w["map"], w["cops"], w["thieves"], w["envs"], args.rays, 0, dev)
+            s2, c2, m2 = build_sim(w["map"], w["cops"], w["thieves"], w["envs"], w.get("rays", args.rays), 0, dev)
             s2.reset()
             k_steps = 300                                   # own step counts: the driver's --steps 20 --warmup 5 would only
             e2, k2, _ = timed_steps(s2, k_steps, 100, fence, hip)   # see the first ticks after the reset
@@ -278,6 +279,7 @@ def main() -> None:
                             "roofline_frac": bytes2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
             s2.close()
         extra["learner_collect_plus_update"] = learner_throughput(args.map, cfg.n_envs, args.rays)
+        extra["learner_collect_plus_update, 90 rays"] = learner_throughput(args.map, cfg.n_envs, 90)
     if rank == 0:
         A, R = cfg.n_agents, cfg.n_rays
         bytes_launch = algorithmic_bytes_per_env_step(A, R) * cfg.n_envs
