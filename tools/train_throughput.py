@@ -32,3 +32,5 @@ graphs = {r: bool(rl._graphs) for r, rl in tr.roles.items()}
 print(f"{N} envs, horizon {tr.tcfg.horizon}, {name}: collect {steps / tc / 1e6:.2f} M env-steps/s ({1e3 * tc / K:.2f} ms), "
       f"update {steps / tu / 1e6:.2f} M env-steps/s ({1e3 * tu / K:.2f} ms), end to end {steps / (tc + tu) / 1e6:.2f} M env-steps/s; "
       f"update graphs {graphs}, stats {tr.read_stats()}")
+env.check_errors()                                       # device-side error flags of the env core (bad actions, dropped contacts)
+assert all(v == v and abs(v) < 1e6 for v in tr.read_stats().values()), "non-finite training statistics"
