@@ -63,7 +63,7 @@ class TrunkBwd(C.Structure):
 
 ROLLOUT_SYMBOLS = ("cat_rollout_abi_version", "cat_rollout_last_error", "cat_rollout_pack", "cat_rollout_sample", "cat_rollout_post")
 DENSE_SYMBOLS = ("cat_dense_abi_version", "cat_dense_last_error", "cat_dense_bias_act", "cat_dense_act_grad", "cat_dense_sum_chunks",
-                 "cat_dense_wgrad_splits", "cat_dense_wgrad")
+                 "cat_dense_wgrad_splits", "cat_dense_wgrad", "cat_dense_forward", "cat_dense_dgrad")
 PPO_SYMBOLS = ("cat_ppo_abi_version", "cat_ppo_last_error", "cat_ppo_loss_grad", "cat_ppo_adam_step")
 
 
@@ -162,6 +162,9 @@ def lib() -> C.CDLL:
         L.cat_dense_wgrad_splits.argtypes = [C.c_int32] * 4
         L.cat_dense_wgrad.restype = C.c_int
         L.cat_dense_wgrad.argtypes = [C.c_void_p, C.c_void_p]
+        for n in ("cat_dense_forward", "cat_dense_dgrad"):
+            getattr(L, n).restype = C.c_int
+            getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
         assert L.cat_dense_abi_version() == 1
         L.cat_rollout_abi_version.restype = C.c_int
         L.cat_rollout_last_error.restype = C.c_char_p
@@ -439,6 +442,43 @@ def dense_wgrad(g, x, slot=None):
         sum_chunks(partial, slot.view(G, M * N) if slot.is_contiguous() else slot.as_strided((G, M * N), (slot.stride(0), 1)), accumulate=True)
         return None
     return sum_chunks(partial).view(G, M, N)
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("G", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("x_or_gr", C.c_void_p), ("w", C.c_void_p),
+                ("sw_g", C.c_int64), ("bias", C.c_void_p), ("sb_g", C.c_int64), ("act", C.c_int32), ("pad", C.c_int32), ("out", C.c_void_p)]
+
+
+def gemm_supported(x, w) -> bool:
+    """The layer kernels take rows of 16-byte runs: in-features a multiple of 8, weight rows contiguous and aligned."""
+    return (x.shape[2] % 8 == 0 and w.stride(2) == 1 and w.stride(1) == w.shape[2] and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0)
+
+
+def dense_forward(x, w, bias, act: int):
+    """act(x [G, M, K] @ w [G, N, K]^T + bias [G, N]) -> bf16 [G, M, N]; bias may be None (act must then be ACT_NONE)."""
+    import torch
+    G, M, K = x.shape
+    N = w.shape[1]
+    x = x.contiguous()
+    assert x.dtype == w.dtype == torch.bfloat16 and w.shape == (G, N, K) and gemm_supported(x, w)
+    assert bias is None or (bias.shape == (G, N) and bias.dtype == torch.bfloat16 and bias.stride(1) == 1)
+    y = torch.empty(G, M, N, dtype=torch.bfloat16, device=x.device)
+    a = GemmArgs(G, M, N, K, x.data_ptr(), w.data_ptr(), w.stride(0), _ptr(bias), 0 if bias is None else bias.stride(0), act, 0, y.data_ptr())
+    _check(lib().cat_dense_forward(C.byref(a), _stream()), "cat_dense_forward")
+    return y
+
+
+def dense_dgrad(gr, w):
+    """gr [G, M, N] @ w [G, N, K] -> bf16 [G, M, K]: the gradient w.r.t. the layer's input."""
+    import torch
+    G, M, N = gr.shape
+    K = w.shape[2]
+    gr = gr.contiguous()
+    assert gr.dtype == w.dtype == torch.bfloat16 and w.shape == (G, N, K) and w.stride(2) == 1 and w.stride(1) == K and K % 8 == 0
+    dx = torch.empty(G, M, K, dtype=torch.bfloat16, device=gr.device)
+    a = GemmArgs(G, M, N, K, gr.data_ptr(), w.data_ptr(), w.stride(0), 0, 0, 0, 0, dx.data_ptr())
+    _check(lib().cat_dense_dgrad(C.byref(a), _stream()), "cat_dense_dgrad")
+    return dx
 
 
 _ONES = {}

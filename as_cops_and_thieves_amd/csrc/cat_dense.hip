@@ -232,6 +232,167 @@ __global__ __launch_bounds__(BLOCK) void wgrad_kernel(const cat_dense_wgrad_args
         }
 }
 
+// ---- forward product with the bias / activation epilogue, and the input gradient ------------------------------------------
+// Both: 128 x 128 output tile per workgroup, 4 waves of 64 x 64, 32-deep steps through double-buffered LDS, computed
+// transposed (the weights are the A operand) so that a lane's four accumulator registers are four consecutive output
+// columns of one row: 8-byte stores.  Forward reduces over k, which is the contiguous index of x AND of w: plain 16-byte
+// fragment reads (80-byte LDS rows: 16 lanes on 16 rows cover all banks).  The input gradient reduces over n, the ROW
+// index of w: its fragments come through the transposed LDS read as in wgrad_kernel, the gradient's through two 8-byte
+// reads that follow the same k permutation.
+constexpr int GM_LD = 40;         // LDS row of a [128][32] tile, in elements (80 B)
+
+__device__ __forceinline__ bf16x8 run8(const __bf16 *base, int width, int col, bool vec)
+{
+    const bf16x8 z8 = {};
+    if (vec) return col < width ? *(const bf16x8 *)(base + col) : z8;
+    bf16x8 v = z8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (col + j < width) v[j] = base[col + j];
+    return v;
+}
+
+__global__ __launch_bounds__(BLOCK) void dense_fwd_kernel(const cat_dense_gemm_args a)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 sx[2][WG_BM * GM_LD], sw[2][WG_BN * GM_LD];
+    const int tiles_n = (a.N + WG_BN - 1) / WG_BN;
+    const int m0 = (blockIdx.x / tiles_n) * WG_BM, n0 = (blockIdx.x % tiles_n) * WG_BN, g = blockIdx.z;
+    const __bf16 *X = (const __bf16 *)a.x_or_gr + (size_t)g * a.M * a.K, *W = (const __bf16 *)a.w + (size_t)g * a.sw_g;
+    const int lrow = threadIdx.x >> 2, lch = threadIdx.x & 3;          // thread: rows lrow, lrow + 64; 16-byte chunk lch of the 32 k
+    const bf16x8 z8 = {};
+    bf16x8 rx[2], rw[2];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0 + lrow + 64 * h, n = n0 + lrow + 64 * h, k = kb + 8 * lch;
+            rx[h] = (m < a.M && k < a.K) ? *(const bf16x8 *)(X + (size_t)m * a.K + k) : z8;
+            rw[h] = (n < a.N && k < a.K) ? *(const bf16x8 *)(W + (size_t)n * a.K + k) : z8;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *(bf16x8 *)&sx[buf][(lrow + 64 * h) * GM_LD + 8 * lch] = rx[h];
+            *(bf16x8 *)&sw[buf][(lrow + 64 * h) * GM_LD + 8 * lch] = rw[h];
+        }
+    };
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, r = l & 15, wn = w >> 1, wm = w & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = (a.K + WG_BK - 1) / WG_BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nk) gload(WG_BK * (it + 1));
+        bf16x8 wf[4], xf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            wf[t] = *(const bf16x8 *)&sw[buf][(wn * 64 + 16 * t + r) * GM_LD + 8 * q];
+            xf[t] = *(const bf16x8 *)&sx[buf][(wm * 64 + 16 * t + r) * GM_LD + 8 * q];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        if (it + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const __bf16 *bg = a.bias ? (const __bf16 *)a.bias + (size_t)g * a.sb_g : nullptr;
+    __bf16 *Y = (__bf16 *)a.out + (size_t)g * a.M * a.N;
+    const bool vec_n = a.N % 4 == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + 16 * i + 4 * q;
+        float b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = (bg && n + e < a.N) ? (float)bg[n + e] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + 16 * j + r;
+            if (m >= a.M || n >= a.N) continue;
+            f32x4 v = acc[i][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e] + b[e], a.act);
+            __bf16 *dst = Y + (size_t)m * a.N + n;
+            if (vec_n) *(bf16x4 *)dst = __builtin_convertvector(v, bf16x4);       // n + 3 < N follows from N % 4 == 0
+            else
+                for (int e = 0; e < 4 && n + e < a.N; ++e) dst[e] = (__bf16)v[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void dense_dgrad_kernel(const cat_dense_gemm_args a)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 sg[2][WG_BM * GM_LD], swt[2][WG_BK * WG_LD];
+    const int tiles_k = (a.K + 127) / 128;
+    const int m0 = (blockIdx.x / tiles_k) * WG_BM, k0 = (blockIdx.x % tiles_k) * 128, g = blockIdx.z;
+    const __bf16 *GR = (const __bf16 *)a.x_or_gr + (size_t)g * a.M * a.N, *W = (const __bf16 *)a.w + (size_t)g * a.sw_g;
+    const int lrow = threadIdx.x >> 2, lch = threadIdx.x & 3;          // gradient tile [128 m][32 n]
+    const int wrow = threadIdx.x >> 4, wch = threadIdx.x & 15;         // weight tile [32 n][128 k]: rows wrow, wrow + 16
+    const bool vec_g = a.N % 8 == 0;
+    const bf16x8 z8 = {};
+    bf16x8 rg[2], rw[2];
+    auto gload = [&](int nb) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0 + lrow + 64 * h;
+            rg[h] = m < a.M ? run8(GR + (size_t)m * a.N, a.N, nb + 8 * lch, vec_g) : z8;
+            const int n = nb + wrow + 16 * h, k = k0 + 8 * wch;
+            rw[h] = (n < a.N && k < a.K) ? *(const bf16x8 *)(W + (size_t)n * a.K + k) : z8;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *(bf16x8 *)&sg[buf][(lrow + 64 * h) * GM_LD + 8 * lch] = rg[h];
+            *(bf16x8 *)&swt[buf][(wrow + 16 * h) * WG_LD + 8 * wch] = rw[h];
+        }
+    };
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, r = l & 15, wk = w >> 1, wm = w & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nn = (a.N + WG_BK - 1) / WG_BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int it = 0; it < nn; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nn) gload(WG_BK * (it + 1));
+        bf16x8 wf[4], gf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            wf[t] = tr_frag(swt[buf], 4 * q, wk * 64 + 16 * t);                       // A[row = k-out][n in {4q.., 16+4q..}]
+            const __bf16 *row = &sg[buf][(wm * 64 + 16 * t + r) * GM_LD];
+            const bf16x4 lo = *(const bf16x4 *)(row + 4 * q), hi = *(const bf16x4 *)(row + 16 + 4 * q);
+            gf[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);          // B[the same n's][col = m]
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], gf[j], acc[i][j], 0, 0, 0);
+        if (it + 1 < nn) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    __bf16 *DX = (__bf16 *)a.out + (size_t)g * a.M * a.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + wk * 64 + 16 * i + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + 16 * j + r;
+            if (m < a.M && k < a.K) *(bf16x4 *)(DX + (size_t)m * a.K + k) = __builtin_convertvector(acc[i][j], bf16x4);   // K % 8 == 0
+        }
+    }
+}
+
 thread_local char g_err[256] = "";
 int fail(int code, const char *msg)
 {
@@ -306,6 +467,32 @@ extern "C" int cat_dense_wgrad(const cat_dense_wgrad_args *a, void *stream)
         return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_wgrad: NULL or misaligned buffer");
     const int tiles = ((a->M + WG_BM - 1) / WG_BM) * ((a->N + WG_BN - 1) / WG_BN);
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, a->splits, a->G), dim3(BLOCK), 0, (hipStream_t)stream, *a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_DENSE_OK : fail(CAT_DENSE_ERR_HIP, hipGetErrorString(e));
+}
+
+static int gemm_args_ok(const cat_dense_gemm_args *a)
+{
+    return a && a->G > 0 && a->G <= 65535 && a->M > 0 && a->N > 0 && a->K > 0 && a->K % 8 == 0 && a->x_or_gr && a->w && a->out &&
+           !((uintptr_t)a->w % 16) && !(a->sw_g % 8) && !((uintptr_t)a->out % 16);
+}
+
+extern "C" int cat_dense_forward(const cat_dense_gemm_args *a, void *stream)
+{
+    if (!gemm_args_ok(a) || ((uintptr_t)a->x_or_gr % 16) || a->act < CAT_ACT_NONE || a->act > CAT_ACT_TANH)
+        return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_forward: bad dimensions (K % 8), NULL or misaligned buffer");
+    const int tiles = ((a->M + WG_BM - 1) / WG_BM) * ((a->N + WG_BN - 1) / WG_BN);
+    hipLaunchKernelGGL(dense_fwd_kernel, dim3(tiles, 1, a->G), dim3(BLOCK), 0, (hipStream_t)stream, *a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_DENSE_OK : fail(CAT_DENSE_ERR_HIP, hipGetErrorString(e));
+}
+
+extern "C" int cat_dense_dgrad(const cat_dense_gemm_args *a, void *stream)
+{
+    if (!gemm_args_ok(a) || ((a->N % 8 == 0) && ((uintptr_t)a->x_or_gr % 16)))
+        return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_dgrad: bad dimensions (K % 8), NULL or misaligned buffer");
+    const int tiles = ((a->M + WG_BM - 1) / WG_BM) * ((a->K + 127) / 128);
+    hipLaunchKernelGGL(dense_dgrad_kernel, dim3(tiles, 1, a->G), dim3(BLOCK), 0, (hipStream_t)stream, *a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAT_DENSE_OK : fail(CAT_DENSE_ERR_HIP, hipGetErrorString(e));
 }

@@ -264,17 +264,26 @@ class _Lin(torch.autograd.Function):
         return dx, dw, db
 
 
+_OWN_GEMMS = os.environ.get("CAT_LIB_GEMM", "0") != "1"   # the layers' products through csrc/cat_dense.hip (else the BLAS library)
+
+
 class _LinAct(torch.autograd.Function):
-    """act(x @ w^T + b) for G stacked layers in bf16 on the GPU: the product is a library GEMM, the bias broadcast and
-    the activation one in-place pass over its result, the activation's derivative and the bias gradient (column sums)
-    one pass over the incoming gradient (``csrc/cat_dense.hip``).  act: 0 none, 1 ReLU, 2 tanh; b None = a bare product.
+    """act(x @ w^T + b) for G stacked layers in bf16 on the GPU (``csrc/cat_dense.hip``): product + bias + activation in
+    one MFMA kernel, the activation's derivative and the bias gradient (column sums) in one pass over the incoming
+    gradient, the input gradient and the weight gradient as MFMA kernels of their own (CAT_LIB_GEMM=1: the two
+    products that are not reductions over the rows through the BLAS library instead, with the bias / activation as an
+    in-place pass).  act: 0 none, 1 ReLU, 2 tanh; b None = a bare product.
     Gradients of FlatParams leaves are added straight into their slots of the flat gradient buffer (see _LSTMSeq)."""
 
     @staticmethod
     def forward(ctx, x, w, b, act):
-        y = torch.bmm(x, w.transpose(1, 2))
-        if b is not None:
-            _learn_native.dense_bias_act_(y, b, act)
+        ctx.own = _OWN_GEMMS and _learn_native.gemm_supported(x, w)
+        if ctx.own:   # product, bias and activation in one kernel (csrc/cat_dense.hip)
+            y = _learn_native.dense_forward(x, w, b, act)
+        else:
+            y = torch.bmm(x, w.transpose(1, 2))
+            if b is not None:
+                _learn_native.dense_bias_act_(y, b, act)
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.act, ctx.has_bias = act, b is not None
         ctx.slots = (_grad_slot(w), _grad_slot(b))
@@ -291,7 +300,9 @@ class _LinAct(torch.autograd.Function):
                 _learn_native.sum_chunks(part, b_slot, accumulate=True)
             else:
                 db = _learn_native.sum_chunks(part)
-        dx = torch.bmm(g, w) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _learn_native.dense_dgrad(g, w) if ctx.own else torch.bmm(g, w)
         return dx, _weight_grad(g, x, w_slot), db, None
 
 

@@ -57,6 +57,25 @@ typedef struct cat_dense_wgrad_args {
 int cat_dense_wgrad_splits(int32_t G, int32_t K, int32_t M, int32_t N);
 int cat_dense_wgrad(const cat_dense_wgrad_args *a, void *stream);
 
+/* The layer itself and its input gradient for the G stacked networks (bf16, fp32 accumulation), so that a training step's
+   products do not depend on a BLAS library's kernel selection:
+     forward : y[g][m][n] = act( sum_k x[g][m][k] w[g][n][k] + bias[g][n] )      x [G][M][K], w [G][N][K] (row stride K, network
+               stride sw_g), bias [G][N] (stride sb_g) or NULL, y [G][M][N]; K % 8 == 0
+     dgrad   : dx[g][m][k] = sum_n gr[g][m][n] w[g][n][k]                        gr [G][M][N], dx [G][M][K]; K % 8 == 0
+   Everything contiguous in its last dimension and 16-byte aligned (gr: when N % 8 == 0, else read element by element). */
+typedef struct cat_dense_gemm_args {
+    int32_t G, M, N, K;
+    const void *x_or_gr;        /* forward: x; dgrad: gr */
+    const void *w;
+    int64_t sw_g;
+    const void *bias;           /* forward only */
+    int64_t sb_g;
+    int32_t act, pad;           /* forward only: CAT_ACT_* */
+    void *out;                  /* forward: y; dgrad: dx */
+} cat_dense_gemm_args;
+int cat_dense_forward(const cat_dense_gemm_args *a, void *stream);
+int cat_dense_dgrad(const cat_dense_gemm_args *a, void *stream);
+
 int cat_dense_abi_version(void);
 const char *cat_dense_last_error(void);
 

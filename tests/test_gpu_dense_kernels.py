@@ -52,3 +52,28 @@ def test_weight_gradient_kernel_matches_a_gemm_in_fp32(G, K, M, N):
     assert ln.dense_wgrad(g, x, slot) is None
     torch.cuda.synchronize()
     assert float((slot.float() - (1 + want)).abs().max()) <= 2 ** -6 * scale and bool((flat[:, :8] == 1).all())
+
+
+@pytest.mark.parametrize("G,M,N,K,act", [(3, 16384, 256, 288, 2), (3, 16384, 512, 256, 0), (3, 4096, 128, 128, 1), (2, 1000, 4, 64, 0),
+                                          (3, 777, 1, 64, 0), (1, 130, 136, 72, 1), (3, 16384, 256, 416, 2), (5, 300, 64, 128, 1)])
+def test_layer_forward_and_input_gradient_kernels_match_fp32_gemms(G, M, N, K, act):
+    """cat_dense_forward / cat_dense_dgrad against torch in fp32 on the same bf16 operands (w as a row-strided view of a
+    flat buffer, ragged tiles, the 4- and 1-wide heads).  Stored as bf16: 2^-7 relative to the largest value."""
+    import torch
+    from as_cops_and_thieves_amd import _learn_native as ln
+    gen = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(G, M, K, generator=gen, device="cuda").to(torch.bfloat16)
+    flat = (torch.randn(G, N * K + 40, generator=gen, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    w = flat[:, 16:16 + N * K].view(G, N, K)
+    b = torch.randn(G, N, generator=gen, device="cuda").to(torch.bfloat16)
+    f = {0: lambda t: t, 1: torch.relu, 2: torch.tanh}[act]
+    want = f(torch.bmm(x.float(), w.float().transpose(1, 2)) + b.float().unsqueeze(1))
+    got = ln.dense_forward(x, w, b, act)
+    assert got.shape == (G, M, N) and float((got.float() - want).abs().max()) <= 2 ** -7 * max(1.0, float(want.abs().max()))
+    bare = ln.dense_forward(x, w, None, 0)
+    assert float((bare.float() - torch.bmm(x.float(), w.float().transpose(1, 2))).abs().max()) <= 2 ** -7 * 8
+    gr = torch.randn(G, M, N, generator=gen, device="cuda").to(torch.bfloat16)
+    dx_want = torch.bmm(gr.float(), w.float())
+    dx = ln.dense_dgrad(gr, w)
+    torch.cuda.synchronize()
+    assert dx.shape == (G, M, K) and float((dx.float() - dx_want).abs().max()) <= 2 ** -7 * max(1.0, float(dx_want.abs().max()))
