@@ -63,7 +63,7 @@ class TrunkBwd(C.Structure):
 
 ROLLOUT_SYMBOLS = ("cat_rollout_abi_version", "cat_rollout_last_error", "cat_rollout_pack", "cat_rollout_sample", "cat_rollout_post")
 DENSE_SYMBOLS = ("cat_dense_abi_version", "cat_dense_last_error", "cat_dense_bias_act", "cat_dense_act_grad", "cat_dense_sum_chunks",
-                 "cat_dense_wgrad_splits", "cat_dense_wgrad", "cat_dense_forward", "cat_dense_dgrad")
+                 "cat_dense_wgrad_splits", "cat_dense_wgrad", "cat_dense_forward", "cat_dense_dgrad", "cat_dense_sum_chunks2")
 PPO_SYMBOLS = ("cat_ppo_abi_version", "cat_ppo_last_error", "cat_ppo_loss_grad", "cat_ppo_adam_step")
 
 
@@ -162,6 +162,8 @@ def lib() -> C.CDLL:
         L.cat_dense_wgrad_splits.argtypes = [C.c_int32] * 4
         L.cat_dense_wgrad.restype = C.c_int
         L.cat_dense_wgrad.argtypes = [C.c_void_p, C.c_void_p]
+        L.cat_dense_sum_chunks2.restype = C.c_int
+        L.cat_dense_sum_chunks2.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         for n in ("cat_dense_forward", "cat_dense_dgrad"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
@@ -425,9 +427,22 @@ def wgrad_supported(g, x) -> bool:
     return g.shape[1] >= 512
 
 
-def dense_wgrad(g, x, slot=None):
+class SumJob(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("chunks", C.c_int32), ("n", C.c_int32), ("dst0", C.c_void_p), ("sd0_g", C.c_int64),
+                ("dst1", C.c_void_p), ("sd1_g", C.c_int64), ("accumulate", C.c_int32), ("pad", C.c_int32)]
+
+
+def _sum_job(partial, dst, accumulate: bool) -> SumJob:
+    G, chunks = partial.shape[:2]
+    n = partial[0, 0].numel()
+    assert partial.is_contiguous() and dst.shape[0] == G and dst[0].numel() == n and dst[0].is_contiguous()
+    return SumJob(partial.data_ptr(), chunks, n, dst.data_ptr(), dst.stride(0), 0, 0, 1 if accumulate else 0, 0)
+
+
+def dense_wgrad(g, x, slot=None, bias_job=None):
     """g bf16 [G, K, M] (gradient of a layer's pre-activations), x bf16 [G, K, N] (its input) -> sum_k g[k, m] x[k, n] as
-    bf16 [G, M, N]: ADDED into ``slot`` (a [G, M, N] view whose [M, N] blocks are contiguous) when given, else returned."""
+    bf16 [G, M, N]: ADDED into ``slot`` (a [G, M, N] view whose [M, N] blocks are contiguous) when given, else returned.
+    ``bias_job`` = (partial fp32 [G, chunks, M], bias slot [G, M]): that chunk sum rides in the same launch."""
     import torch
     G, K, M = g.shape
     N = x.shape[2]
@@ -437,11 +452,17 @@ def dense_wgrad(g, x, slot=None):
     partial = torch.empty(G, S, M * N, dtype=torch.float32, device=g.device)
     a = WgradArgs(G, K, M, N, g.data_ptr(), x.data_ptr(), partial.data_ptr(), S, 0)
     _check(lib().cat_dense_wgrad(C.byref(a), _stream()), "cat_dense_wgrad")
+    out = None
     if slot is not None:
         assert slot.shape == (G, M, N) and slot[0].is_contiguous()
-        sum_chunks(partial, slot.view(G, M * N) if slot.is_contiguous() else slot.as_strided((G, M * N), (slot.stride(0), 1)), accumulate=True)
-        return None
-    return sum_chunks(partial).view(G, M, N)
+        dst = slot.view(G, M * N) if slot.is_contiguous() else slot.as_strided((G, M * N), (slot.stride(0), 1))
+    else:
+        out = torch.empty(G, M * N, dtype=torch.bfloat16, device=g.device)
+        dst = out
+    ja = _sum_job(partial, dst, slot is not None)
+    jb = None if bias_job is None else _sum_job(bias_job[0], bias_job[1], True)
+    _check(lib().cat_dense_sum_chunks2(C.byref(ja), None if jb is None else C.byref(jb), G, _stream()), "cat_dense_sum_chunks2")
+    return None if slot is not None else out.view(G, M, N)
 
 
 class GemmArgs(C.Structure):

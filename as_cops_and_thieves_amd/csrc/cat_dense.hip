@@ -106,28 +106,38 @@ __global__ __launch_bounds__(BLOCK) void act_grad_kernel(cat_dense_dims d, const
 }
 
 // block = 32 columns x 8 chunk lanes: a column's chunks are read by eight threads in parallel (32 loads each at 256
-// chunks) and added up through LDS
-__global__ __launch_bounds__(BLOCK) void sum_chunks_kernel(const float *partial, int chunks, int n, __bf16 *dst0, int64_t sd0, __bf16 *dst1,
-                                                           int64_t sd1, int accumulate)
+// chunks) and added up through LDS.  One launch serves up to two independent jobs (a layer's weight and bias gradients).
+struct SumJob {
+    const float *partial;
+    int chunks, n;
+    __bf16 *dst0, *dst1;
+    long long sd0, sd1;
+    int accumulate, blocks;
+};
+
+__global__ __launch_bounds__(BLOCK) void sum_chunks_kernel(SumJob j0, SumJob j1)
 {
     __shared__ float lds[BLOCK];
-    const int g = blockIdx.y, cl = threadIdx.x & 31, lane = threadIdx.x >> 5, j = blockIdx.x * 32 + cl;
+    const bool second = (int)blockIdx.x >= j0.blocks;
+    const SumJob &jb = second ? j1 : j0;
+    const int bx = second ? (int)blockIdx.x - j0.blocks : (int)blockIdx.x;
+    const int g = blockIdx.y, cl = threadIdx.x & 31, lane = threadIdx.x >> 5, j = bx * 32 + cl;
     float s = 0.0f;
-    if (j < n) {
-        const float *p = partial + (size_t)g * chunks * n + j;
-        for (int c = lane; c < chunks; c += 8) s += p[(size_t)c * n];
+    if (j < jb.n) {
+        const float *p = jb.partial + (size_t)g * jb.chunks * jb.n + j;
+        for (int c = lane; c < jb.chunks; c += 8) s += p[(size_t)c * jb.n];
     }
     lds[threadIdx.x] = s;
     __syncthreads();
-    if (lane == 0 && j < n) {
+    if (lane == 0 && j < jb.n) {
 #pragma unroll
         for (int k = 1; k < 8; ++k) s += lds[32 * k + cl];
-        if (accumulate) {
-            dst0[(size_t)g * sd0 + j] = (__bf16)(s + (float)dst0[(size_t)g * sd0 + j]);
-            if (dst1) dst1[(size_t)g * sd1 + j] = (__bf16)(s + (float)dst1[(size_t)g * sd1 + j]);
+        if (jb.accumulate) {
+            jb.dst0[(size_t)g * jb.sd0 + j] = (__bf16)(s + (float)jb.dst0[(size_t)g * jb.sd0 + j]);
+            if (jb.dst1) jb.dst1[(size_t)g * jb.sd1 + j] = (__bf16)(s + (float)jb.dst1[(size_t)g * jb.sd1 + j]);
         } else {
-            dst0[(size_t)g * sd0 + j] = (__bf16)s;
-            if (dst1) dst1[(size_t)g * sd1 + j] = (__bf16)s;
+            jb.dst0[(size_t)g * jb.sd0 + j] = (__bf16)s;
+            if (jb.dst1) jb.dst1[(size_t)g * jb.sd1 + j] = (__bf16)s;
         }
     }
 }
@@ -440,10 +450,20 @@ extern "C" int cat_dense_act_grad(const cat_dense_dims *d, const void *d_y, cons
 extern "C" int cat_dense_sum_chunks(const float *partial, int32_t G, int32_t chunks, int32_t n, void *dst0, int64_t sd0_g, void *dst1,
                                     int64_t sd1_g, int32_t accumulate, void *stream)
 {
-    if (!partial || !dst0 || G <= 0 || G > 65535 || chunks <= 0 || n <= 0)
+    cat_dense_sum_job j = {partial, chunks, n, dst0, sd0_g, dst1, sd1_g, accumulate, 0};
+    return cat_dense_sum_chunks2(&j, nullptr, G, stream);
+}
+
+extern "C" int cat_dense_sum_chunks2(const cat_dense_sum_job *a, const cat_dense_sum_job *b, int32_t G, void *stream)
+{
+    if (!a || !a->partial || !a->dst0 || G <= 0 || G > 65535 || a->chunks <= 0 || a->n <= 0 ||
+        (b && (!b->partial || !b->dst0 || b->chunks <= 0 || b->n <= 0)))
         return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_sum_chunks: bad dimensions or NULL buffer");
-    hipLaunchKernelGGL(sum_chunks_kernel, dim3((n + 31) / 32, G), dim3(BLOCK), 0, (hipStream_t)stream, partial, chunks, n,
-                       (__bf16 *)dst0, sd0_g, (__bf16 *)dst1, sd1_g, accumulate);
+    SumJob j0 = {a->partial, a->chunks, a->n, (__bf16 *)a->dst0, (__bf16 *)a->dst1, a->sd0_g, a->sd1_g, a->accumulate, (a->n + 31) / 32};
+    SumJob j1 = j0;
+    j1.blocks = 0;
+    if (b) j1 = SumJob{b->partial, b->chunks, b->n, (__bf16 *)b->dst0, (__bf16 *)b->dst1, b->sd0_g, b->sd1_g, b->accumulate, (b->n + 31) / 32};
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3(j0.blocks + (b ? j1.blocks : 0), G), dim3(BLOCK), 0, (hipStream_t)stream, j0, j1);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAT_DENSE_OK : fail(CAT_DENSE_ERR_HIP, hipGetErrorString(e));
 }

@@ -70,12 +70,13 @@ def _grad_slot(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return p.grad
 
 
-def _weight_grad(g: torch.Tensor, x: torch.Tensor, slot: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+def _weight_grad(g: torch.Tensor, x: torch.Tensor, slot: Optional[torch.Tensor], bias_job=None) -> Optional[torch.Tensor]:
     """sum over the rows of g[:, k, :]^T x[:, k, :] for the G stacked layers (bf16 on the GPU): added into ``slot`` (returns
     None) or returned.  The reduction runs over tens of thousands of rows into a small matrix: ``csrc/cat_dense.hip``'s
     split-K kernel where its tiling applies, the library GEMM otherwise (tiny heads)."""
     if _learn_native.wgrad_supported(g, x):
-        return _learn_native.dense_wgrad(g, x, slot)
+        return _learn_native.dense_wgrad(g, x, slot, bias_job)
+    assert bias_job is None
     if slot is not None:
         slot.baddbmm_(g.transpose(1, 2), x)
         return None
@@ -293,17 +294,19 @@ class _LinAct(torch.autograd.Function):
     def backward(ctx, go):
         x, w, y = ctx.saved_tensors
         w_slot, b_slot = ctx.slots
-        g, db = go.contiguous(), None
+        g, db, bias_job = go.contiguous(), None, None
         if ctx.has_bias:
             g, part = _learn_native.dense_act_grad(g, y, ctx.act)
-            if b_slot is not None:
+            if b_slot is not None and w_slot is not None and _learn_native.wgrad_supported(g, x):
+                bias_job = (part, b_slot)                      # its chunk sum rides in the weight gradient's launch
+            elif b_slot is not None:
                 _learn_native.sum_chunks(part, b_slot, accumulate=True)
             else:
                 db = _learn_native.sum_chunks(part)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _learn_native.dense_dgrad(g, w) if ctx.own else torch.bmm(g, w)
-        return dx, _weight_grad(g, x, w_slot), db, None
+        return dx, _weight_grad(g, x, w_slot, bias_job), db, None
 
 
 def _lin_act(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int) -> torch.Tensor:

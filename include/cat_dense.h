@@ -43,6 +43,17 @@ int cat_dense_act_grad(const cat_dense_dims *d, const void *d_y, const void *y, 
    and of the other per-workgroup partial sums of this library.  dst1 may be NULL; accumulate != 0 adds to what dst holds. */
 int cat_dense_sum_chunks(const float *partial, int32_t G, int32_t chunks, int32_t n, void *dst0, int64_t sd0_g, void *dst1,
                          int64_t sd1_g, int32_t accumulate, void *stream);
+/* the same for two independent buffers in ONE launch (a layer's weight and bias gradients); b may be NULL */
+typedef struct cat_dense_sum_job {
+    const float *partial;
+    int32_t chunks, n;
+    void *dst0;
+    int64_t sd0_g;
+    void *dst1;
+    int64_t sd1_g;
+    int32_t accumulate, pad;
+} cat_dense_sum_job;
+int cat_dense_sum_chunks2(const cat_dense_sum_job *a, const cat_dense_sum_job *b, int32_t G, void *stream);
 
 /* The weight gradient of a dense layer: partial[g][s][m][n] = sum over the rows k of split s of a[g][k][m] * b[g][k][n]
    (a = the gradient w.r.t. the layer's pre-activations [G][K][M], b = the layer's input [G][K][N], both bf16 contiguous;

@@ -53,7 +53,7 @@ def test_lstm_library_exports_every_declared_symbol_and_struct_layouts_match():
                                                     "cat_trunk_bwd": "TrunkBwd", "cat_trunk_finish_args": "TrunkFinish"}),
     ("cat_ppo.h", "cat_ppo_", "PPO_SYMBOLS", {"cat_ppo_loss": "PpoLoss", "cat_ppo_adam": "PpoAdam"}),
     ("cat_rollout.h", "cat_rollout_", "ROLLOUT_SYMBOLS", {"cat_rollout_pack_args": "PackArgs", "cat_rollout_sample_args": "SampleArgs", "cat_rollout_post_args": "PostArgs"}),
-    ("cat_dense.h", "cat_dense_", "DENSE_SYMBOLS", {"cat_dense_dims": "DenseDims", "cat_dense_wgrad_args": "WgradArgs", "cat_dense_gemm_args": "GemmArgs"})])
+    ("cat_dense.h", "cat_dense_", "DENSE_SYMBOLS", {"cat_dense_dims": "DenseDims", "cat_dense_wgrad_args": "WgradArgs", "cat_dense_gemm_args": "GemmArgs", "cat_dense_sum_job": "SumJob"})])
 def test_learner_kernel_headers_match_the_library_and_the_ctypes_mirror(header, prefix, symbols, structs):
     from as_cops_and_thieves_amd import _learn_native as ln
     ln.build()
