@@ -27,7 +27,7 @@ class Dims(C.Structure):
 
 class FwdArgs(C.Structure):
     _fields_ = [("d", Dims), ("xproj", C.c_void_p), ("sx_g", C.c_int64), ("sx_t", C.c_int64), ("sx_b", C.c_int64),
-                ("bias", C.c_void_p), ("sb_g", C.c_int64), ("w_hh", C.c_void_p), ("sw_g", C.c_int64), ("h0", C.c_void_p), ("c0", C.c_void_p), ("keep", C.c_void_p),
+                ("bias", C.c_void_p), ("sb_g", C.c_int64), ("bias2", C.c_void_p), ("sb2_g", C.c_int64), ("w_hh", C.c_void_p), ("sw_g", C.c_int64), ("h0", C.c_void_p), ("c0", C.c_void_p), ("keep", C.c_void_p),
                 ("out", C.c_void_p), ("so_g", C.c_int64), ("so_t", C.c_int64), ("so_b", C.c_int64),
                 ("h_last", C.c_void_p), ("c_last", C.c_void_p), ("h_in", C.c_void_p), ("saved_acts", C.c_void_p),
                 ("saved_cell", C.c_void_p)]
@@ -200,7 +200,7 @@ def saved_sizes(G: int, T: int, B: int):
     return lib().cat_lstm_saved_acts_bytes(C.byref(d)), lib().cat_lstm_saved_cell_bytes(C.byref(d))
 
 
-def seq_forward(xproj, w_hh, bias, h0, c0, keep, save: bool, state_out=None):
+def seq_forward(xproj, w_hh, bias, h0, c0, keep, save: bool, state_out=None, bias2=None):
     """xproj bf16 [G, T, B, 4H] (any outer strides), w_hh bf16 [G, 4H, H] (rows contiguous), bias bf16 [G, 4H] or None,
     h0/c0 bf16 [G, B, H], keep fp32 [T, B] or None.  Returns out [G, T, B, H], h_T, c_T and, with ``save``, (h_in, acts, cell) for backward."""
     import torch
@@ -224,10 +224,11 @@ def seq_forward(xproj, w_hh, bias, h0, c0, keep, save: bool, state_out=None):
         h_in = torch.empty(G, T, B, HIDDEN, dtype=torch.bfloat16, device=dev)
         acts = torch.empty(na, dtype=torch.uint8, device=dev)
         cell = torch.empty(nc, dtype=torch.uint8, device=dev)
-    if bias is not None:
-        assert bias.shape == (G, H4) and bias.dtype == torch.bfloat16 and bias.stride(1) == 1
+    for bv in (bias, bias2):
+        assert bv is None or (bv.shape == (G, H4) and bv.dtype == torch.bfloat16 and bv.stride(1) == 1)
+    assert bias2 is None or bias is not None
     a = FwdArgs(Dims(G, T, B, 0), xproj.data_ptr(), xproj.stride(0), xproj.stride(1), xproj.stride(2),
-                _ptr(bias), 0 if bias is None else bias.stride(0), w_hh.data_ptr(), w_hh.stride(0), h0.data_ptr(), c0.data_ptr(), _ptr(keep),
+                _ptr(bias), 0 if bias is None else bias.stride(0), _ptr(bias2), 0 if bias2 is None else bias2.stride(0), w_hh.data_ptr(), w_hh.stride(0), h0.data_ptr(), c0.data_ptr(), _ptr(keep),
                 out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), hT.data_ptr(), cT.data_ptr(),
                 _ptr(h_in), _ptr(acts), _ptr(cell))
     _check(lib().cat_lstm_seq_forward(C.byref(a), _stream()), "cat_lstm_seq_forward")

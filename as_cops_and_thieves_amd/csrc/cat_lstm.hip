@@ -76,7 +76,12 @@ __global__ __launch_bounds__(NW *LANES, SAVE ? 1 : 2) void lstm_seq_fwd_kernel(c
     for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
-            bias[gt][hh] = a.bias ? *(const bf16x4 *)((const __bf16 *)a.bias + (size_t)g * a.sb_g + gt * H + hid0 + 16 * hh) : zero4();
+        {
+            f32x4 bsum = a.bias ? widen(*(const bf16x4 *)((const __bf16 *)a.bias + (size_t)g * a.sb_g + gt * H + hid0 + 16 * hh))
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias2) bsum += widen(*(const bf16x4 *)((const __bf16 *)a.bias2 + (size_t)g * a.sb2_g + gt * H + hid0 + 16 * hh));
+            bias[gt][hh] = narrow(bsum);           // one rounding of the sum, as the bf16 addition of the two vectors gives
+        }
     // a workgroup takes the 16-sequence blocks blk, blk + gridDim.x, ...: one each in training (the grid covers them), several
     // when there are more blocks than the device holds at once (a rollout tick of thousands of envs) -- W_hh is loaded once
     for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -338,7 +343,7 @@ extern "C" int cat_lstm_seq_forward(const cat_lstm_fwd *a, void *stream)
     if (!aligned(a->w_hh, 16) || (a->sw_g % 8) || !aligned(a->xproj, 8) || (a->sx_g % 4) || (a->sx_t % 4) || (a->sx_b % 4) ||
         !aligned(a->out, 8) || (a->so_g % 4) || (a->so_t % 4) || (a->so_b % 4) || !aligned(a->h0, 8) || !aligned(a->c0, 8) ||
         !aligned(a->h_last, 8) || !aligned(a->c_last, 8) || !aligned(a->h_in, 8) || !aligned(a->saved_acts, 8) || !aligned(a->saved_cell, 8) ||
-        !aligned(a->bias, 8) || (a->bias && (a->sb_g % 4)))
+        !aligned(a->bias, 8) || (a->bias && (a->sb_g % 4)) || !aligned(a->bias2, 8) || (a->bias2 && (a->sb2_g % 4)) || (a->bias2 && !a->bias))
         return fail(CAT_LSTM_ERR_BAD_ARG, "cat_lstm_seq_forward: misaligned buffer or stride");
     // more blocks than one resident round of the device (one workgroup per CU at this register count): fold them
     const int nb = blocks_of(a->d);

@@ -104,9 +104,9 @@ class _LSTMSeq(torch.autograd.Function):
         ctx.set_materialize_grads(False)           # unused final-state gradients arrive as None, not as zero tensors
         ctx.native = xproj.is_cuda and xproj.dtype == torch.bfloat16
         if ctx.native:
-            bias = b_ih if (b_ih is None or b_hh is None) else b_ih + b_hh
-            out, hT, cT, (h_in, acts, cell) = _learn_native.seq_forward(xproj, w_hh, bias, h0, c0, keep, save=train, state_out=state_out)
-            ctx.has_bias = bias is not None
+            out, hT, cT, (h_in, acts, cell) = _learn_native.seq_forward(xproj, w_hh, b_ih, h0, c0, keep, save=train, state_out=state_out,
+                                                                        bias2=b_hh if b_ih is not None else None)
+            ctx.has_bias = b_ih is not None
             ctx.slots = (_grad_slot(w_hh), _grad_slot(b_ih), _grad_slot(b_hh))
             if train:
                 ctx.save_for_backward(w_hh, h_in, acts, cell, keep if keep is not None else torch.empty(0))

@@ -50,8 +50,10 @@ typedef struct cat_lstm_fwd {
     cat_lstm_dims d;
     const void *xproj;          /* bf16 [G][T][B][4H]: x_t W_ih^T (+ b_ih + b_hh when bias is NULL) */
     int64_t sx_g, sx_t, sx_b;
-    const void *bias;           /* bf16 [G][4H] = b_ih + b_hh, added to every step's pre-activations; or NULL */
+    const void *bias;           /* bf16 [G][4H], added to every step's pre-activations (b_ih, or b_ih + b_hh); or NULL */
     int64_t sb_g;
+    const void *bias2;          /* a second such vector (b_hh), or NULL: the kernel adds the two */
+    int64_t sb2_g;
     const void *w_hh;           /* bf16 [G][4H][H] */
     int64_t sw_g;
     const void *h0, *c0;        /* bf16 [G][B][H], contiguous */

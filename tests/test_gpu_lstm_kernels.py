@@ -124,3 +124,18 @@ def test_one_launch_per_direction_inside_a_hip_graph():
     torch.cuda.synchronize()
     for a, b in zip(got, eager):
         assert torch.equal(a, b)
+
+
+def test_two_bias_vectors_are_added_by_the_kernel():
+    """b_ih and b_hh handed over separately (as StackedNet does) = their bf16 sum handed over as one vector."""
+    import torch
+    from as_cops_and_thieves_amd import _learn_native
+    xproj, w_hh, h0, c0, keep = _case(3, 5, 70, True, seed=21)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    b1 = (0.3 * torch.randn(3, 4 * H, generator=gen, device="cuda")).to(torch.bfloat16)
+    b2 = (0.3 * torch.randn(3, 4 * H, generator=gen, device="cuda")).to(torch.bfloat16)
+    for save in (False, True):
+        two = _learn_native.seq_forward(xproj, w_hh, b1, h0, c0, keep, save=save, bias2=b2)
+        one = _learn_native.seq_forward(xproj, w_hh, b1 + b2, h0, c0, keep, save=save)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(two[:3], one[:3]))
