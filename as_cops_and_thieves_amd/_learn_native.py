@@ -11,6 +11,8 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 LIB_PATH = PKG / "libcat_learn.so"
+if os.environ.get("CAT_LEARN_LIB"):         # diagnostic builds (A/B of kernel variants): another build of the same sources
+    LIB_PATH = Path(os.environ["CAT_LEARN_LIB"]).resolve()
 SOURCES = tuple(PKG / "csrc" / f"cat_{n}.hip" for n in ("lstm", "trunk", "ppo", "dense", "rollout"))
 HEADERS = tuple(ROOT / "include" / f"cat_{n}.h" for n in ("lstm", "trunk", "ppo", "dense", "rollout"))
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared"]

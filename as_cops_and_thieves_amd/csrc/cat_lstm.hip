@@ -4,9 +4,11 @@
 // masks forward, the gate gradient + a batched GEMM + masks backward -- about forty ~5 us launches per step and
 // layer.  Here the window of one layer is ONE launch per direction:
 //
-//   * a workgroup = 16 sequences of one network, 4 waves; wave w owns hidden units [32w, 32w+32) with all four gates;
+//   * a workgroup = 16 sequences of one network, 8 waves; wave w owns hidden units [16w, 16w+16) with all four gates
+//     (the recurrence is a chain of T dependent steps with 16 sequences as the matrix cores' N: what shortens a step is more
+//     waves sharing its gate arithmetic -- two per SIMD, whose matrix-core and transcendental work overlap);
 //   * the products are computed TRANSPOSED on v_mfma_f32_16x16x32_bf16: gates^T [4H x 16] = W_hh [4H x H] * h^T, so the
-//     A operand is rows of W_hh (register resident for the whole window: 32 fragments = 128 VGPRs per lane), the lanes
+//     A operand is rows of W_hh (register resident for the whole window: 16 fragments = 64 VGPRs per lane), the lanes
 //     of an accumulator are sequences, and the four registers of a lane are four CONSECUTIVE hidden units: every
 //     global access of the recurrence is an 8-byte (4 x bf16) access, the cell arithmetic happens in the accumulator
 //     registers in fp32, and the cell state c never leaves the registers during the window;
@@ -24,7 +26,12 @@
 
 namespace {
 
-constexpr int H = CAT_LSTM_HIDDEN, H4 = 4 * H, BM = CAT_LSTM_ROWS_PER_BLOCK, NW = 4, LANES = 64;
+#ifndef CAT_LSTM_WAVES
+#define CAT_LSTM_WAVES 8
+#endif
+constexpr int H = CAT_LSTM_HIDDEN, H4 = 4 * H, BM = CAT_LSTM_ROWS_PER_BLOCK, NW = CAT_LSTM_WAVES, LANES = 64;
+constexpr int HH = H / (16 * NW);                    // 16-unit groups of hidden units per wave (8 waves: 1, 4 waves: 2)
+static_assert(HH * 16 * NW == H && HH >= 1, "the waves of a workgroup split the hidden units in groups of 16");
 constexpr int HPAD = H + 8, GPAD = H4 + 8;          // LDS row strides (bf16): 272 B / 1040 B -> 16 rows hit 64 distinct banks
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -41,41 +48,41 @@ __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __bui
 // index (in bf16 elements) of a lane's 4-vector inside the saved buffers
 __device__ __forceinline__ size_t acts_index(int t, int g, int G, int nblk, int blk, int w, int tile, int lane)
 {
-    return ((((size_t)(t * G + g) * nblk + blk) * NW + w) * 8 + tile) * (LANES * 4) + lane * 4;
+    return ((((size_t)(t * G + g) * nblk + blk) * NW + w) * (4 * HH) + tile) * (LANES * 4) + lane * 4;
 }
 __device__ __forceinline__ size_t cell_index(int t, int g, int G, int nblk, int blk, int w, int which, int hh, int lane)
 {
-    return (((((size_t)(t * G + g) * nblk + blk) * NW + w) * 2 + which) * 2 + hh) * (LANES * 4) + lane * 4;
+    return (((((size_t)(t * G + g) * nblk + blk) * NW + w) * 2 + which) * HH + hh) * (LANES * 4) + lane * 4;
 }
 
-// SAVE = training (keeps what backward needs; one workgroup per CU at its register count); !SAVE = inference (rollout
-// ticks: thousands of sequences, nothing kept): compiled to fit two workgroups per CU, which hide each other's latencies
+// SAVE = training (keeps what backward needs); !SAVE = inference (rollout ticks: thousands of sequences, nothing kept).
+// Either way one 8-wave workgroup per CU is resident (152 - 176 VGPRs)
 template <bool SAVE>
 __global__ __launch_bounds__(NW *LANES, SAVE ? 1 : 2) void lstm_seq_fwd_kernel(const cat_lstm_fwd a)
 {
     __shared__ __attribute__((aligned(16))) __bf16 hbuf[2][BM][HPAD];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, q = l >> 4, r = l & 15;
     const int g = blockIdx.y, G = a.d.G, T = a.d.T, B = a.d.B, nblk = (B + BM - 1) / BM;
-    const int hid0 = 32 * w + 4 * q;                       // + 16 * hh: this lane's four hidden units of half hh
+    const int hid0 = 16 * HH * w + 4 * q;                       // + 16 * hh: this lane's four hidden units of half hh
 
     // W_hh fragments: A[row = gate column n0 + r][k = 32 ks + 8 q + j]
-    bf16x8 wf[4][2][4];
+    bf16x8 wf[4][HH][4];
     {
         const __bf16 *wg = (const __bf16 *)a.w_hh + (size_t)g * a.sw_g;
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
-                    wf[gt][hh][ks] = *(const bf16x8 *)(wg + (size_t)(gt * H + 32 * w + 16 * hh + r) * H + 32 * ks + 8 * q);
+                    wf[gt][hh][ks] = *(const bf16x8 *)(wg + (size_t)(gt * H + 16 * HH * w + 16 * hh + r) * H + 32 * ks + 8 * q);
     }
     constexpr bool save = SAVE;
-    bf16x4 bias[4][2];                                     // kept packed: registers are what limits this kernel to two per CU
+    bf16x4 bias[4][HH];                                     // kept packed: registers are what limits this kernel to two per CU
 #pragma unroll
     for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
+        for (int hh = 0; hh < HH; ++hh)
         {
             f32x4 bsum = a.bias ? widen(*(const bf16x4 *)((const __bf16 *)a.bias + (size_t)g * a.sb_g + gt * H + hid0 + 16 * hh))
                                 : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -90,11 +97,11 @@ __global__ __launch_bounds__(NW *LANES, SAVE ? 1 : 2) void lstm_seq_fwd_kernel(c
     const __bf16 *xg = (const __bf16 *)a.xproj + (size_t)g * a.sx_g + (size_t)b * a.sx_b;
     __bf16 *og = (__bf16 *)a.out + (size_t)g * a.so_g + (size_t)b * a.so_b;
     const size_t state_row = ((size_t)g * B + b) * H;
-    f32x4 c[2];
+    f32x4 c[HH];
     {
         const float k0 = (a.keep && row_ok) ? a.keep[b] : 1.0f;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < HH; ++hh) {
             const int hid = hid0 + 16 * hh;
             f32x4 h = widen(row_ok ? *(const bf16x4 *)((const __bf16 *)a.h0 + state_row + hid) : zero4()) * k0;
             c[hh] = widen(row_ok ? *(const bf16x4 *)((const __bf16 *)a.c0 + state_row + hid) : zero4()) * k0;
@@ -107,24 +114,24 @@ __global__ __launch_bounds__(NW *LANES, SAVE ? 1 : 2) void lstm_seq_fwd_kernel(c
 
     // the input-side pre-activations and the keep flag of step t + 1 are fetched while step t computes: the recurrence
     // is a chain of T dependent steps, and a global-memory round trip at the head of each would be most of its length
-    bf16x4 xn[4][2];
+    bf16x4 xn[4][HH];
     float kn_next = 1.0f;
     auto fetch = [&](int t) {
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+            for (int hh = 0; hh < HH; ++hh)
                 xn[gt][hh] = (row_ok && t < T) ? *(const bf16x4 *)(xg + (size_t)t * a.sx_t + gt * H + hid0 + 16 * hh) : zero4();
         kn_next = (a.keep && row_ok && t + 1 < T) ? a.keep[(size_t)(t + 1) * B + b] : 1.0f;
     };
     fetch(0);
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
-        f32x4 acc[4][2];
+        f32x4 acc[4][HH];
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) acc[gt][hh] = widen(xn[gt][hh]) + widen(bias[gt][hh]);
+            for (int hh = 0; hh < HH; ++hh) acc[gt][hh] = widen(xn[gt][hh]) + widen(bias[gt][hh]);
         const float kn = kn_next;
         fetch(t + 1);
 #pragma unroll
@@ -133,11 +140,11 @@ __global__ __launch_bounds__(NW *LANES, SAVE ? 1 : 2) void lstm_seq_fwd_kernel(c
 #pragma unroll
             for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
+                for (int hh = 0; hh < HH; ++hh)
                     acc[gt][hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[gt][hh][ks], hb, acc[gt][hh], 0, 0, 0);
         }
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < HH; ++hh) {
             const int hid = hid0 + 16 * hh;
             f32x4 gi, gf, gg, go, cy, tc, hy;
 #pragma unroll
@@ -152,10 +159,10 @@ __global__ __launch_bounds__(NW *LANES, SAVE ? 1 : 2) void lstm_seq_fwd_kernel(c
             }
             if (save) {
                 __bf16 *sa = (__bf16 *)a.saved_acts, *sc = (__bf16 *)a.saved_cell;
-                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 0 + hh, l)) = narrow(gi);
-                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 2 + hh, l)) = narrow(gf);
-                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 4 + hh, l)) = narrow(gg);
-                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 6 + hh, l)) = narrow(go);
+                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 0 * HH + hh, l)) = narrow(gi);
+                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 1 * HH + hh, l)) = narrow(gf);
+                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 2 * HH + hh, l)) = narrow(gg);
+                *(bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 3 * HH + hh, l)) = narrow(go);
                 *(bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 0, hh, l)) = narrow(c[hh]);
                 *(bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 1, hh, l)) = narrow(tc);
             }
@@ -182,46 +189,48 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_
     const int g = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x, G = a.d.G, T = a.d.T, B = a.d.B;
     const int b = blk * BM + r;
     const bool row_ok = b < B;
-    const int hid0 = 32 * w + 4 * q;
+    const int hid0 = 16 * HH * w + 4 * q;
 
     // W_hh^T fragments: A[row = hidden m0 + r][k = gate column 32 ks + 8 q + j] = W_hh[k][m0 + r]
-    bf16x8 wt[2][16];
+    bf16x8 wt[HH][16];
     {
         const __bf16 *wg = (const __bf16 *)a.w_hh + (size_t)g * a.sw_g;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
+        for (int hh = 0; hh < HH; ++hh)
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    wt[hh][ks][j] = wg[(size_t)(32 * ks + 8 * q + j) * H + 32 * w + 16 * hh + r];
+                    wt[hh][ks][j] = wg[(size_t)(32 * ks + 8 * q + j) * H + 16 * HH * w + 16 * hh + r];
     }
     const __bf16 *og = a.d_out ? (const __bf16 *)a.d_out + (size_t)g * a.so_g + (size_t)b * a.so_b : nullptr;
     __bf16 *xg = (__bf16 *)a.d_xproj + (size_t)g * a.sx_g + (size_t)b * a.sx_b;
     const size_t state_row = ((size_t)g * B + b) * H;
     const __bf16 *sa = (const __bf16 *)a.saved_acts, *sc = (const __bf16 *)a.saved_cell;
 
-    f32x4 dbs[4][2];                                  // sums over the steps of this lane's gate gradients (bias gradient)
+    f32x4 dbs[4][HH];                                  // sums over the steps of this lane's gate gradients (bias gradient)
 #pragma unroll
-    for (int gt = 0; gt < 4; ++gt) dbs[gt][0] = dbs[gt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 dh[2], dc[2];
+    for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < HH; ++hh) dbs[gt][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dh[HH], dc[HH];
+#pragma unroll
+    for (int hh = 0; hh < HH; ++hh) {
         const int hid = hid0 + 16 * hh;
         dh[hh] = widen((a.d_h_last && row_ok) ? *(const bf16x4 *)((const __bf16 *)a.d_h_last + state_row + hid) : zero4());
         dc[hh] = widen((a.d_c_last && row_ok) ? *(const bf16x4 *)((const __bf16 *)a.d_c_last + state_row + hid) : zero4());
     }
 
     // what step t - 1 reads from global memory is fetched while step t computes (see the forward kernel)
-    bf16x4 pd[2], pa[4][2], pc[2][2];
+    bf16x4 pd[HH], pa[4][HH], pc[2][HH];
     float kt_next = 1.0f;
     auto fetch = [&](int t) {
         const bool in = t >= 0;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < HH; ++hh) {
             pd[hh] = (in && og && row_ok) ? *(const bf16x4 *)(og + (size_t)t * a.so_t + hid0 + 16 * hh) : zero4();
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) pa[gt][hh] = in ? *(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, 2 * gt + hh, l)) : zero4();
+            for (int gt = 0; gt < 4; ++gt) pa[gt][hh] = in ? *(const bf16x4 *)(sa + acts_index(t, g, G, nblk, blk, w, gt * HH + hh, l)) : zero4();
             pc[0][hh] = in ? *(const bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 0, hh, l)) : zero4();
             pc[1][hh] = in ? *(const bf16x4 *)(sc + cell_index(t, g, G, nblk, blk, w, 1, hh, l)) : zero4();
         }
@@ -231,16 +240,16 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_
     for (int t = T - 1; t >= 0; --t) {
         const int buf = t & 1;
         const float kt = kt_next;
-        f32x4 d2[2], gi2[2], gf2[2], gg2[2], go2[2], cin2[2], tc2[2];
+        f32x4 d2[HH], gi2[HH], gf2[HH], gg2[HH], go2[HH], cin2[HH], tc2[HH];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < HH; ++hh) {
             d2[hh] = dh[hh] + widen(pd[hh]);
             gi2[hh] = widen(pa[0][hh]); gf2[hh] = widen(pa[1][hh]); gg2[hh] = widen(pa[2][hh]); go2[hh] = widen(pa[3][hh]);
             cin2[hh] = widen(pc[0][hh]); tc2[hh] = widen(pc[1][hh]);
         }
         fetch(t - 1);
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < HH; ++hh) {
             const int hid = hid0 + 16 * hh;
             const f32x4 d = d2[hh], gi = gi2[hh], gf = gf2[hh], gg = gg2[hh], go = go2[hh], cin = cin2[hh], tc = tc2[hh];
             f32x4 di, df, dg, d_o;
@@ -269,16 +278,18 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_
         }
         __syncthreads();
         if (t > 0 || a.d_h0) {
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            f32x4 acc[HH];
+#pragma unroll
+            for (int hh = 0; hh < HH; ++hh) acc[hh] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const bf16x8 db = *(const bf16x8 *)&dgbuf[buf][r][32 * ks + 8 * q];
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
+                for (int hh = 0; hh < HH; ++hh)
                     acc[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[hh][ks], db, acc[hh], 0, 0, 0);
             }
-            dh[0] = acc[0] * kt;
-            dh[1] = acc[1] * kt;
+#pragma unroll
+            for (int hh = 0; hh < HH; ++hh) dh[hh] = acc[hh] * kt;
         }
     }
     if (a.part_dbias) {   // add the 16 rows (lanes r) up; lane r == 0 of every group of 16 writes four columns
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < HH; ++hh) {
                 f32x4 v = dbs[gt][hh];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(NW *LANES) void lstm_seq_bwd_kernel(const cat_lstm_
     }
     if (row_ok) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+        for (int hh = 0; hh < HH; ++hh) {
             const int hid = hid0 + 16 * hh;
             if (a.d_h0) *(bf16x4 *)((__bf16 *)a.d_h0 + state_row + hid) = narrow(dh[hh]);
             if (a.d_c0) *(bf16x4 *)((__bf16 *)a.d_c0 + state_row + hid) = narrow(dc[hh]);
@@ -326,11 +337,11 @@ extern "C" int cat_lstm_blocks(const cat_lstm_dims *d) { return d && dims_ok(*d)
 
 extern "C" size_t cat_lstm_saved_acts_bytes(const cat_lstm_dims *d)
 {
-    return d && dims_ok(*d) ? (size_t)d->T * d->G * blocks_of(*d) * NW * 8 * LANES * 4 * 2 : 0;
+    return d && dims_ok(*d) ? (size_t)d->T * d->G * blocks_of(*d) * NW * 4 * HH * LANES * 4 * 2 : 0;
 }
 extern "C" size_t cat_lstm_saved_cell_bytes(const cat_lstm_dims *d)
 {
-    return d && dims_ok(*d) ? (size_t)d->T * d->G * blocks_of(*d) * NW * 4 * LANES * 4 * 2 : 0;
+    return d && dims_ok(*d) ? (size_t)d->T * d->G * blocks_of(*d) * NW * 2 * HH * LANES * 4 * 2 : 0;
 }
 
 extern "C" int cat_lstm_seq_forward(const cat_lstm_fwd *a, void *stream)
@@ -352,7 +363,7 @@ extern "C" int cat_lstm_seq_forward(const cat_lstm_fwd *a, void *stream)
         const int rounds = (nb * a->d.G + 255) / 256;
         hipLaunchKernelGGL(lstm_seq_fwd_kernel<true>, dim3((nb + rounds - 1) / rounds, a->d.G), dim3(NW * LANES), 0, (hipStream_t)stream, *a);
     } else {
-        const int rounds = (nb * a->d.G + 511) / 512;      // two workgroups per CU are resident
+        const int rounds = (nb * a->d.G + 255) / 256;
         hipLaunchKernelGGL(lstm_seq_fwd_kernel<false>, dim3((nb + rounds - 1) / rounds, a->d.G), dim3(NW * LANES), 0, (hipStream_t)stream, *a);
     }
     const hipError_t e = hipGetLastError();
