@@ -148,7 +148,7 @@ def timed_steps(sim, steps: int, warmup: int, fence, hip: "HipEvents", first_tic
     return elapsed, sum(hip.elapsed_ms(a, b) for a, b in ev.values()) / len(ev), len(ev)
 
 
-def learner_throughput(map_name: str, n_envs: int, rays: int) -> dict:
+def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16) -> dict:
     """SURVEY 8(f) rank 2 beside the headline: env-steps/s of the MAPPO trainer on the same env workload -- rollout
     collection (env tick + the six stacked LSTM networks per tick) plus the PPO update of ``CFG_AGENT`` (4 epochs x 4
     minibatches), both as replayed HIP graphs over libcat_learn.so.  3 untimed rollout+update rounds (the graphs are
@@ -159,7 +159,7 @@ def learner_throughput(map_name: str, n_envs: int, rays: int) -> dict:
         from as_cops_and_thieves_amd import VecCopsEnv, load_preset
         from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, TrainerConfig
         env = VecCopsEnv(load_preset(map_name), num_envs=n_envs, num_rays=rays, max_step_count=400)
-        tr = MAPPOTrainer(env, None, TrainerConfig(), seed=0)
+        tr = MAPPOTrainer(env, None, TrainerConfig(horizon=horizon), seed=0)
         for _ in range(3):
             tr.collect(); tr.update()
         torch.cuda.synchronize()
@@ -280,6 +280,9 @@ def main() -> None:
             s2.close()
         extra["learner_collect_plus_update"] = learner_throughput(args.map, cfg.n_envs, args.rays)
         extra["learner_collect_plus_update, 90 rays"] = learner_throughput(args.map, cfg.n_envs, 90)
+        # 128-tick rollouts (8 BPTT windows per env and update): the setting with which the cops learn to catch random
+        # thieves (tests/test_gpu_mappo.py::test_cops_learn_to_catch_random_thieves_on_squarinth; self_play's default)
+        extra["learner_collect_plus_update, 128-tick rollouts"] = learner_throughput(args.map, cfg.n_envs, args.rays, horizon=128)
     if rank == 0:
         A, R = cfg.n_agents, cfg.n_rays
         bytes_launch = algorithmic_bytes_per_env_step(A, R) * cfg.n_envs
