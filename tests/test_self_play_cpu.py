@@ -48,6 +48,23 @@ def test_self_play_iterations_archives_checkpoints_and_resume(tmp_path):
     assert [h["iteration"] for h in res["iterations"]] == [3] and (tmp_path / "joint_iter_3_full_agent.pt").exists()
 
 
+def test_default_trainer_configuration_uses_128_tick_rollouts(tmp_path):
+    """Without a trainer_cfg the loop builds its own: the role-training length of TrainingConfig and 128-tick rollouts (8
+    BPTT windows of 16 per env and update -- the rollout length with which the learner learns the game)."""
+    seen = {}
+
+    def factory(n, s):
+        env = OracleVecEnv(CMAP, n, num_rays=16, max_step_count=12, seed=s)
+        seen.setdefault("envs", []).append(env)
+        return env
+    rc = RoleConfig(learning_epochs=1, mini_batches=2, random_timesteps=0, learning_starts=0, kl_threshold=0.0)
+    res = run_self_play("squarinth", 2, tmp_path, iterations=1, env_factory=factory, log=lambda *a: None, role_cfg={"cop": rc, "thief": rc},
+                        training=TrainingConfig(training_timesteps_per_role_training=128, n_trial_episodes=1, num_opponents_to_evaluate=1))
+    assert [h["iteration"] for h in res["iterations"]] == [0]
+    sd = torch.load(tmp_path / "joint_iter_0_full_agent.pt", weights_only=False)
+    assert float(sd["optimizers"]["cop_0"]["steps"].max()) == 2.0      # ONE update of 1 epoch x 2 minibatches after 128 ticks
+
+
 def test_evaluation_books_one_outcome_for_each_of_five_distinct_opponents(tmp_path):
     env, ev = FACTORY(8, 1), FACTORY(6, 2)
     learned = MAPPOTrainer(env, {"cop": RC, "thief": RC}, TC, seed=0)
