@@ -52,13 +52,17 @@ class TrunkParams(C.Structure):
                 ("sw1_g", C.c_int64), ("sb1_g", C.c_int64), ("sw2_g", C.c_int64), ("sb2_g", C.c_int64)]
 
 
+class TrunkRows(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("sel", C.c_int32), ("block", C.c_int32)]
+
+
 class TrunkFwd(C.Structure):
-    _fields_ = [("d", TrunkDims), ("p", TrunkParams), ("x", C.c_void_p), ("sx_g", C.c_int64), ("sx_n", C.c_int64),
+    _fields_ = [("d", TrunkDims), ("p", TrunkParams), ("x", C.c_void_p), ("sx_g", C.c_int64), ("sx_n", C.c_int64), ("x_rows", TrunkRows),
                 ("out", C.c_void_p), ("so_g", C.c_int64), ("so_n", C.c_int64)]
 
 
 class TrunkBwd(C.Structure):
-    _fields_ = [("d", TrunkDims), ("p", TrunkParams), ("x", C.c_void_p), ("sx_g", C.c_int64), ("sx_n", C.c_int64),
+    _fields_ = [("d", TrunkDims), ("p", TrunkParams), ("x", C.c_void_p), ("sx_g", C.c_int64), ("sx_n", C.c_int64), ("x_rows", TrunkRows),
                 ("out", C.c_void_p), ("d_out", C.c_void_p), ("so_g", C.c_int64), ("so_n", C.c_int64),
                 ("part_dw1", C.c_void_p), ("part_db1", C.c_void_p), ("part_dw2", C.c_void_p), ("part_db2", C.c_void_p)]
 
@@ -144,7 +148,7 @@ def lib() -> C.CDLL:
         for n in ("cat_trunk_forward", "cat_trunk_backward", "cat_trunk_grad_finish"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
-        assert L.cat_trunk_abi_version() == 1
+        assert L.cat_trunk_abi_version() == 2
         L.cat_ppo_abi_version.restype = C.c_int
         L.cat_ppo_last_error.restype = C.c_char_p
         for n in ("cat_ppo_loss_grad", "cat_ppo_adam_step"):
@@ -278,26 +282,42 @@ def _trunk_params(w1, b1, w2, b2, G: int, C_in: int) -> TrunkParams:
     return TrunkParams(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w1.stride(0), b1.stride(0), w2.stride(0), b2.stride(0))
 
 
-def trunk_forward(x, w1, b1, w2, b2, R: int):
-    """x bf16 [G, N, C * R] in (channel, ray) order -> bf16 [G, N, L2 * 32] in (position, channel) order."""
+def _trunk_rows(x, rows, block: int):
+    """(samples N, cat_trunk_rows) of an input [G, rows of x, C * R]: all of them, or -- ``rows`` int64 [sel] on the device,
+    ``block`` -- the minibatch of ``sel`` sequences out of ``block`` per step, read in place (include/cat_trunk.h)."""
     import torch
-    G, N, CR = x.shape
+    if rows is None:
+        return x.shape[1], TrunkRows(None, 0, 0)
+    assert rows.dtype == torch.int64 and rows.is_contiguous() and rows.device == x.device and rows.dim() == 1
+    sel = rows.shape[0]
+    assert 0 < sel <= block and x.shape[1] % block == 0
+    return (x.shape[1] // block) * sel, TrunkRows(rows.data_ptr(), sel, block)
+
+
+def trunk_forward(x, w1, b1, w2, b2, R: int, rows=None, block: int = 0):
+    """x bf16 [G, N, C * R] in (channel, ray) order -> bf16 [G, N, L2 * 32] in (position, channel) order.  With ``rows``: x is
+    the whole [G, steps * block, C * R] buffer and N = steps * len(rows) (``_trunk_rows``)."""
+    import torch
+    G, _, CR = x.shape
     C_in = CR // R
     assert x.dtype == torch.bfloat16 and x.stride(2) == 1 and C_in * R == CR
+    N, xr = _trunk_rows(x, rows, block)
     d = TrunkDims(G, N, C_in, R)
     L2 = lib().cat_trunk_out_positions(C.byref(d))
     out = torch.empty(G, N, L2 * 32, dtype=torch.bfloat16, device=x.device)
-    a = TrunkFwd(d, _trunk_params(w1, b1, w2, b2, G, C_in), x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(), out.stride(0), out.stride(1))
+    a = TrunkFwd(d, _trunk_params(w1, b1, w2, b2, G, C_in), x.data_ptr(), x.stride(0), x.stride(1), xr, out.data_ptr(), out.stride(0), out.stride(1))
     _check(lib().cat_trunk_forward(C.byref(a), _stream()), "cat_trunk_forward")
     return out
 
 
-def trunk_backward(x, w1, b1, w2, b2, out, d_out, R: int):
+def trunk_backward(x, w1, b1, w2, b2, out, d_out, R: int, rows=None, block: int = 0):
     """fp32 per-workgroup partial sums [G, B, 64, 32], [G, B, 64], [G, B, 32, 320], [G, B, 32] of the parameter gradients
-    (columns kk * C + c and kk * 64 + c_in): the caller adds the B slabs up."""
+    (columns kk * C + c and kk * 64 + c_in): the caller adds the B slabs up.  ``rows``, ``block``: as in ``trunk_forward``."""
     import torch
-    G, N, CR = x.shape
+    G, _, CR = x.shape
     C_in = CR // R
+    N, xr = _trunk_rows(x, rows, block)
+    assert out.shape[1] == N
     d = TrunkDims(G, N, C_in, R)
     d_out = d_out.contiguous()
     assert out.is_contiguous() and d_out.shape == out.shape and d_out.dtype == torch.bfloat16
@@ -307,7 +327,7 @@ def trunk_backward(x, w1, b1, w2, b2, out, d_out, R: int):
     pb1 = torch.empty(G, nb, 64, dtype=torch.float32, device=dev)
     pw2 = torch.empty(G, nb, 32, 320, dtype=torch.float32, device=dev)
     pb2 = torch.empty(G, nb, 32, dtype=torch.float32, device=dev)
-    a = TrunkBwd(d, _trunk_params(w1, b1, w2, b2, G, C_in), x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(), d_out.data_ptr(),
+    a = TrunkBwd(d, _trunk_params(w1, b1, w2, b2, G, C_in), x.data_ptr(), x.stride(0), x.stride(1), xr, out.data_ptr(), d_out.data_ptr(),
                  out.stride(0), out.stride(1), pw1.data_ptr(), pb1.data_ptr(), pw2.data_ptr(), pb2.data_ptr())
     _check(lib().cat_trunk_backward(C.byref(a), _stream()), "cat_trunk_backward")
     return pw1, pb1, pw2, pb2

@@ -99,11 +99,20 @@ __device__ __forceinline__ bf16x4 load_rays(const __bf16 *chan, int ray0, int R)
 // input tile -> LDS in (ray, channel) order (and optionally [column][sample]).  Thread (sample s = t / 16, u = t % 16)
 // takes runs of 4 rays: one 8-byte load per channel, interleaved in registers, written as one run of 4 C elements.
 // Rows past N read as zero; the row tails (columns >= C R) are zeroed once per launch by clear_tails.
-__device__ __forceinline__ void stage_x(const __bf16 *xg, int64_t sx_n, int n0, int N, const Geo &ge, __bf16 *xs, __bf16 *xT)
+// the row of x that sample n reads (cat_trunk_rows): a minibatch picked out of the rollout buffer, step-major
+__device__ __forceinline__ size_t source_row(const cat_trunk_rows &m, int n)
+{
+    if (!m.rows) return (size_t)n;
+    const int t = n / m.sel;
+    return (size_t)t * m.block + (size_t)m.rows[n - t * m.sel];
+}
+
+__device__ __forceinline__ void stage_x(const __bf16 *xg, int64_t sx_n, const cat_trunk_rows &xr, int n0, int N, const Geo &ge, __bf16 *xs,
+                                        __bf16 *xT)
 {
     const int s = threadIdx.x >> 4, u = threadIdx.x & 15;
     const bool ok = n0 + s < N;
-    const __bf16 *row = xg + (size_t)(n0 + s) * sx_n;
+    const __bf16 *row = xg + (ok ? source_row(xr, n0 + s) : 0) * sx_n;
     const bf16x4 z4 = narrow(f32x4{0.f, 0.f, 0.f, 0.f});
     for (int ch = u; 4 * ch < ge.R; ch += 16) {
         bf16x4 v[4];
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(NW *LANES) void trunk_fwd_kernel(const cat_trunk_fw
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n0 = tile * TS;
-        stage_x(xg, a.sx_n, n0, N, ge, xs, nullptr);
+        stage_x(xg, a.sx_n, a.x_rows, n0, N, ge, xs, nullptr);
         __syncthreads();
         for (int p = w; p < ge.L1; p += NW) {
             const bf16x8 xb = ld8(xs + r * ge.XS + 2 * p * ge.C + 8 * q);
@@ -204,13 +213,13 @@ struct Raw {            // one tile's global data in flight: fetched a tile ahea
     bf16x4 y[4], d[4];  // runs 4 (u + 32 i) .. of the layer's output and of its gradient
 };
 
-__device__ __forceinline__ void fetch_raw(Raw &rw, const __bf16 *xg, int64_t sx_n, const __bf16 *og, const __bf16 *dg, int64_t so_n,
-                                          int n0, int N, const Geo &ge)
+__device__ __forceinline__ void fetch_raw(Raw &rw, const __bf16 *xg, int64_t sx_n, const cat_trunk_rows &xr, const __bf16 *og,
+                                          const __bf16 *dg, int64_t so_n, int n0, int N, const Geo &ge)
 {
     const int s = threadIdx.x >> 5, u = threadIdx.x & 31;
     const bool ok = n0 + s < N;
     const bf16x4 z4 = narrow(f32x4{0.f, 0.f, 0.f, 0.f});
-    const __bf16 *row = xg + (size_t)(n0 + s) * sx_n;
+    const __bf16 *row = xg + (ok ? source_row(xr, n0 + s) : 0) * sx_n;
 #pragma unroll
     for (int c = 0; c < 4; ++c) rw.x[c] = (ok && c < ge.C && 4 * u < ge.R) ? load_rays(row + c * ge.R, 4 * u, ge.R) : z4;
     const size_t o = (size_t)(n0 + s) * so_n;
@@ -313,11 +322,11 @@ __global__ __launch_bounds__(NWB *LANES) void trunk_bwd_kernel(const cat_trunk_b
         xT[j * TS + s] = (__bf16)0.0f;
     }
     Raw raw;
-    fetch_raw(raw, xg, a.sx_n, og, dg, a.so_n, blockIdx.x * TS, N, ge);
+    fetch_raw(raw, xg, a.sx_n, a.x_rows, og, dg, a.so_n, blockIdx.x * TS, N, ge);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         commit_raw(raw, ge, xs, xT, dp2, dp2T);
-        fetch_raw(raw, xg, a.sx_n, og, dg, a.so_n, (tile + (int)gridDim.x) * TS, N, ge);      // past the end: zeros, unused
+        fetch_raw(raw, xg, a.sx_n, a.x_rows, og, dg, a.so_n, (tile + (int)gridDim.x) * TS, N, ge);      // past the end: zeros, unused
         __syncthreads();
         for (int p = w; p < L1; p += NWB) {          // the intermediate again: D[sample 4 q + e][channel 16 mt + r]
             const bf16x8 xb = ld8(xs + r * ge.XS + 2 * p * ge.C + 8 * q);
@@ -458,6 +467,7 @@ bool dims_ok(const cat_trunk_dims &d)
     return d.G > 0 && d.G <= 65535 && d.N > 0 && (d.C == 2 || d.C == 4) && d.R >= 20 && d.R <= 512 && d.R % 2 == 0;
 }
 bool aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
+bool rows_ok(const cat_trunk_rows &r, int N) { return !r.rows || (r.sel > 0 && r.block >= r.sel && N % r.sel == 0); }
 int tiles_of(const cat_trunk_dims &d) { return (d.N + TS - 1) / TS; }
 int bwd_blocks(const cat_trunk_dims &d)
 {
@@ -494,6 +504,7 @@ extern "C" int cat_trunk_forward(const cat_trunk_fwd *a, void *stream)
     if (!params_ok(a->p) || !a->x || !a->out) return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_forward: a required buffer is NULL or misaligned");
     if (!aligned(a->x, 8) || (a->sx_g % 4) || (a->sx_n % 4) || !aligned(a->out, 8) || (a->so_g % 4) || (a->so_n % 4))
         return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_forward: misaligned buffer or stride");
+    if (!rows_ok(a->x_rows, a->d.N)) return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_forward: x_rows needs 0 < sel <= block and N a multiple of sel");
     const Geo ge(a->d);
     const int lds = (int)ge.fwd_lds();
     static int lds_set = 0;
@@ -516,6 +527,7 @@ extern "C" int cat_trunk_backward(const cat_trunk_bwd *a, void *stream)
     if (!aligned(a->x, 8) || (a->sx_g % 4) || (a->sx_n % 4) || !aligned(a->out, 8) || !aligned(a->d_out, 8) || (a->so_g % 4) ||
         (a->so_n % 4) || !aligned(a->part_dw1, 4) || !aligned(a->part_dw2, 4))
         return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_backward: misaligned buffer or stride");
+    if (!rows_ok(a->x_rows, a->d.N)) return fail(CAT_TRUNK_ERR_BAD_ARG, "cat_trunk_backward: x_rows needs 0 < sel <= block and N a multiple of sel");
     const Geo ge(a->d);
     const int lds = (int)ge.bwd_lds();
     static int lds_set = 0;

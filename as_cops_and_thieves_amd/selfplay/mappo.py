@@ -232,8 +232,9 @@ class RoleLearner:
         sel = lambda x: x.index_select(2, idx)
         keep = (~self.start.index_select(1, idx)).to(torch.float32)                    # [T, B]
         st = lambda s: s.index_select(2, idx)
-        logits, _ = self.policy.forward(sel(b["pin"]), (st(self.p0[0]), st(self.p0[1])), keep)
-        values, _ = self.value.forward(sel(b["vin"]), (st(self.v0[0]), st(self.v0[1])), keep)
+        # the observations of the minibatch are read out of the rollout buffers in place (the fused trunk kernels take the index)
+        logits, _ = self.policy.forward(b["pin"], (st(self.p0[0]), st(self.p0[1])), keep, select=idx)
+        values, _ = self.value.forward(b["vin"], (st(self.v0[0]), st(self.v0[1])), keep, select=idx)
         M = float(logits.shape[1] * logits.shape[2])                                     # samples per agent in the minibatch
         if self.native:   # loss, statistics and d loss / d (logits, values) in one launch (csrc/cat_ppo.hip)
             sums, d_logits, d_values = _learn_native.ppo_loss_grad(

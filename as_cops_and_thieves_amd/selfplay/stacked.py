@@ -346,25 +346,27 @@ class _ConvTrunk(torch.autograd.Function):
     """Conv1d(C, 64, 5, stride 2) -> ReLU -> Conv1d(64, 32, 5, stride 3) -> ReLU of the G stacked networks, bf16 on the
     GPU: one launch of ``libcat_learn.so`` forward and one backward (``csrc/cat_trunk.hip``); the 64-channel intermediate
     never leaves the LDS.  x [G, N, C * R] (channel, ray); w1 [G, 64, C, 5]; b1 [G, 64]; w2 [G, 32, 64, 5]; b2 [G, 32].
-    Returns [G, N, L2 * 32] in (position, channel) order, like the dense path below."""
+    Returns [G, N, L2 * 32] in (position, channel) order, like the dense path below.  ``rows`` (int64 [sel]), ``block``: x is
+    the whole rollout buffer [G, steps * block, C * R] and the kernels read the minibatch of ``sel`` sequences per step out of
+    it in place (N = steps * sel) -- no gathered copy of the observations."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, R):
-        out = _learn_native.trunk_forward(x, w1, b1, w2, b2, R)
+    def forward(ctx, x, w1, b1, w2, b2, R, rows=None, block=0):
+        out = _learn_native.trunk_forward(x, w1, b1, w2, b2, R, rows, block)
         ctx.save_for_backward(x, w1, b1, w2, b2, out)
-        ctx.R = R
+        ctx.R, ctx.rows, ctx.block = R, rows, block
         ctx.slots = tuple(_grad_slot(p) for p in (w1, b1, w2, b2))
         return out
 
     @staticmethod
     def backward(ctx, go):
         x, w1, b1, w2, b2, out = ctx.saved_tensors
-        parts = _learn_native.trunk_backward(x, w1, b1, w2, b2, out, go, ctx.R)
+        parts = _learn_native.trunk_backward(x, w1, b1, w2, b2, out, go, ctx.R, ctx.rows, ctx.block)
         if all(s is not None for s in ctx.slots):   # slabs added up straight into the flat gradient buffer
             _learn_native.trunk_grad_finish(parts, w1.shape[2], ctx.R, ctx.slots)
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         dw1, db1, dw2, db2 = _learn_native.trunk_grad_finish(parts, w1.shape[2], ctx.R)
-        return None, dw1, db1, dw2, db2, None
+        return None, dw1, db1, dw2, db2, None, None, None
 
 
 DENSE_PAD = 1     # widths of the dense-trunk layers can be zero-padded to multiples of this (padding did not avoid the fault below)
@@ -432,17 +434,24 @@ class StackedNet:
         z = torch.zeros(self.layers, self.fp.G, B, HIDDEN, device=self.fp.master.device, dtype=self.fp.compute_dtype)
         return z, z.clone()
 
-    def forward(self, x: torch.Tensor, state, keep: Optional[torch.Tensor], update_state: bool = False):
+    def forward(self, x: torch.Tensor, state, keep: Optional[torch.Tensor], update_state: bool = False,
+                select: Optional[torch.Tensor] = None):
         """x: [G, T, B, C*R] (time-major); state: (h, c) each [layers, G, B, H]; keep: [T, B] (1 = carry the state
         into step t, 0 = an episode starts there) or None.  Returns (out [G, T, B, n_out], new state).  ``update_state``
-        (rollouts, no_grad, kernel path): the recurrence kernels write the new state INTO ``state`` and that is returned."""
-        G, T, B, _ = x.shape
+        (rollouts, no_grad, kernel path): the recurrence kernels write the new state INTO ``state`` and that is returned.
+        ``select`` (int64 [B'], a PPO minibatch): the network runs on x[:, :, select] -- the sequences ``select`` of the
+        rollout buffer x -- which the fused trunk kernels read in place; state and keep are those of the selection."""
+        G, T, B_all, _ = x.shape
+        B = B_all if select is None else select.shape[0]
         dt = self.fp.compute_dtype
         N = T * B
-        z = x.reshape(G, N, self.C * self.R).to(dt)                                              # (channel, ray) order
-        if self.fused_trunk and z.is_cuda and dt == torch.bfloat16 and _learn_native.trunk_supported(G, N, self.C, self.R):
+        fused = (self.fused_trunk and x.is_cuda and dt == torch.bfloat16 and _learn_native.trunk_supported(G, N, self.C, self.R))
+        if select is not None and not (fused and x.dtype == dt and x.is_contiguous()):
+            x, select = x.index_select(2, select), None
+        z = x.reshape(G, T * x.shape[2], self.C * self.R).to(dt)                                 # (channel, ray) order
+        if fused:
             z = _ConvTrunk.apply(z, self.w("trunk.features.0.weight"), self.w("trunk.features.0.bias"),
-                                 self.w("trunk.features.2.weight"), self.w("trunk.features.2.bias"), self.R)
+                                 self.w("trunk.features.2.weight"), self.w("trunk.features.2.bias"), self.R, select, B_all)
         else:   # fp32 / CPU, or a ray count whose intermediate does not fit the LDS (R = 90): dense GEMMs
             z = torch.nn.functional.pad(z, (0, self.in1 - self.C * self.R))
             layers = []

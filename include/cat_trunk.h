@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CAT_TRUNK_ABI_VERSION 1
+#define CAT_TRUNK_ABI_VERSION 2
 #define CAT_TRUNK_C1 64          /* channels after the first convolution */
 #define CAT_TRUNK_C2 32          /* channels after the second */
 #define CAT_TRUNK_TILE 16        /* samples per workgroup pass */
@@ -52,11 +52,20 @@ typedef struct cat_trunk_params {
     int64_t sw1_g, sb1_g, sw2_g, sb2_g;
 } cat_trunk_params;
 
+/* Optional row selection of the input (a PPO minibatch read straight out of the rollout buffer, without a gathered copy):
+   with rows != NULL, sample n reads row (n / sel) * block + rows[n % sel] of x -- sel sequences picked out of block, step-major.
+   Every rows[j] must lie in [0, block); the kernels do not check it. */
+typedef struct cat_trunk_rows {
+    const int64_t *rows;    /* DEVICE [sel], or NULL: sample n reads row n */
+    int32_t sel, block;
+} cat_trunk_rows;
+
 typedef struct cat_trunk_fwd {
     cat_trunk_dims d;
     cat_trunk_params p;
-    const void *x;      /* bf16 [G][N][C * R], (channel, ray) order */
+    const void *x;      /* bf16 [G][N][C * R] (or the larger buffer x_rows selects from), (channel, ray) order */
     int64_t sx_g, sx_n;
+    cat_trunk_rows x_rows;
     void *out;          /* bf16 [G][N][L2 * 32], (position, channel) order, after the second ReLU */
     int64_t so_g, so_n;
 } cat_trunk_fwd;
@@ -66,6 +75,7 @@ typedef struct cat_trunk_bwd {
     cat_trunk_params p;
     const void *x;
     int64_t sx_g, sx_n;
+    cat_trunk_rows x_rows;   /* as in forward */
     const void *out;    /* what forward wrote (the ReLU mask of the second layer) */
     const void *d_out;  /* bf16, gradient w.r.t. out; same strides as out */
     int64_t so_g, so_n;

@@ -106,3 +106,27 @@ def test_stacked_network_with_the_fused_trunk_equals_the_dense_path():
     assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-2
     err, cos = _rel(outs[0][1], outs[1][1])
     assert err <= 5e-2 and cos >= 0.995, (err, cos)
+
+
+@pytest.mark.parametrize("C,R,steps,block,sel", [(2, 64, 16, 300, 75), (4, 64, 5, 64, 64), (4, 90, 3, 200, 37)])
+def test_minibatch_rows_read_in_place_equal_the_gathered_copy(C, R, steps, block, sel):
+    """cat_trunk_rows: the kernels read sample n = (step, j) from row step * block + rows[j] of the rollout buffer -- the same
+    bits, forward and in every parameter gradient, as running them on torch's gathered copy of those rows."""
+    import torch
+    from as_cops_and_thieves_amd.selfplay.stacked import _ConvTrunk
+    G = 3
+    x, w1, b1, w2, b2 = _case(G, steps * block, C, R, seed=C * R + sel)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    rows = torch.randperm(block, generator=gen, device="cuda")[:sel].contiguous()
+    gathered = x.view(G, steps, block, C * R).index_select(2, rows).reshape(G, steps * sel, C * R).contiguous()
+    results = []
+    for args in ((x, rows, block), (gathered, None, 0)):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+        out = _ConvTrunk.apply(args[0], *leaves, R, args[1], args[2])
+        r = torch.randn(out.shape, generator=torch.Generator(device="cuda").manual_seed(5), device="cuda").to(torch.bfloat16)
+        (out.float() * r.float()).sum().backward()
+        results.append((out.detach(), [t.grad for t in leaves]))
+    torch.cuda.synchronize()
+    assert results[0][0].shape == (G, steps * sel, results[1][0].shape[2]) and torch.equal(results[0][0], results[1][0])
+    for got, want in zip(results[0][1], results[1][1]):
+        assert torch.equal(got, want)
