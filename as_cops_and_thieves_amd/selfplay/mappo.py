@@ -66,8 +66,9 @@ class TrainerConfig:
     timesteps: int = 100_000               # TrainingConfig.training_timesteps_per_role_training
     opponent_freeze_duration: int = 15_000
     policy_freeze_duration: int = 15_000
-    horizon: int = 16                      # ticks per rollout; a multiple of ``bptt``.  16 is the throughput-test setting;
-                                           # to LEARN the game use >= 128 (self_play's default; tests/test_gpu_mappo.py)
+    horizon: int = 128                     # ticks per rollout; a multiple of ``bptt``.  With 16 (one BPTT window, the setting
+                                           # of the bench line's first learner figure) the cops do not learn to catch even
+                                           # random thieves in 262 M env-steps; with 128 they do (tests/test_gpu_mappo.py)
     bptt: int = 16                         # BPTT window (reference LSTM sequence_length).  A rollout of W = horizon / bptt
                                            # windows trains on W * num_envs sequences per update: the same number of
                                            # optimiser steps over W times the data (the update's cost is dominated by

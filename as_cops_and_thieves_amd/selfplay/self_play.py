@@ -173,9 +173,9 @@ def run_self_play(map_name: str, num_envs: int, out_dir: Path, iterations: Optio
     ``env_factory(num_envs, seed)``: build the envs some other way (the CPU tests pass a stand-in env with the same surface)."""
     tc = training or TrainingConfig()
     iterations = tc.num_self_play_iterations if iterations is None else iterations
-    # 128-tick rollouts: with 16-tick rollouts the cops' win rate against random thieves stays at its untrained 10 % for
-    # 262 M env-steps, with 128 it rises (profiles/r02_learning_curves.txt); the reference collects 4096 ticks per update
-    trainer_cfg = trainer_cfg or TrainerConfig(timesteps=tc.training_timesteps_per_role_training, horizon=128)
+    # TrainerConfig's 128-tick rollouts: with 16-tick rollouts the cops' win rate against random thieves stays at its untrained
+    # 10 % for 262 M env-steps, with 128 it rises (profiles/r02_learning_curves.txt); the reference collects 4096 ticks per update
+    trainer_cfg = trainer_cfg or TrainerConfig(timesteps=tc.training_timesteps_per_role_training)
     out_dir = Path(out_dir)
     arch = {tc.cop_role_prefix: out_dir / "cops", tc.thief_role_prefix: out_dir / "thieves"}
     for p in arch.values():

@@ -281,7 +281,7 @@ def main() -> None:
         extra["learner_collect_plus_update"] = learner_throughput(args.map, cfg.n_envs, args.rays)
         extra["learner_collect_plus_update, 90 rays"] = learner_throughput(args.map, cfg.n_envs, 90)
         # 128-tick rollouts (8 BPTT windows per env and update): the setting with which the cops learn to catch random
-        # thieves (tests/test_gpu_mappo.py::test_cops_learn_to_catch_random_thieves_on_squarinth; self_play's default)
+        # thieves (tests/test_gpu_mappo.py::test_cops_learn_to_catch_random_thieves_on_squarinth; TrainerConfig's default)
         extra["learner_collect_plus_update, 128-tick rollouts"] = learner_throughput(args.map, cfg.n_envs, args.rays, horizon=128)
     if rank == 0:
         A, R = cfg.n_agents, cfg.n_rays

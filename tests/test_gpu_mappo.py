@@ -120,7 +120,7 @@ def test_learner_learns_a_function_of_the_ray_observations():
     from as_cops_and_thieves_amd.selfplay.probe import NearestRayRewardEnv
     env = NearestRayRewardEnv(VecCopsEnv(load_preset("squarinth"), 1024, num_rays=64, max_step_count=400, seed=1))
     rc = RoleConfig(random_timesteps=0, learning_starts=0, learning_rate=3e-4, entropy_loss_scale=0.01)
-    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0), seed=0)
+    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(horizon=16, policy_freeze_duration=0, opponent_freeze_duration=0), seed=0)
 
     def accuracy(rollouts):
         tot = 0.0
@@ -160,7 +160,7 @@ def test_cops_learn_to_catch_random_thieves_on_squarinth():
                        horizon=128)
     tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, tc, seed=0)
     tr.set_frozen(role="thief", policy=True, value=True)
-    evr = MAPPOTrainer(ev, {"cop": rc, "thief": rc}, TrainerConfig(graph_rollout=False, graph_update=False, normalize_inputs=True), seed=1)
+    evr = MAPPOTrainer(ev, {"cop": rc, "thief": rc}, TrainerConfig(horizon=16, graph_rollout=False, graph_update=False, normalize_inputs=True), seed=1)
 
     def cop_win_rate():
         evr.load_state_dict(tr.state_dict(), optimizer=False)
@@ -183,7 +183,7 @@ def test_self_play_protocol_on_baseline_config_3(tmp_path):
     from as_cops_and_thieves_amd.selfplay.mappo import RoleConfig, TrainerConfig
     from as_cops_and_thieves_amd.selfplay.self_play import TrainingConfig, run_self_play
     rc = RoleConfig(learning_epochs=1, mini_batches=2, random_timesteps=16, learning_starts=32)
-    kw = dict(training=TrainingConfig(n_trial_episodes=5), trainer_cfg=TrainerConfig(timesteps=64, policy_freeze_duration=48,
+    kw = dict(training=TrainingConfig(n_trial_episodes=5), trainer_cfg=TrainerConfig(horizon=16, timesteps=64, policy_freeze_duration=48,
                                                                                    opponent_freeze_duration=48),
               role_cfg={"cop": rc, "thief": rc}, num_rays=64, n_cops=3, n_thieves=2, max_step_count=120, seed=1, log=lambda *a: None)
     run_self_play("grandbyrinth", 8192, tmp_path, iterations=3, **kw)
@@ -212,7 +212,7 @@ def test_trainer_runs_with_other_ray_counts(rays):
     assert ln.trunk_supported(3, 1024, 4, rays) == (rays != 128)
     env = VecCopsEnv(load_preset("squarinth"), 128, num_rays=rays, max_step_count=60, seed=2)
     rc = RoleConfig(learning_epochs=1, mini_batches=2, random_timesteps=0, learning_starts=0)
-    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0), seed=1)
+    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(horizon=16, policy_freeze_duration=0, opponent_freeze_duration=0), seed=1)
     before = {r: rl.fp.master.clone() for r, rl in tr.roles.items()}
     for _ in range(4):
         tr.collect(); tr.update()
@@ -238,7 +238,7 @@ def test_reference_default_ray_count_trains_at_full_batch_size(tmp_path, dense):
         from as_cops_and_thieves_amd import VecCopsEnv, load_preset
         from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, TrainerConfig
         env = VecCopsEnv(load_preset("labyrinth"), 4096, num_rays=90, max_step_count=400)
-        tr = MAPPOTrainer(env, None, TrainerConfig(), seed=0)
+        tr = MAPPOTrainer(env, None, TrainerConfig(horizon=16), seed=0)
         for _ in range(3):
             tr.collect(); tr.update()
         torch.cuda.synchronize()
@@ -263,7 +263,7 @@ def test_fp32_compute_on_the_gpu_still_trains():
     from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, RoleConfig, TrainerConfig
     env = VecCopsEnv(load_preset("squarinth"), 256, num_rays=64, max_step_count=60, seed=2)
     rc = RoleConfig(learning_epochs=1, mini_batches=2, random_timesteps=0, learning_starts=0)
-    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0, compute_bf16=False), seed=1)
+    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(horizon=16, policy_freeze_duration=0, opponent_freeze_duration=0, compute_bf16=False), seed=1)
     rl = next(iter(tr.roles.values()))
     before = rl.fp.master.clone()
     for _ in range(3):

@@ -25,7 +25,7 @@ CHILD = textwrap.dedent("""
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
     env = VecCopsEnv(load_preset("squarinth"), 256, num_rays=64, max_step_count=60, seed=2, env_id_offset=256 * rank)
     rc = RoleConfig(learning_epochs=2, mini_batches=2, random_timesteps=0, learning_starts=0, kl_threshold=kl, learning_rate=3e-3)
-    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(timesteps=64, policy_freeze_duration=0, opponent_freeze_duration=0), seed=0)
+    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(horizon=16, timesteps=64, policy_freeze_duration=0, opponent_freeze_duration=0), seed=0)
     tr.train()
     torch.cuda.synchronize()
     rl = next(iter(tr.roles.values()))

@@ -25,7 +25,7 @@ CHILD = textwrap.dedent("""
         os.environ["CAT_FORCE_ALLREDUCE"] = "1" if force else "0"
         env = VecCopsEnv(load_preset("squarinth"), 256, num_rays=64, max_step_count=60, seed=2)
         rc = RoleConfig(learning_epochs=1, mini_batches=2, random_timesteps=0, learning_starts=0)
-        tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0), seed=3)
+        tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(horizon=16, policy_freeze_duration=0, opponent_freeze_duration=0), seed=3)
         for _ in range(3):
             tr.collect(); tr.update()
         torch.cuda.synchronize()

@@ -48,6 +48,7 @@ def test_reference_hyperparameters():
         assert (c.random_timesteps, c.learning_starts, c.kl_threshold, c.value_loss_scale, c.grad_norm_clip) == (10_000, 15_000, 0.015, 0.5, 0.5)
     tc = TrainerConfig()
     assert (tc.timesteps, tc.opponent_freeze_duration, tc.policy_freeze_duration) == (100_000, 15_000, 15_000)
+    assert (tc.horizon, tc.bptt) == (128, 16)      # build-side: 8 BPTT windows of the reference's sequence length per rollout
 
 
 def test_recurrent_state_resets_at_episode_starts():

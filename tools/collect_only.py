@@ -9,7 +9,7 @@ from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, TrainerConfig
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 env = VecCopsEnv(load_preset("labyrinth"), num_envs=N, num_rays=64, max_step_count=400)
-tr = MAPPOTrainer(env, None, TrainerConfig(), seed=0)
+tr = MAPPOTrainer(env, None, TrainerConfig(horizon=16), seed=0)
 for _ in range(3):
     tr.collect()
 torch.cuda.synchronize()

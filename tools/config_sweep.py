@@ -23,7 +23,7 @@ elif case == "mixed":
     maps = [load_preset(n) for n in ("labyrinth", "squarinth", "lbirinth", "grandbyrinth", "agh-map")]
     env = VecCopsEnv(maps, 4000, num_rays=64, max_step_count=400, slot_map_ids=[i % 5 for i in range(4000)])
     cfg = None
-tr = MAPPOTrainer(env, cfg, TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0), seed=0)
+tr = MAPPOTrainer(env, cfg, TrainerConfig(horizon=16, policy_freeze_duration=0, opponent_freeze_duration=0), seed=0)
 for _ in range(4):
     tr.collect(); tr.update()
 torch.cuda.synchronize()

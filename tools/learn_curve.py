@@ -36,7 +36,7 @@ ev = VecCopsEnv(the_map, num_envs=512, num_rays=64, max_step_count=msc, seed=99)
 tc = TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0, random_action_roles=("thief",), normalize_inputs=norm, horizon=horizon)
 tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, tc, seed=0)
 tr.set_frozen(role="thief", policy=True, value=True)
-evr = MAPPOTrainer(ev, {"cop": rc, "thief": rc}, TrainerConfig(graph_rollout=False, graph_update=False, normalize_inputs=norm), seed=1)
+evr = MAPPOTrainer(ev, {"cop": rc, "thief": rc}, TrainerConfig(horizon=16, graph_rollout=False, graph_update=False, normalize_inputs=norm), seed=1)
 t0 = time.time()
 for u in range(U + 1):
     if u % max(1, U // 10) == 0:

@@ -19,7 +19,7 @@ norm = (sys.argv[3] == "norm") if len(sys.argv) > 3 else False
 lr = float(sys.argv[4]) if len(sys.argv) > 4 else 3e-4
 env = NearestRayRewardEnv(VecCopsEnv(load_preset("squarinth"), num_envs=N, num_rays=64, max_step_count=400, seed=1))
 rc = RoleConfig(random_timesteps=0, learning_starts=0, learning_rate=lr, entropy_loss_scale=0.01)
-tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(policy_freeze_duration=0, opponent_freeze_duration=0, normalize_inputs=norm), seed=0)
+tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(horizon=16, policy_freeze_duration=0, opponent_freeze_duration=0, normalize_inputs=norm), seed=0)
 t0 = time.time()
 for u in range(U + 1):
     tr.collect()
