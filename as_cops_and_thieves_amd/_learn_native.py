@@ -173,7 +173,7 @@ def lib() -> C.CDLL:
         for n in ("cat_dense_forward", "cat_dense_dgrad"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
-        assert L.cat_dense_abi_version() == 1
+        assert L.cat_dense_abi_version() == 2
         L.cat_rollout_abi_version.restype = C.c_int
         L.cat_rollout_last_error.restype = C.c_char_p
         for n in ("cat_rollout_pack", "cat_rollout_sample", "cat_rollout_post"):
@@ -443,7 +443,8 @@ def sum_chunks(partial, dst=None, dst2=None, accumulate: bool = False):
 
 class WgradArgs(C.Structure):
     _fields_ = [("G", C.c_int32), ("K", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p),
-                ("partial", C.c_void_p), ("splits", C.c_int32), ("pad", C.c_int32)]
+                ("partial", C.c_void_p), ("splits", C.c_int32), ("pad", C.c_int32),
+                ("b1", C.c_void_p), ("partial1", C.c_void_p), ("N1", C.c_int32), ("pad1", C.c_int32)]
 
 
 def wgrad_supported(g, x) -> bool:
@@ -473,7 +474,7 @@ def dense_wgrad(g, x, slot=None, bias_job=None):
     assert g.dtype == x.dtype == torch.bfloat16 and x.shape[:2] == (G, K)
     S = lib().cat_dense_wgrad_splits(G, K, M, N)
     partial = torch.empty(G, S, M * N, dtype=torch.float32, device=g.device)
-    a = WgradArgs(G, K, M, N, g.data_ptr(), x.data_ptr(), partial.data_ptr(), S, 0)
+    a = WgradArgs(G, K, M, N, g.data_ptr(), x.data_ptr(), partial.data_ptr(), S, 0, None, None, 0, 0)
     _check(lib().cat_dense_wgrad(C.byref(a), _stream()), "cat_dense_wgrad")
     out = None
     if slot is not None:
@@ -486,6 +487,28 @@ def dense_wgrad(g, x, slot=None, bias_job=None):
     jb = None if bias_job is None else _sum_job(bias_job[0], bias_job[1], True)
     _check(lib().cat_dense_sum_chunks2(C.byref(ja), None if jb is None else C.byref(jb), G, _stream()), "cat_dense_sum_chunks2")
     return None if slot is not None else out.view(G, M, N)
+
+
+def dense_wgrad2(g, x0, x1, slot0, slot1) -> None:
+    """The weight gradients of TWO layers that share the gradient g [G, K, M] of their summed pre-activations (an LSTM layer:
+    W_ih with its input x0 [G, K, N0], W_hh with h_in x1 [G, K, N1]): one launch reads g once, one launch adds the slabs of
+    both up into ``slot0`` [G, M, N0] and ``slot1`` [G, M, N1]."""
+    import torch
+    G, K, M = g.shape
+    N0, N1 = x0.shape[2], x1.shape[2]
+    g, x0, x1 = g.contiguous(), x0.contiguous(), x1.contiguous()
+    assert g.dtype == x0.dtype == x1.dtype == torch.bfloat16 and x0.shape[:2] == (G, K) and x1.shape[:2] == (G, K)
+    S = lib().cat_dense_wgrad_splits(G, K, M, 128 * (-(-N0 // 128) - (-N1 // 128)))
+    p0 = torch.empty(G, S, M * N0, dtype=torch.float32, device=g.device)
+    p1 = torch.empty(G, S, M * N1, dtype=torch.float32, device=g.device)
+    a = WgradArgs(G, K, M, N0, g.data_ptr(), x0.data_ptr(), p0.data_ptr(), S, 0, x1.data_ptr(), p1.data_ptr(), N1, 0)
+    _check(lib().cat_dense_wgrad(C.byref(a), _stream()), "cat_dense_wgrad")
+    jobs = []
+    for part, slot, N in ((p0, slot0, N0), (p1, slot1, N1)):
+        assert slot.shape == (G, M, N) and slot[0].is_contiguous()
+        dst = slot.view(G, M * N) if slot.is_contiguous() else slot.as_strided((G, M * N), (slot.stride(0), 1))
+        jobs.append(_sum_job(part, dst, True))
+    _check(lib().cat_dense_sum_chunks2(C.byref(jobs[0]), C.byref(jobs[1]), G, _stream()), "cat_dense_sum_chunks2")
 
 
 class GemmArgs(C.Structure):

@@ -167,15 +167,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16 *tile, int row0, int col0
 __global__ __launch_bounds__(BLOCK) void wgrad_kernel(const cat_dense_wgrad_args a)
 {
     __shared__ __attribute__((aligned(16))) __bf16 sa[2][WG_BK * WG_LD], sb[2][WG_BK * WG_LD];
-    const int tiles_n = (a.N + WG_BN - 1) / WG_BN;
-    const int m0 = (blockIdx.x / tiles_n) * WG_BM, n0 = (blockIdx.x % tiles_n) * WG_BN, split = blockIdx.y, g = blockIdx.z;
+    // column tiles: those of b, then those of the optional second input b1 (its own width, slabs and row stride)
+    const int tiles_n0 = (a.N + WG_BN - 1) / WG_BN, tiles_n = tiles_n0 + (a.b1 ? (a.N1 + WG_BN - 1) / WG_BN : 0);
+    const int tn = blockIdx.x % tiles_n;
+    const bool second = tn >= tiles_n0;
+    const int N = second ? a.N1 : a.N;
+    const int m0 = (blockIdx.x / tiles_n) * WG_BM, n0 = (second ? tn - tiles_n0 : tn) * WG_BN, split = blockIdx.y, g = blockIdx.z;
     const int rows_per = ((a.K + a.splits - 1) / a.splits + WG_BK - 1) / WG_BK * WG_BK;
     const int k0 = split * rows_per, k1 = min(a.K, k0 + rows_per);
     const int lr = threadIdx.x >> 4, lc = threadIdx.x & 15;
-    const __bf16 *A = (const __bf16 *)a.a + (size_t)g * a.K * a.M, *B = (const __bf16 *)a.b + (size_t)g * a.K * a.N;
+    const __bf16 *A = (const __bf16 *)a.a + (size_t)g * a.K * a.M, *B = (const __bf16 *)(second ? a.b1 : a.b) + (size_t)g * a.K * N;
     const bf16x8 z8 = {};
     bf16x8 ra[2], rb[2];
-    const bool vec_a = a.M % 8 == 0, vec_b = a.N % 8 == 0;     // rows of 16-byte runs; else (tiny heads) element by element
+    const bool vec_a = a.M % 8 == 0, vec_b = N % 8 == 0;       // rows of 16-byte runs; else (tiny heads) element by element
     auto row_run = [&](const __bf16 *base, int width, int col, bool vec) -> bf16x8 {
         if (vec) return col < width ? *(const bf16x8 *)(base + col) : z8;
         bf16x8 v = z8;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(BLOCK) void wgrad_kernel(const cat_dense_wgrad_args
         for (int h = 0; h < 2; ++h) {
             const int row = kb + lr + 16 * h;
             ra[h] = row < k1 ? row_run(A + (size_t)row * a.M, a.M, m0 + 8 * lc, vec_a) : z8;
-            rb[h] = row < k1 ? row_run(B + (size_t)row * a.N, a.N, n0 + 8 * lc, vec_b) : z8;
+            rb[h] = row < k1 ? row_run(B + (size_t)row * N, N, n0 + 8 * lc, vec_b) : z8;
         }
     };
     auto lstore = [&](int buf) {
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void wgrad_kernel(const cat_dense_wgrad_args
         if (it + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
-    float *out = a.partial + ((size_t)g * a.splits + split) * a.M * a.N;
+    float *out = (second ? a.partial1 : a.partial) + ((size_t)g * a.splits + split) * a.M * N;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) void wgrad_kernel(const cat_dense_wgrad_args
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int n = n0 + wn * 64 + 16 * j + r;
-                    if (n < a.N) out[(size_t)m * a.N + n] = acc[i][j][e];
+                    if (n < N) out[(size_t)m * N + n] = acc[i][j][e];
                 }
         }
 }
@@ -485,7 +489,9 @@ extern "C" int cat_dense_wgrad(const cat_dense_wgrad_args *a, void *stream)
         return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_wgrad: bad dimensions");
     if (!a->a || !a->b || !a->partial || ((a->M % 8 == 0) && ((uintptr_t)a->a % 16)) || ((a->N % 8 == 0) && ((uintptr_t)a->b % 16)))
         return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_wgrad: NULL or misaligned buffer");
-    const int tiles = ((a->M + WG_BM - 1) / WG_BM) * ((a->N + WG_BN - 1) / WG_BN);
+    if (a->b1 && (a->N1 <= 0 || !a->partial1 || ((a->N1 % 8 == 0) && ((uintptr_t)a->b1 % 16))))
+        return fail(CAT_DENSE_ERR_BAD_ARG, "cat_dense_wgrad: the second input needs N1 > 0, its slabs and an aligned buffer");
+    const int tiles = ((a->M + WG_BM - 1) / WG_BM) * ((a->N + WG_BN - 1) / WG_BN + (a->b1 ? (a->N1 + WG_BN - 1) / WG_BN : 0));
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, a->splits, a->G), dim3(BLOCK), 0, (hipStream_t)stream, *a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAT_DENSE_OK : fail(CAT_DENSE_ERR_HIP, hipGetErrorString(e));

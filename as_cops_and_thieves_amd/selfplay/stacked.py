@@ -95,8 +95,9 @@ class _LSTMSeq(torch.autograd.Function):
     CPU (the parity tests, ``compute_bf16=False``): the same recurrence step by step in torch."""
 
     @staticmethod
-    def forward(ctx, xproj, w_hh, b_ih, b_hh, h0, c0, keep, state_out=None, grad_mode=True):
+    def forward(ctx, xproj, w_hh, b_ih, b_hh, h0, c0, keep, state_out=None, grad_mode=True, shared=None):
         G, T, B, _ = xproj.shape
+        ctx.shared = shared        # _SharedWgrad of the projection that produced xproj: its weight gradient is taken here
         # ``grad_mode`` = torch.is_grad_enabled() at the CALL (inside a Function's forward it always reads False, and
         # needs_input_grad stays True for parameters under no_grad): a rollout tick keeps nothing for a backward pass
         train = grad_mode and any(ctx.needs_input_grad)
@@ -167,8 +168,14 @@ class _LSTMSeq(torch.autograd.Function):
             dg_all = torch.stack(dgs, 1)                                          # [G, T, B, 4H] = d xproj
         a = dg_all.reshape(G, T * B, dg_all.shape[3])
         hin = h_in.reshape(G, T * B, h_in.shape[3])
-        d_w = _weight_grad(a, hin, w_slot) if ctx.native else torch.bmm(a.transpose(1, 2), hin)   # one product over all steps
-        return dg_all, d_w, d_bih, d_bhh, dh, dc, None, None, None
+        sh = ctx.shared
+        if (ctx.native and sh is not None and sh.slot is not None and w_slot is not None and _learn_native.wgrad_supported(a, hin)):
+            # W_ih's and W_hh's gradients share d xproj: one launch reads it once (the projection's backward then skips its own)
+            _learn_native.dense_wgrad2(a, sh.x, hin, sh.slot, w_slot)
+            sh.taken, d_w = True, None
+        else:
+            d_w = _weight_grad(a, hin, w_slot) if ctx.native else torch.bmm(a.transpose(1, 2), hin)   # one product over all steps
+        return dg_all, d_w, d_bih, d_bhh, dh, dc, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------- flat parameters
@@ -268,6 +275,16 @@ class _Lin(torch.autograd.Function):
 _OWN_GEMMS = os.environ.get("CAT_LIB_GEMM", "0") != "1"   # the layers' products through csrc/cat_dense.hip (else the BLAS library)
 
 
+class _SharedWgrad:
+    """Hand-over between a bare projection (``_LinAct`` with ``shared``) and the ``_LSTMSeq`` that consumes its output: the
+    projection's forward leaves its input and its weight's gradient slot here; the recurrence's backward -- which runs first
+    and holds the gradient both weight gradients are products of -- takes both in one launch and says so."""
+
+    def __init__(self):
+        self.x = self.slot = None
+        self.taken = False
+
+
 class _LinAct(torch.autograd.Function):
     """act(x @ w^T + b) for G stacked layers in bf16 on the GPU (``csrc/cat_dense.hip``): product + bias + activation in
     one MFMA kernel, the activation's derivative and the bias gradient (column sums) in one pass over the incoming
@@ -277,8 +294,11 @@ class _LinAct(torch.autograd.Function):
     Gradients of FlatParams leaves are added straight into their slots of the flat gradient buffer (see _LSTMSeq)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act):
+    def forward(ctx, x, w, b, act, shared=None):
         ctx.own = _OWN_GEMMS and _learn_native.gemm_supported(x, w)
+        ctx.shared = shared
+        if shared is not None:
+            shared.x, shared.slot, shared.taken = x, _grad_slot(w), False
         if ctx.own:   # product, bias and activation in one kernel (csrc/cat_dense.hip)
             y = _learn_native.dense_forward(x, w, b, act)
         else:
@@ -306,7 +326,10 @@ class _LinAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _learn_native.dense_dgrad(g, w) if ctx.own else torch.bmm(g, w)
-        return dx, _weight_grad(g, x, w_slot, bias_job), db, None
+        if ctx.shared is not None and ctx.shared.taken:            # the recurrence's backward has added this weight gradient already
+            assert bias_job is None
+            return dx, None, db, None, None
+        return dx, _weight_grad(g, x, w_slot, bias_job), db, None, None
 
 
 def _lin_act(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int) -> torch.Tensor:
@@ -478,13 +501,15 @@ class StackedNet:
         hs, cs = [], []
         for l in range(self.layers):
             w_ih, b_ih, b_hh = (self.w(f"trunk.lstm.{n}_l{l}") for n in ("weight_ih", "bias_ih", "bias_hh"))
+            shared = None
             if native:   # the recurrence kernel adds the biases and returns their gradient: the projection is a bare GEMM
-                xp = _LinAct.apply(inp, w_ih, None, 0).view(G, T, B, 4 * HIDDEN)
+                shared = _SharedWgrad() if torch.is_grad_enabled() else None
+                xp = _LinAct.apply(inp, w_ih, None, 0, shared).view(G, T, B, 4 * HIDDEN)
             else:
                 xp, b_ih, b_hh = _lin(inp, w_ih, b_ih + b_hh).view(G, T, B, 4 * HIDDEN), None, None
             in_place = update_state and native and not torch.is_grad_enabled() and h0.dtype == dt
             out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), b_ih, b_hh, h0[l].to(dt), c0[l].to(dt), kp,
-                                         (h0[l], c0[l]) if in_place else None, torch.is_grad_enabled())
+                                         (h0[l], c0[l]) if in_place else None, torch.is_grad_enabled(), shared)
             hs.append(hT); cs.append(cT)
             inp = out.reshape(G, N, HIDDEN)
         y = inp

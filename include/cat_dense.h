@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-#define CAT_DENSE_ABI_VERSION 1
+#define CAT_DENSE_ABI_VERSION 2
 #define CAT_DENSE_MAX_CHUNKS 256
 #define CAT_DENSE_MAX_OUT 1024
 
@@ -64,6 +64,12 @@ typedef struct cat_dense_wgrad_args {
     const void *a, *b;
     float *partial;             /* [G][splits][M][N] */
     int32_t splits, pad;
+    /* optional second input that shares the gradient a (an LSTM layer: W_ih's input and W_hh's h_in share d_xproj, which
+       is then read once): b1 bf16 [G][K][N1] or NULL, its slabs partial1 [G][splits][M][N1].  splits: take
+       cat_dense_wgrad_splits(G, K, M, 128 * (ceil(N / 128) + ceil(N1 / 128))) -- the tile count of both together. */
+    const void *b1;
+    float *partial1;
+    int32_t N1, pad1;
 } cat_dense_wgrad_args;
 int cat_dense_wgrad_splits(int32_t G, int32_t K, int32_t M, int32_t N);
 int cat_dense_wgrad(const cat_dense_wgrad_args *a, void *stream);

@@ -77,3 +77,26 @@ def test_layer_forward_and_input_gradient_kernels_match_fp32_gemms(G, M, N, K, a
     dx = ln.dense_dgrad(gr, w)
     torch.cuda.synchronize()
     assert dx.shape == (G, M, K) and float((dx.float() - dx_want).abs().max()) <= 2 ** -7 * max(1.0, float(dx_want.abs().max()))
+
+
+@pytest.mark.parametrize("G,K,M,N0,N1", [(3, 16384, 512, 256, 128), (2, 4099, 512, 128, 128), (1, 1024, 130, 72, 8)])
+def test_two_inputs_sharing_one_gradient_get_their_weight_gradients_in_one_launch(G, K, M, N0, N1):
+    """cat_dense_wgrad with a second input (an LSTM layer's W_ih and W_hh share d xproj): each gradient equals the fp32
+    product of the same bf16 operands to the accuracy of a bf16 result, added INTO the slots."""
+    import torch
+    from as_cops_and_thieves_amd import _learn_native as ln
+    gen = torch.Generator(device="cuda").manual_seed(K + N1)
+    g = torch.randn(G, K, M, generator=gen, device="cuda").to(torch.bfloat16)
+    x0 = torch.randn(G, K, N0, generator=gen, device="cuda").to(torch.bfloat16)
+    x1 = torch.randn(G, K, N1, generator=gen, device="cuda").to(torch.bfloat16)
+    flat = torch.zeros(G, M * (N0 + N1) + 16, dtype=torch.bfloat16, device="cuda")      # slots inside a wider flat buffer
+    s0 = flat[:, 8:8 + M * N0].view(G, M, N0)
+    s1 = flat[:, 8 + M * N0:8 + M * (N0 + N1)].view(G, M, N1)
+    s0.fill_(1.0)
+    ln.dense_wgrad2(g, x0, x1, s0, s1)
+    torch.cuda.synchronize()
+    for slot, x, base in ((s0, x0, 1.0), (s1, x1, 0.0)):
+        want = torch.bmm(g.float().transpose(1, 2), x.float()) + base
+        err = float((slot.float() - want).norm() / want.norm())
+        assert err <= 6e-3, err
+    assert float(flat[:, :8].abs().max()) == 0.0 and float(flat[:, 8 + M * (N0 + N1):].abs().max()) == 0.0
