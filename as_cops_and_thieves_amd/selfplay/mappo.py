@@ -78,6 +78,8 @@ class TrainerConfig:
     graph_update: bool = True              # capture the minibatch step (forward, losses, backward / clip, Adam)
     reference_q11: bool = False            # True: every critic sees the alphabetically first agent's channels (quirk Q11)
     random_action_roles: Tuple[str, ...] = ()   # roles that act uniformly at random throughout (a fixed random opponent)
+    deferred_values: bool = True           # kernel path: the critics do not run tick by tick (nothing in a rollout reads
+                                           # their output) but once per BPTT window after the last tick, on all its ticks
     normalize_inputs: bool = False         # False = the reference: raw distances (0..400) and type codes (0..4) go into the
                                            # convolutions (skrl's state_preprocessor is None).  True (build-side option):
                                            # distances / ray length, types / 4 -- see tools/learn_curve.py
@@ -447,13 +449,14 @@ class MAPPOTrainer:
         tensors only and no host synchronisation: the whole loop is captured in one HIP graph and replayed."""
         N, T = self.N, self.tcfg.horizon
         all_fused = self._native_post and not random_actions and all(rl.native and rl.random_rows is None for rl in self.roles.values())
+        defer = all_fused and self._native_io and self.tcfg.deferred_values
         for t in range(T):
             state = self.env.state()
             keep = self._keep32 if all_fused else (~self._starts).view(1, N)
             self._start_buf[t].copy_(self._starts)
             for rl in self.roles.values():
                 if t % rl.bptt == 0:                # the recurrent state at the start of a BPTT window is kept
-                    for dst, src in zip(rl.p0w + rl.v0w, rl.p_state + rl.v_state):
+                    for dst, src in zip(rl.p0w + (() if defer else rl.v0w), rl.p_state + (() if defer else rl.v_state)):
                         dst[t // rl.bptt].copy_(src)
                 b = rl.buf
                 fused = self._native_io and rl.native and not random_actions and rl.random_rows is None
@@ -463,14 +466,17 @@ class MAPPOTrainer:
                 else:
                     pin, vin = self._inputs(rl, self._obs, state)
                 logits, p_new = rl.policy.forward(pin.unsqueeze(1), rl.p_state, keep, update_state=True)
-                val, v_new = rl.value.forward(vin.unsqueeze(1), rl.v_state, keep, update_state=True)
+                if defer:                        # the critic runs after the last tick (below): no tick reads its value
+                    val, v_new = None, rl.v_state
+                else:
+                    val, v_new = rl.value.forward(vin.unsqueeze(1), rl.v_state, keep, update_state=True)
                 for old, new in zip(rl.p_state + rl.v_state, p_new + v_new):
                     if old is not new:           # the kernel path has already written the new state in place
                         old.copy_(new)
                 if fused:   # draw, log-probability, value and the env's action columns in one launch
                     u = torch.rand(rl.G, N, device=self.device)
-                    _learn_native.rollout_sample(logits[:, 0].contiguous(), u, val[:, 0, :, 0].contiguous(), b["act"][:, t], b["logp"][:, t],
-                                                 b["val"][:, t], self._actions, rl.indices)
+                    _learn_native.rollout_sample(logits[:, 0].contiguous(), u, None if defer else val[:, 0, :, 0].contiguous(), b["act"][:, t],
+                                                 b["logp"][:, t], None if defer else b["val"][:, t], self._actions, rl.indices)
                     continue
                 logp_all = torch.log_softmax(logits[:, 0].float(), dim=-1)                               # [G, N, 4]
                 if random_actions:
@@ -497,6 +503,18 @@ class MAPPOTrainer:
             self._done_buf[t].copy_(done)
             self._starts.copy_(done)               # the env auto-resets: the next tick starts a new episode
             self._keep32.copy_((~done).view(1, N))
+        if defer:
+            # The critics, one BPTT window at a time over the stored input rows: 16 ticks x N envs per launch instead of N, the
+            # recurrence of a window in one launch per layer, and the window-start states fall out on the way.  (The cell state
+            # stays fp32 inside a window, as in the training forward, where tick-by-tick it is rounded to bf16 every tick.)
+            keep_all = (~self._start_buf).to(torch.float32)
+            for rl in self.roles.values():
+                L = rl.bptt
+                for k in range(rl.W):
+                    for dst, src in zip(rl.v0w, rl.v_state):
+                        dst[k].copy_(src)
+                    val, _ = rl.value.forward(rl.buf["vin"][:, k * L:(k + 1) * L], rl.v_state, keep_all[k * L:(k + 1) * L], update_state=True)
+                    rl.buf["val"][:, k * L:(k + 1) * L].copy_(val[..., 0])
 
     @torch.no_grad()
     def collect(self, random_actions: bool = False) -> None:

@@ -274,3 +274,30 @@ def test_fp32_compute_on_the_gpu_still_trains():
     assert rl.fp.compute_dtype == torch.float32 and rl.fp.lp is rl.fp.master and not rl.native
     assert torch.isfinite(rl.fp.master).all() and not torch.equal(before, rl.fp.master)
     env.close()
+
+
+def test_critics_run_per_window_after_the_rollout_give_the_tick_by_tick_values():
+    """TrainerConfig.deferred_values: the same rollout (same seeds: same actions, rewards, inputs) with the critics run tick by
+    tick and with the critics run once per BPTT window afterwards.  Everything the actors produce is identical; the values, the
+    critics' recurrent state and its window-start copies agree to bf16 accuracy (inside a window the cell state stays fp32
+    where tick by tick it is rounded every tick)."""
+    import torch
+    from as_cops_and_thieves_amd import VecCopsEnv, load_preset
+    from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, RoleConfig, TrainerConfig
+    rc = RoleConfig(random_timesteps=0, learning_starts=0)
+    runs = []
+    for deferred in (False, True):
+        env = VecCopsEnv(load_preset("squarinth"), 256, num_rays=64, max_step_count=40, seed=5)
+        tc = TrainerConfig(horizon=32, policy_freeze_duration=0, opponent_freeze_duration=0, deferred_values=deferred, graph_rollout=False)
+        tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, tc, seed=2)
+        tr.collect(); tr.collect()                                  # the second rollout starts from a carried state, mid-episode
+        rl = next(iter(tr.roles.values()))
+        runs.append({k: v.clone() for k, v in rl.buf.items()} | {"v_state": [s.clone() for s in rl.v_state], "v0w": [s.clone() for s in rl.v0w]})
+        env.close()
+    a, b = runs
+    for k in ("pin", "vin", "act", "logp", "rew"):
+        assert torch.equal(a[k], b[k]), k
+    scale = float(a["val"].abs().max())
+    assert float((a["val"] - b["val"]).abs().max()) <= 3e-2 * max(scale, 1.0)
+    for x, y in zip(a["v_state"] + a["v0w"], b["v_state"] + b["v0w"]):
+        assert float((x.float() - y.float()).abs().max()) <= 2.0 ** -6 * max(1.0, float(x.float().abs().max()))   # two bf16 ulps of the largest cell state
