@@ -70,7 +70,7 @@ class TrunkBwd(C.Structure):
 ROLLOUT_SYMBOLS = ("cat_rollout_abi_version", "cat_rollout_last_error", "cat_rollout_pack", "cat_rollout_sample", "cat_rollout_post")
 DENSE_SYMBOLS = ("cat_dense_abi_version", "cat_dense_last_error", "cat_dense_bias_act", "cat_dense_act_grad", "cat_dense_sum_chunks",
                  "cat_dense_wgrad_splits", "cat_dense_wgrad", "cat_dense_forward", "cat_dense_dgrad", "cat_dense_sum_chunks2")
-PPO_SYMBOLS = ("cat_ppo_abi_version", "cat_ppo_last_error", "cat_ppo_loss_grad", "cat_ppo_adam_step")
+PPO_SYMBOLS = ("cat_ppo_abi_version", "cat_ppo_last_error", "cat_ppo_loss_grad", "cat_ppo_adam_step", "cat_ppo_gae_scan")
 
 
 class PpoLoss(C.Structure):
@@ -154,7 +154,7 @@ def lib() -> C.CDLL:
         for n in ("cat_ppo_loss_grad", "cat_ppo_adam_step"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
-        assert L.cat_ppo_abi_version() == 1
+        assert L.cat_ppo_abi_version() == 2
         L.cat_dense_abi_version.restype = C.c_int
         L.cat_dense_last_error.restype = C.c_char_p
         L.cat_dense_bias_act.restype = C.c_int
@@ -388,6 +388,28 @@ def ppo_adam_step(ar, col_train, epoch_active, m, v, steps, master, lp, kl_out, 
     a = PpoAdam(G, P, 256, 0, ar.data_ptr(), col_train.data_ptr(), epoch_active.data_ptr(), m.data_ptr(), v.data_ptr(), steps.data_ptr(),
                 master.data_ptr(), _ptr(lp), kl_out.data_ptr(), scratch.data_ptr(), lr, beta1, beta2, eps, grad_norm_clip, kl_threshold or 0.0)
     _check(lib().cat_ppo_adam_step(C.byref(a), _stream()), "cat_ppo_adam_step")
+
+
+class PpoGae(C.Structure):
+    _fields_ = [("G", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("pad", C.c_int32), ("rewards", C.c_void_p), ("values", C.c_void_p),
+                ("dones", C.c_void_p), ("last_values", C.c_void_p), ("gamma", C.c_float), ("lambda_", C.c_float),
+                ("adv", C.c_void_p), ("ret", C.c_void_p)]
+
+
+def ppo_gae(rewards, values, dones, last_values, gamma: float, lam: float, adv_out, ret_out) -> None:
+    """rewards, values, adv_out, ret_out fp32 [G, T, N] contiguous; dones bool / uint8 [T, N]; last_values fp32 [G, N]: the whole
+    reverse scan in one launch (include/cat_ppo.h)."""
+    import torch
+    G, T, N = rewards.shape
+    for t in (rewards, values, adv_out, ret_out):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (G, T, N)
+    last_values = last_values.contiguous()
+    assert last_values.dtype == torch.float32 and last_values.shape == (G, N)
+    d8 = dones.contiguous().view(torch.uint8) if dones.dtype == torch.bool else dones.contiguous()
+    assert d8.dtype == torch.uint8 and d8.shape == (T, N)
+    a = PpoGae(G, T, N, 0, rewards.data_ptr(), values.data_ptr(), d8.data_ptr(), last_values.data_ptr(), gamma, lam,
+               adv_out.data_ptr(), ret_out.data_ptr())
+    _check(lib().cat_ppo_gae_scan(C.byref(a), _stream()), "cat_ppo_gae_scan")
 
 
 # ---------------------------------------------------------------------------------------------- dense-layer epilogues

@@ -131,6 +131,25 @@ __global__ __launch_bounds__(BLOCK) void adam_kernel(const cat_ppo_adam a)
     }
 }
 
+// one thread per (agent, env): the reverse scan of the rollout's T ticks; lanes = envs, so every access is coalesced
+__global__ __launch_bounds__(BLOCK) void gae_kernel(const cat_ppo_gae a)
+{
+    const int n = blockIdx.x * BLOCK + threadIdx.x, g = blockIdx.y;
+    if (n >= a.N) return;
+    const size_t col = (size_t)g * a.T * a.N + n;
+    float last = 0.0f, nxt = a.last_values[(size_t)g * a.N + n];
+    const float gl = a.gamma * a.lambda;
+    for (int t = a.T - 1; t >= 0; --t) {
+        const size_t o = col + (size_t)t * a.N;
+        const float nd = a.dones[(size_t)t * a.N + n] ? 0.0f : 1.0f, v = a.values[o];
+        const float delta = a.rewards[o] + a.gamma * nxt * nd - v;
+        last = delta + gl * nd * last;
+        a.adv[o] = last;
+        a.ret[o] = last + v;
+        nxt = v;
+    }
+}
+
 thread_local char g_err[256] = "";
 int fail(int code, const char *msg)
 {
@@ -152,6 +171,16 @@ extern "C" int cat_ppo_loss_grad(const cat_ppo_loss *a, void *stream)
     if (((uintptr_t)a->logits % 8) || ((uintptr_t)a->d_logits % 8))
         return fail(CAT_PPO_ERR_BAD_ARG, "cat_ppo_loss_grad: logits must be 8-byte aligned");
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(a->chunks, a->G), dim3(BLOCK), 0, (hipStream_t)stream, *a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? CAT_PPO_OK : fail(CAT_PPO_ERR_HIP, hipGetErrorString(e));
+}
+
+extern "C" int cat_ppo_gae_scan(const cat_ppo_gae *a, void *stream)
+{
+    if (!a || a->G <= 0 || a->G > 65535 || a->T <= 0 || a->N <= 0) return fail(CAT_PPO_ERR_BAD_ARG, "cat_ppo_gae_scan: bad dimensions");
+    if (!a->rewards || !a->values || !a->dones || !a->last_values || !a->adv || !a->ret)
+        return fail(CAT_PPO_ERR_BAD_ARG, "cat_ppo_gae_scan: a required buffer is NULL");
+    hipLaunchKernelGGL(gae_kernel, dim3((a->N + BLOCK - 1) / BLOCK, a->G), dim3(BLOCK), 0, (hipStream_t)stream, *a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAT_PPO_OK : fail(CAT_PPO_ERR_HIP, hipGetErrorString(e));
 }

@@ -345,11 +345,15 @@ class RoleLearner:
                use_graph: bool) -> None:
         """dones/starts [T, N]; last_values [G, N] (bootstrap, already zeroed where the next tick starts an episode)."""
         cfg, b = self.cfg, self.buf
-        adv, ret = compute_gae(b["rew"], b["val"], dones, last_values, cfg.discount_factor, cfg.gae_lambda)
+        if self.native:   # the reverse scan over the T ticks as one launch (csrc/cat_ppo.hip) instead of ~7 small ones per tick
+            adv = torch.empty_like(b["adv"])
+            _learn_native.ppo_gae(b["rew"], b["val"], dones, last_values, cfg.discount_factor, cfg.gae_lambda, adv, b["ret"])
+        else:
+            adv, ret = compute_gae(b["rew"], b["val"], dones, last_values, cfg.discount_factor, cfg.gae_lambda)
+            b["ret"].copy_(ret)
         mean = adv.mean(dim=(1, 2), keepdim=True)
         std = adv.std(dim=(1, 2), keepdim=True)
         b["adv"].copy_((adv - mean) / (std + 1e-8))                                     # skrl: per agent, whole memory
-        b["ret"].copy_(ret)
         if self.W == 1:
             self.start = starts
         else:   # the rollout as W * N training sequences of ``bptt`` ticks: [G, W * bptt, N, ..] -> [G, bptt, W * N, ..]

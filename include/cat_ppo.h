@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CAT_PPO_ABI_VERSION 1
+#define CAT_PPO_ABI_VERSION 2
 #define CAT_PPO_ACTIONS 4            /* the four impulse actions of every agent (cat_sim.h, cat_step) */
 #define CAT_PPO_MAX_CHUNKS 256
 
@@ -61,6 +61,19 @@ typedef struct cat_ppo_adam {
     float *norm_partial;        /* [G][chunks] scratch */
     float lr, beta1, beta2, eps, grad_norm_clip, kl_threshold;
 } cat_ppo_adam;
+
+/* Generalised advantage estimation over a stored rollout (skrl's compute_gae, reverse scan over the T ticks; one thread per
+ * (agent, env) column):  delta_t = r_t + gamma * V_{t+1} * (1 - done_t) - V_t,  A_t = delta_t + gamma * lambda * (1 - done_t) * A_{t+1},
+ * V_T = last_values, A_T = 0;  adv = A, ret = A + V.  The advantage normalisation stays with the caller. */
+typedef struct cat_ppo_gae {
+    int32_t G, T, N, pad;
+    const float *rewards, *values;      /* [G][T][N] */
+    const uint8_t *dones;               /* [T][N]: 1 = the episode ended with tick t (no bootstrap across it) */
+    const float *last_values;           /* [G][N] */
+    float gamma, lambda;
+    float *adv, *ret;                   /* [G][T][N] */
+} cat_ppo_gae;
+int cat_ppo_gae_scan(const cat_ppo_gae *a, void *stream);
 
 int cat_ppo_abi_version(void);
 const char *cat_ppo_last_error(void);

@@ -78,3 +78,23 @@ def test_optimiser_step_matches_the_torch_formulation():
         assert torch.equal(lp, master.to(torch.bfloat16))
     assert float(ref_active[1]) == 0.0 and float(ref_active[0]) == 1.0
     assert torch.equal(master[col == 0], start[col == 0])                                   # frozen columns never move
+
+
+@pytest.mark.parametrize("G,T,N", [(3, 128, 4096), (2, 16, 1000), (1, 1, 7)])
+def test_gae_scan_equals_the_torch_recursion(G, T, N):
+    """cat_ppo_gae_scan against selfplay.mappo.compute_gae (the formulation tests/test_mappo_cpu.py pins to the textbook
+    recursion): one launch for the whole reverse scan.  fp32 both; the kernel may contract a multiply-add, hence 1e-5."""
+    import torch
+    from as_cops_and_thieves_amd import _learn_native as ln
+    from as_cops_and_thieves_amd.selfplay.mappo import compute_gae
+    gen = torch.Generator(device="cuda").manual_seed(T * 7 + N)
+    rew = torch.randn(G, T, N, generator=gen, device="cuda")
+    val = torch.randn(G, T, N, generator=gen, device="cuda")
+    dones = torch.rand(T, N, generator=gen, device="cuda") < 0.05
+    last = torch.randn(G, N, generator=gen, device="cuda")
+    want_adv, want_ret = compute_gae(rew, val, dones, last, 0.99, 0.95)
+    adv, ret = torch.empty_like(rew), torch.empty_like(rew)
+    ln.ppo_gae(rew, val, dones, last, 0.99, 0.95, adv, ret)
+    torch.cuda.synchronize()
+    scale = float(want_adv.abs().max())
+    assert float((adv - want_adv).abs().max()) <= 1e-5 * scale and float((ret - want_ret).abs().max()) <= 1e-5 * max(scale, float(want_ret.abs().max()))
