@@ -728,8 +728,7 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
     const unsigned d_empty = f64_to_f16(p.ray_length);  // np.full(R, ray_length, float16) entity.py:200
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int cpa = (R + kLanes - 1) / kLanes;   // chunks per agent
-    // row_words 1 / 2 / 4: count byte + ids in 8-byte words; 0: the 4-byte row of small maps, six 5-bit ids (31 = none)
-    const int rw = uni(p.row_words), row_cap = rw ? 8 * rw - 1 : 6;
+    const int rw = uni(p.row_words), row_cap = 8 * rw - 1;
     const int gate = launder(uni(p.gate)), n_cops = launder(uni(D::n_cops(p)));
     const double wall_r = launder(p.wall_r), rc = launder(p.rc);
     // the setup of agent_setup, back into registers (lane i / lane i*A+j), broadcast with readlane below
@@ -744,17 +743,12 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
         const int ck = kb + lane;
         const int cell = __builtin_amdgcn_readlane(my_cell, i);
         const size_t r = (cell < 0 || ck >= R) ? 0 : (size_t)cell * R + ck;
-        if (rw == 0) w0 = ((GAS const unsigned *)G(p.grid_rows))[gd.row_base + r];
-        else {
-            GAS const unsigned long long *ptr = G(p.grid_rows) + (gd.row_base + r) * rw;
-            w0 = ptr[0];
-            if (rw > 1) w1 = ptr[1];
-            if (rw > 2) { w2 = ptr[2]; w3 = ptr[3]; }
-        }
+        GAS const unsigned long long *ptr = G(p.grid_rows) + (gd.row_base + r) * rw;
+        w0 = ptr[0];
+        if (rw > 1) w1 = ptr[1];
+        if (rw > 2) { w2 = ptr[2]; w3 = ptr[3]; }
     }
-    auto row_id = [&](int q) -> int {   // the q-th candidate id of the row; q is wave-uniform
-        if (rw == 0) return (int)(((unsigned)w0 >> (5 * q)) & 31u);
-        const int b = q + 1;
+    auto row_byte = [&](int b) -> int {   // b is wave-uniform
         unsigned long long w = w0;
         if (b >= 8) w = b < 16 ? w1 : (b < 24 ? w2 : w3);
         return (int)((w >> (8 * (b & 7))) & 0xFF);
@@ -774,13 +768,7 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
         const double bx = ax + L.rayd[2 * kk], by = ay + L.rayd[2 * kk + 1];  // entity.py:191-193
         const double rdx = bx - ax, rdy = by - ay, rix = 1.0 / rdx, riy = 1.0 / rdy;
         // ---- candidates of this ray: walls from the spatial hash (ascending ids), then the other agents
-        int cnt_w;
-        if (rw == 0) {   // ids ascending, unused slots (and the two top bits) all ones: the list ends where the ones begin
-            const int ones = __builtin_clz(~((unsigned)w0 << 2) | 1u);      // leading ones of the 30 id bits (| 1: clz(0) is undefined)
-            cnt_w = 6 - ((ones * 13) >> 6);                                  // ones / 5 for ones <= 32, at most 6
-            if (cnt_w < 0) cnt_w = 0;
-        } else cnt_w = (int)(w0 & 0xFF);
-        if (!(active && cellid >= 0)) cnt_w = 0;
+        int cnt_w = (active && cellid >= 0) ? (int)(w0 & 0xFF) : 0;
         if (__ballot(cnt_w == 255) != 0ull) {   // saturated count byte (a map with >= 255 walls along one ray)
             if (cnt_w == 255) {
                 const size_t r0 = (size_t)cellid * R + k;
@@ -811,7 +799,7 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
                 double tbb = 0.0;
                 if (has) {
                     if (jj < cnt_w) {
-                        if (jj < row_cap) id = row_id(jj);
+                        if (jj < row_cap) id = row_byte(jj + 1);
                         else {   // more than 31 candidate walls on one ray: the rest of the list, from the CSR arrays
                             const size_t r0 = (size_t)cellid * R + k;
                             id = G(p.grid_ent)[gd.ent_base + G(p.grid_off)[gd.off_base + r0] + jj];
@@ -1875,7 +1863,7 @@ struct GridHost {
     std::vector<unsigned long long> rows;   // per (cell, ray): count | first ids (row_words 8-byte words), see finalize_rows
     std::vector<int> rows_of;               // rows per map
     std::vector<unsigned long long> crows;  // per cell: count | first 7 contact candidates
-    int max_row = 0, row_words = 1, max_walls = 0;
+    int max_row = 0, row_words = 1;
     std::vector<int> off, coff;
     std::vector<unsigned char> ent, cent;
 };
@@ -1932,7 +1920,6 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                 }
                 const int n = (int)g.ent.size() - d.ent_base - g.off.back();
                 if (n > g.max_row) g.max_row = n;
-                if (S > g.max_walls) g.max_walls = S;
             }
         }
     }
@@ -1954,30 +1941,8 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
 // Packed rows, one per (cell, ray): byte 0 = count (saturating at 255), then the first 8*row_words - 1
 // candidate ids; row_words (1, 2 or 4 eight-byte words) is the smallest that holds the longest list of
 // any map of the sim, lists beyond 31 ids continue in the CSR arrays (slow path on the device).
-// Small maps (at most 31 walls, at most 6 candidates on any ray -- labyrinth, squarinth, grandbyrinth): row_words = 0, a
-// 4-byte row of six 5-bit ids in ascending order, unused slots and the two top bits all ones; the rows are what the tick
-// kernel reads most of from HBM, and this halves them.  CAT_GRID_ROWS8=1 keeps the 8-byte rows.
 static void finalize_rows(GridHost &g)
 {
-    const char *keep8 = getenv("CAT_GRID_ROWS8");
-    if (g.max_walls <= 31 && g.max_row <= 6 && !(keep8 && atoi(keep8) == 1)) {
-        g.row_words = 0;
-        std::vector<unsigned> r32;
-        for (size_t m = 0; m < g.desc.size(); m++) {
-            GridDesc &d = g.desc[m];
-            d.row_base = (int)r32.size();
-            for (int r = 0; r < g.rows_of[m]; r++) {
-                const int o0 = g.off[d.off_base + r] + d.ent_base, n = g.off[d.off_base + r + 1] + d.ent_base - o0;
-                unsigned w = 0xFFFFFFFFu;
-                for (int q = 0; q < n; q++) w = (w & ~(31u << (5 * q))) | ((unsigned)g.ent[o0 + q] << (5 * q));
-                r32.push_back(w);
-            }
-        }
-        r32.push_back(0xFFFFFFFFu);                       // even count: the table is uploaded as 8-byte words
-        g.rows.assign((r32.size() + 1) / 2, ~0ull);
-        memcpy(g.rows.data(), r32.data(), r32.size() * sizeof(unsigned));
-        return;
-    }
     g.row_words = g.max_row <= 7 ? 1 : (g.max_row <= 15 ? 2 : 4);
     const int cap = 8 * g.row_words - 1;
     g.rows.clear();

@@ -289,17 +289,6 @@ def test_generic_kernel_on_the_rosters_that_have_a_fixed_instantiation(name, ray
     _run(cfg, [m], np.zeros(24, np.int32), ticks=45, rng=np.random.default_rng(9), auto_reset=True)
 
 
-@pytest.mark.parametrize("name,rays", [("labyrinth", 64), ("squarinth", 90)])
-def test_eight_byte_rows_on_the_maps_that_get_four_byte_rows(name, rays, monkeypatch):
-    """Maps with at most 31 walls and at most 6 candidates per ray carry their spatial-hash rows as 4 bytes (six 5-bit ids) --
-    what every other test of these maps exercises; CAT_GRID_ROWS8=1 keeps the one-word 8-byte rows (count byte + 7 ids), which a
-    larger map with short lists would get.  Both reproduce the oracle."""
-    from as_cops_and_thieves_amd.config import SimConfig
-    monkeypatch.setenv("CAT_GRID_ROWS8", "1")
-    cfg = SimConfig(n_envs=24, n_rays=rays, max_step_count=30, seed=29)
-    _run(cfg, [compiled(name)], np.zeros(24, np.int32), ticks=45, rng=np.random.default_rng(3), auto_reset=True)
-
-
 def test_one_cop_vs_one_thief_on_squarinth():
     """BASELINE configs[0]'s roster (the reference's plumbing case): A = 2, one agent pair, 90 rays, generic kernel."""
     from as_cops_and_thieves_amd.config import SimConfig

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel trace of the default bench command + PMC passes (one counter group per pass, with
-# --kernel-trace only), summarised into profiles/<tag>_*.  usage: tools/collect_profiles.sh r01
+# --kernel-trace only; 25 launches from the reset, as in round 1 -- no burn-in: the running batch reads a third more, DESIGN.md
+# section 4), summarised into profiles/<tag>_*.  usage: tools/collect_profiles.sh r01
 set -e
 tag=${1:-r01}
 out=gpurun_out/prof_$tag
@@ -14,7 +15,7 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST
          "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" \
          "GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc$i -o p -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc$i.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc$i -o p -- python3 bench.py --steps 20 --warmup 5 --burn-in 0 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc$i.err
 done
 mkdir -p profiles
 head -4 $out/trace/t_kernel_stats.csv > profiles/${tag}_final_kernel_stats.csv

@@ -24,7 +24,7 @@ out = {
     "hbm_bytes_per_launch": int(round((2 * val["FETCH_SIZE"] + val["WRITE_SIZE"]) * 1024)),
     "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of a "
                "coalesced stream); this kernel mixes 16-byte record loads with 8-byte table gathers, so the read side is an upper estimate",
-    "collected_with": f"tools/collect_profiles.sh {tag}: rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras",
+    "collected_with": f"tools/collect_profiles.sh {tag}: rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 20 --warmup 5 --burn-in 0 --no-cpu-baseline --no-extras (25 launches from the reset, as in round 1; the running batch after bench.py's burn-in reads a third more: DESIGN.md section 4)",
     "source": f"profiles/{tag}_final_pmc_summary.txt",
     "valu": {
         "valu_insts_per_wave": val["SQ_INSTS_VALU"] / waves, "salu_insts_per_wave": val["SQ_INSTS_SALU"] / waves,
