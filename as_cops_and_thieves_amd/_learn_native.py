@@ -151,7 +151,7 @@ def lib() -> C.CDLL:
         assert L.cat_trunk_abi_version() == 2
         L.cat_ppo_abi_version.restype = C.c_int
         L.cat_ppo_last_error.restype = C.c_char_p
-        for n in ("cat_ppo_loss_grad", "cat_ppo_adam_step"):
+        for n in ("cat_ppo_loss_grad", "cat_ppo_adam_step", "cat_ppo_gae_scan"):
             getattr(L, n).restype = C.c_int
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
         assert L.cat_ppo_abi_version() == 2

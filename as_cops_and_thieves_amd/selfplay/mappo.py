@@ -27,13 +27,14 @@ from __future__ import annotations
 
 import dataclasses
 import warnings
-from typing import Dict, List, Optional, Tuple
+from typing import Sequence, Dict, List, Optional, Tuple
 
 import torch
 
 from .. import packing
 from .. import _learn_native
-from .stacked import (FlatParams, StackedNet, agent_state_dict, init_from_modules, load_agent_state_dict,
+from .stacked import (FlatParams, StackedNet, adam_state_dict, agent_state_dict, init_from_modules, load_adam_state_dict,
+                      load_agent_state_dict,
                       role_param_shapes)
 
 
@@ -351,8 +352,22 @@ class RoleLearner:
         else:
             adv, ret = compute_gae(b["rew"], b["val"], dones, last_values, cfg.discount_factor, cfg.gae_lambda)
             b["ret"].copy_(ret)
-        mean = adv.mean(dim=(1, 2), keepdim=True)
-        std = adv.std(dim=(1, 2), keepdim=True)
+        if _dist_ready():   # data-parallel ranks: the statistics of the WHOLE batch, as one process holding every shard would use
+            import torch.distributed as dist
+            n_local = adv.shape[1] * adv.shape[2]
+            mom = torch.stack([adv.sum(dim=(1, 2), dtype=torch.float64), (adv.double() ** 2).sum(dim=(1, 2)),
+                               torch.full((adv.shape[0],), float(n_local), dtype=torch.float64, device=adv.device)])
+            if dist.get_backend() == "gloo" and mom.is_cuda:
+                host = mom.cpu(); dist.all_reduce(host); mom = host.to(adv.device)
+            else:
+                dist.all_reduce(mom)
+            n = mom[2]
+            mean64 = mom[0] / n
+            var64 = ((mom[1] - n * mean64 ** 2) / (n - 1)).clamp_min(0.0)                 # unbiased, as Tensor.std
+            mean, std = mean64.float().view(-1, 1, 1), var64.sqrt().float().view(-1, 1, 1)
+        else:
+            mean = adv.mean(dim=(1, 2), keepdim=True)
+            std = adv.std(dim=(1, 2), keepdim=True)
         b["adv"].copy_((adv - mean) / (std + 1e-8))                                     # skrl: per agent, whole memory
         if self.W == 1:
             self.start = starts
@@ -448,17 +463,22 @@ class MAPPOTrainer:
         return pin, vin
 
     # ------------------------------------------------------------------ rollout
-    def _rollout_ticks(self, random_actions: bool) -> None:
+    def _rollout_ticks(self, random_actions) -> None:
         """T ticks: networks -> actions -> env.step into the preallocated buffers.  In-place updates of persistent
-        tensors only and no host synchronisation: the whole loop is captured in one HIP graph and replayed."""
+        tensors only and no host synchronisation: the whole loop is captured in one HIP graph and replayed.
+        ``random_actions``: True / False for every learner, or the set of learner keys still in their ``random_timesteps``."""
         N, T = self.N, self.tcfg.horizon
-        all_fused = self._native_post and not random_actions and all(rl.native and rl.random_rows is None for rl in self.roles.values())
+        random_of = {key: (random_actions is True or (not isinstance(random_actions, bool) and key in random_actions))
+                     for key in self.roles}
+        any_random = any(random_of.values())
+        all_fused = self._native_post and not any_random and all(rl.native and rl.random_rows is None for rl in self.roles.values())
         defer = all_fused and self._native_io and self.tcfg.deferred_values
         for t in range(T):
             state = self.env.state()
             keep = self._keep32 if all_fused else (~self._starts).view(1, N)
             self._start_buf[t].copy_(self._starts)
-            for rl in self.roles.values():
+            for key, rl in self.roles.items():
+                random_actions = random_of[key]
                 if t % rl.bptt == 0:                # the recurrent state at the start of a BPTT window is kept
                     for dst, src in zip(rl.p0w + (() if defer else rl.v0w), rl.p_state + (() if defer else rl.v_state)):
                         dst[t // rl.bptt].copy_(src)
@@ -521,8 +541,9 @@ class MAPPOTrainer:
                     rl.buf["val"][:, k * L:(k + 1) * L].copy_(val[..., 0])
 
     @torch.no_grad()
-    def collect(self, random_actions: bool = False) -> None:
-        """One rollout of ``horizon`` ticks into the role buffers."""
+    def collect(self, random_actions=False) -> None:
+        """One rollout of ``horizon`` ticks into the role buffers (``random_actions``: see ``_rollout_ticks``)."""
+        random_actions = random_actions if isinstance(random_actions, bool) else (frozenset(random_actions) or False)
         use_graph = self.tcfg.graph_rollout and self.use_graphs and not random_actions
         if not use_graph:
             self._rollout_ticks(random_actions)
@@ -542,19 +563,20 @@ class MAPPOTrainer:
         self.timestep += self.tcfg.horizon
 
     # ------------------------------------------------------------------ update
-    def update(self) -> Dict[str, float]:
-        """PPO update of every role from the rollout just collected."""
+    def update(self, only: Optional[Sequence[str]] = None) -> Dict[str, float]:
+        """PPO update of every learner (or of the learner keys in ``only``) from the rollout just collected."""
         N = self.N
+        todo = {k: rl for k, rl in self.roles.items() if only is None or k in only}
         with torch.no_grad():
             state = self.env.state()
             keep = (~self._starts).view(1, N)
             last = {}
-            for role, rl in self.roles.items():
+            for role, rl in todo.items():
                 _, vin = self._inputs(rl, self._obs, state)
                 val, _ = rl.value.forward(vin.unsqueeze(1), tuple(s.clone() for s in rl.v_state), keep)
                 last[role] = val[:, 0, :, 0].float() * (~self._starts).float()
         use_graph = self.tcfg.graph_update and self.use_graphs
-        for role, rl in self.roles.items():
+        for role, rl in todo.items():
             rl.update(self._done_buf, self._start_buf, last[role], self._gen, use_graph)
         return {}
 
@@ -593,10 +615,13 @@ class MAPPOTrainer:
                 self.set_frozen(value=False)                     # "Unfreezing opponent agent" (README.md:104-108)
             if tc.policy_freeze_duration > 0 and t0 <= tc.policy_freeze_duration < t1:
                 self.set_frozen(policy=False)                    # "Unfreezing policy network" (:109-113)
-            random_phase = t0 < max(rl.cfg.random_timesteps for rl in self.roles.values())
-            self.collect(random_actions=random_phase)
-            if not random_phase and self.timestep >= max(rl.cfg.learning_starts for rl in self.roles.values()):
-                self.update()
+            # skrl keeps these two thresholds per agent (each agent's own cfg): a learner still inside its random_timesteps
+            # acts uniformly at random while another already samples its policy, and each starts updating on its own
+            in_random = frozenset(k for k, rl in self.roles.items() if t0 < rl.cfg.random_timesteps)
+            self.collect(random_actions=in_random)
+            ready = [k for k, rl in self.roles.items() if k not in in_random and self.timestep >= rl.cfg.learning_starts]
+            if ready:
+                self.update(only=None if len(ready) == len(self.roles) else ready)
         return self.read_stats()
 
     # ------------------------------------------------------------------ checkpoints
@@ -605,29 +630,40 @@ class MAPPOTrainer:
         rl, g = self.learner_of(agent)
         return agent_state_dict(rl.fp, g)
 
+    META_KEY = "__cat__"     # trainer position; not an agent name, so skrl's ``MAPPO.load`` (which walks possible_agents) skips it
+
     def state_dict(self) -> dict:
-        """The "full agent" (reference ``MAPPO.save``: every model and optimiser) plus the trainer position.  Everything
-        is stored per agent, so a checkpoint does not depend on how the agents were stacked."""
-        opt = {}
+        """The "full agent" in the layout skrl's ``MAPPO.save`` writes ([SKRL-RECALL] ``{agent: {"policy": state_dict,
+        "value": state_dict, "optimizer": Adam.state_dict()}}``; the reference saves it as ``joint_iter_N_full_agent.pt``,
+        agent_learning_utils.py:263) with the reference modules' parameter names, plus the trainer position under
+        ``__cat__``.  Everything is stored per agent, so a checkpoint does not depend on how the agents were stacked."""
+        out = {}
         for a in self.agents:
             rl, g = self.learner_of(a)
-            opt[a] = {"m": rl.m[g].clone(), "v": rl.v[g].clone(), "steps": rl.steps[g].clone()}
-        return {"format": "cat-mappo-2", "timestep": self.timestep, "num_rays": self.R,
-                "models": {a: self.agent_models(a) for a in self.agents}, "optimizers": opt}
+            out[a] = dict(self.agent_models(a), optimizer=adam_state_dict(rl.fp, g, rl.m, rl.v, rl.steps, rl.cfg.learning_rate,
+                                                                         (rl.BETA1, rl.BETA2), rl.EPS))
+        out[self.META_KEY] = {"format": "cat-mappo-3", "timestep": self.timestep, "num_rays": self.R}
+        return out
 
     def load_state_dict(self, sd: dict, roles: Optional[List[str]] = None, optimizer: bool = True) -> None:
         """``roles``: restrict to these roles' models (reference ``copy_role_models``, which copies policy and value
-        weights only: pass ``optimizer=False`` for that)."""
+        weights only: pass ``optimizer=False`` for that).  Accepts this class's checkpoints, a checkpoint written by the
+        reference (skrl layout, no ``__cat__``; preprocessor entries are ignored, the reference configures none) and
+        round-2 files (``{"format": "cat-mappo-2", "models": ..., "optimizers": ...}``)."""
+        if sd.get("format") == "cat-mappo-2":
+            sd = dict({a: dict(sd["models"][a], **({"optimizer": sd["optimizers"][a]} if a in sd.get("optimizers", {}) else {}))
+                       for a in sd["models"]}, **{self.META_KEY: {"timestep": sd.get("timestep", 0)}})
         for a in self.agents:
             if roles is not None and a.split("_")[0] not in roles:
                 continue
+            if a not in sd:
+                raise KeyError(f"checkpoint holds no agent {a!r} (it has {sorted(k for k in sd if k != self.META_KEY)})")
             rl, g = self.learner_of(a)
-            load_agent_state_dict(rl.fp, g, sd["models"][a])
-            if optimizer and a in sd.get("optimizers", {}):
-                o = sd["optimizers"][a]
-                rl.m[g].copy_(o["m"]); rl.v[g].copy_(o["v"]); rl.steps[g].copy_(o["steps"])
+            load_agent_state_dict(rl.fp, g, sd[a])
+            if optimizer and "optimizer" in sd[a]:
+                load_adam_state_dict(rl.fp, g, rl.m, rl.v, rl.steps, sd[a]["optimizer"])
         if optimizer and roles is None:
-            self.timestep = int(sd.get("timestep", 0))
+            self.timestep = int(sd.get(self.META_KEY, {}).get("timestep", 0))
 
     def reset_optimizers(self) -> None:
         """A fresh Adam, as every self-play iteration of the reference constructs a new ``MAPPO`` (orchestration.py:135-144)."""

@@ -10,6 +10,10 @@ and ``cnn_channel_length = 90``).  Inputs use the sorted-key c
 ``packing.py``.  The recurrent state is carried across the rollout and reset where an episode ends
 (the reference, through skrl, re-starts from a zero state on every call during rollout — SURVEY §5
 "long-context"; this is the intended behaviour of the same architecture).
+
+Attribute names are the reference's (``features_extractor``, ``lstm``, ``policy_head`` / ``value_head``;
+non-recurrent pair: ``features_extractor`` + ``net``, ``policy_net.py:17-33``, ``value_net.py:18-28``), so
+``state_dict()`` keys here and in the reference's modules are the same strings and checkpoints move both ways.
 """
 from __future__ import annotations
 
@@ -37,11 +41,13 @@ def conv1d_as_gemm(x: torch.Tensor, conv: nn.Conv1d) -> torch.Tensor:
     return out.reshape(B, L, conv.out_channels).transpose(1, 2)      # [B, out, L_out]
 
 
-class _Trunk(nn.Module):
+class _Recurrent(nn.Module):
+    """Conv trunk + LSTM shared by the recurrent policy and value networks; the head is the subclass's."""
+
     def __init__(self, channels: int, num_rays: int, hidden: int, layers: int):
         super().__init__()
         self.channels, self.num_rays = channels, num_rays
-        self.features = nn.Sequential(
+        self.features_extractor = nn.Sequential(
             nn.Conv1d(channels, 64, kernel_size=5, stride=2), nn.ReLU(),
             nn.Conv1d(64, 32, kernel_size=5, stride=3), nn.ReLU(),
             nn.Flatten(), nn.Linear(32 * conv_out_len(num_rays), 256), nn.Tanh())
@@ -52,7 +58,7 @@ class _Trunk(nn.Module):
         z = torch.zeros(self.layers, batch, self.hidden, device=device, dtype=dtype)
         return z, z.clone()
 
-    def forward(self, x: torch.Tensor, state, starts: Optional[torch.Tensor] = None):
+    def recur(self, x: torch.Tensor, state, starts: Optional[torch.Tensor] = None):
         """x: [B, T, channels*R]; state: (h, c) each [layers, B, hidden]; starts: [B, T] bool, True where
         a new episode begins at that step (state is zeroed before consuming it).
 
@@ -61,10 +67,11 @@ class _Trunk(nn.Module):
         a multiplication by a mask -- no host synchronisation, no per-step library RNN call, and the same
         launch sequence every time (so a rollout can be captured in a HIP graph)."""
         B, T, _ = x.shape
+        fe = self.features_extractor
         z = x.reshape(B * T, self.channels, self.num_rays)
-        z = torch.relu(conv1d_as_gemm(z, self.features[0]))
-        z = torch.relu(conv1d_as_gemm(z, self.features[2]))
-        f = torch.tanh(self.features[5](z.flatten(1))).reshape(B, T, 256)      # == self.features(...)
+        z = torch.relu(conv1d_as_gemm(z, fe[0]))
+        z = torch.relu(conv1d_as_gemm(z, fe[2]))
+        f = torch.tanh(fe[5](z.flatten(1))).reshape(B, T, 256)      # == self.features_extractor(...)
         h, c = state
         keep = None if starts is None else (~starts).unsqueeze(-1)                     # [B, T, 1]
         hs, cs = list(h.unbind(0)), list(c.unbind(0))
@@ -86,31 +93,27 @@ class _Trunk(nn.Module):
         return inp, (torch.stack(hs, 0), torch.stack(cs, 0))
 
 
-class LSTMPolicy(nn.Module):
+class LSTMPolicy(_Recurrent):
+    """``src/models/lstm_policy_net.py:28-53``."""
+
     def __init__(self, num_rays: int, num_actions: int = 4, hidden: int = 128):
-        super().__init__()
-        self.trunk = _Trunk(2, num_rays, hidden, layers=1)
-        self.head = nn.Sequential(nn.Linear(hidden, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
-                                  nn.Linear(64, num_actions))
-
-    def initial_state(self, batch, device, dtype=torch.float32):
-        return self.trunk.initial_state(batch, device, dtype)
+        super().__init__(2, num_rays, hidden, layers=1)
+        self.policy_head = nn.Sequential(nn.Linear(hidden, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
+                                         nn.Linear(64, num_actions))
 
     def forward(self, x, state, starts=None):
-        out, state = self.trunk(x, state, starts)
-        return self.head(out), state            # logits [B, T, 4]
+        out, state = self.recur(x, state, starts)
+        return self.policy_head(out), state            # logits [B, T, 4]
 
 
-class LSTMValue(nn.Module):
+class LSTMValue(_Recurrent):
+    """``src/models/lstm_value_net.py:46-75``."""
+
     def __init__(self, num_rays: int, hidden: int = 128):
-        super().__init__()
-        self.trunk = _Trunk(4, num_rays, hidden, layers=2)
-        self.head = nn.Sequential(nn.Linear(hidden, 256), nn.ReLU(), nn.Linear(256, 128), nn.ReLU(),
-                                  nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 1))
-
-    def initial_state(self, batch, device, dtype=torch.float32):
-        return self.trunk.initial_state(batch, device, dtype)
+        super().__init__(4, num_rays, hidden, layers=2)
+        self.value_head = nn.Sequential(nn.Linear(hidden, 256), nn.ReLU(), nn.Linear(256, 128), nn.ReLU(),
+                                        nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 1))
 
     def forward(self, x, state, starts=None):
-        out, state = self.trunk(x, state, starts)
-        return self.head(out).squeeze(-1), state   # values [B, T]
+        out, state = self.recur(x, state, starts)
+        return self.value_head(out).squeeze(-1), state   # values [B, T]

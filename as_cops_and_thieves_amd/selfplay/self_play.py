@@ -154,7 +154,7 @@ def evaluate_agent(eval_env, evaluator: MAPPOTrainer, learned: MAPPOTrainer, lea
             break
         name = Path(path).name
         seen.add(name)
-        evaluator.load_state_dict(torch.load(path, map_location=evaluator.device, weights_only=False), roles=[opponent_role],
+        evaluator.load_state_dict(torch.load(path, map_location=evaluator.device, weights_only=True), roles=[opponent_role],
                                   optimizer=False)                       # copy_role_models: policy + value weights
         cop_rate, thief_rate = evaluate_agents(eval_env, evaluator, tc.n_trial_episodes)
         opponent_won = (thief_rate > cop_rate) if learned_role == tc.cop_role_prefix else (cop_rate > thief_rate)
@@ -201,7 +201,7 @@ def run_self_play(map_name: str, num_envs: int, out_dir: Path, iterations: Optio
         for role in arch:
             ck = archive.sample_policy_from_archive(arch[role], role, "latest")
             if ck:
-                trainer.load_state_dict(torch.load(ck, map_location=trainer.device, weights_only=False), roles=[role], optimizer=False)
+                trainer.load_state_dict(torch.load(ck, map_location=trainer.device, weights_only=True), roles=[role], optimizer=False)
         trainer.reset_optimizers()
         trainer.reset_episodes()
         # ---- 2. simultaneous training (agent_learning_utils.py:172-197)

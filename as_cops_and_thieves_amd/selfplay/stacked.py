@@ -225,18 +225,18 @@ class FlatParams:
 def _net_shapes(kind: str, R: int) -> Dict[str, Tuple[int, ...]]:
     C, layers = (2, 1) if kind == "policy" else (4, 2)
     L2 = conv_out_len(R)
-    s = {"trunk.features.0.weight": (64, C, 5), "trunk.features.0.bias": (64,),
-         "trunk.features.2.weight": (32, 64, 5), "trunk.features.2.bias": (32,),
-         "trunk.features.5.weight": (256, 32 * L2), "trunk.features.5.bias": (256,)}
+    s = {"features_extractor.0.weight": (64, C, 5), "features_extractor.0.bias": (64,),
+         "features_extractor.2.weight": (32, 64, 5), "features_extractor.2.bias": (32,),
+         "features_extractor.5.weight": (256, 32 * L2), "features_extractor.5.bias": (256,)}
     for l in range(layers):
-        s[f"trunk.lstm.weight_ih_l{l}"] = (4 * HIDDEN, 256 if l == 0 else HIDDEN)
-        s[f"trunk.lstm.weight_hh_l{l}"] = (4 * HIDDEN, HIDDEN)
-        s[f"trunk.lstm.bias_ih_l{l}"] = (4 * HIDDEN,)
-        s[f"trunk.lstm.bias_hh_l{l}"] = (4 * HIDDEN,)
+        s[f"lstm.weight_ih_l{l}"] = (4 * HIDDEN, 256 if l == 0 else HIDDEN)
+        s[f"lstm.weight_hh_l{l}"] = (4 * HIDDEN, HIDDEN)
+        s[f"lstm.bias_ih_l{l}"] = (4 * HIDDEN,)
+        s[f"lstm.bias_hh_l{l}"] = (4 * HIDDEN,)
     dims = [HIDDEN, 128, 64, 4] if kind == "policy" else [HIDDEN, 256, 128, 64, 1]
     for j in range(len(dims) - 1):
-        s[f"head.{2 * j}.weight"] = (dims[j + 1], dims[j])
-        s[f"head.{2 * j}.bias"] = (dims[j + 1],)
+        s[f"{kind}_head.{2 * j}.weight"] = (dims[j + 1], dims[j])
+        s[f"{kind}_head.{2 * j}.bias"] = (dims[j + 1],)
     return s
 
 
@@ -473,13 +473,13 @@ class StackedNet:
             x, select = x.index_select(2, select), None
         z = x.reshape(G, T * x.shape[2], self.C * self.R).to(dt)                                 # (channel, ray) order
         if fused:
-            z = _ConvTrunk.apply(z, self.w("trunk.features.0.weight"), self.w("trunk.features.0.bias"),
-                                 self.w("trunk.features.2.weight"), self.w("trunk.features.2.bias"), self.R, select, B_all)
+            z = _ConvTrunk.apply(z, self.w("features_extractor.0.weight"), self.w("features_extractor.0.bias"),
+                                 self.w("features_extractor.2.weight"), self.w("features_extractor.2.bias"), self.R, select, B_all)
         else:   # fp32 / CPU, or a ray count whose intermediate does not fit the LDS (R = 90): dense GEMMs
             z = torch.nn.functional.pad(z, (0, self.in1 - self.C * self.R))
             layers = []
-            for name, (idx, back, b_idx, b_back, l_out, rows), width in (("trunk.features.0", self.t1, self.in1),
-                                                                         ("trunk.features.2", self.t2, self.t1[5])):
+            for name, (idx, back, b_idx, b_back, l_out, rows), width in (("features_extractor.0", self.t1, self.in1),
+                                                                         ("features_extractor.2", self.t2, self.t1[5])):
                 layers.append((_Expand.apply(self.w(name + ".weight").reshape(G, -1), idx, back).view(G, rows, width),
                                _Expand.apply(self.w(name + ".bias"), b_idx, b_back)))
             # in row chunks of DENSE_ROWS: the shapes of a rollout tick, which the BLAS library handles (see __init__)
@@ -490,17 +490,17 @@ class StackedNet:
                     zc = torch.relu(_lin(zc, w, b))                                              # [G, rows, l_out * c_out (+ zeros)], (l, c)
                 outs.append(zc)
             z = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
-        wfc = self.w("trunk.features.5.weight").view(G, 256, 32, self.L2).transpose(2, 3).reshape(G, 256, self.L2 * 32)
+        wfc = self.w("features_extractor.5.weight").view(G, 256, 32, self.L2).transpose(2, 3).reshape(G, 256, self.L2 * 32)
         if z.shape[2] != self.L2 * 32:                                                           # the dense path's zero padding
             wfc = torch.nn.functional.pad(wfc, (0, z.shape[2] - self.L2 * 32))
-        f = _lin_act(z, wfc, self.w("trunk.features.5.bias"), 2)                                 # [G, T*B, 256], tanh
+        f = _lin_act(z, wfc, self.w("features_extractor.5.bias"), 2)                                 # [G, T*B, 256], tanh
         h0, c0 = state
         kp = None if keep is None else keep.to(torch.float32).contiguous()
         native = f.is_cuda and dt == torch.bfloat16
         inp = f
         hs, cs = [], []
         for l in range(self.layers):
-            w_ih, b_ih, b_hh = (self.w(f"trunk.lstm.{n}_l{l}") for n in ("weight_ih", "bias_ih", "bias_hh"))
+            w_ih, b_ih, b_hh = (self.w(f"lstm.{n}_l{l}") for n in ("weight_ih", "bias_ih", "bias_hh"))
             shared = None
             if native:   # the recurrence kernel adds the biases and returns their gradient: the projection is a bare GEMM
                 shared = _SharedWgrad() if torch.is_grad_enabled() else None
@@ -508,13 +508,13 @@ class StackedNet:
             else:
                 xp, b_ih, b_hh = _lin(inp, w_ih, b_ih + b_hh).view(G, T, B, 4 * HIDDEN), None, None
             in_place = update_state and native and not torch.is_grad_enabled() and h0.dtype == dt
-            out, hT, cT = _LSTMSeq.apply(xp, self.w(f"trunk.lstm.weight_hh_l{l}"), b_ih, b_hh, h0[l].to(dt), c0[l].to(dt), kp,
+            out, hT, cT = _LSTMSeq.apply(xp, self.w(f"lstm.weight_hh_l{l}"), b_ih, b_hh, h0[l].to(dt), c0[l].to(dt), kp,
                                          (h0[l], c0[l]) if in_place else None, torch.is_grad_enabled(), shared)
             hs.append(hT); cs.append(cT)
             inp = out.reshape(G, N, HIDDEN)
         y = inp
         for j in range(self.n_head):
-            y = _lin_act(y, self.w(f"head.{2 * j}.weight"), self.w(f"head.{2 * j}.bias"), 1 if j < self.n_head - 1 else 0)
+            y = _lin_act(y, self.w(f"{self.kind}_head.{2 * j}.weight"), self.w(f"{self.kind}_head.{2 * j}.bias"), 1 if j < self.n_head - 1 else 0)
         if update_state and native and not torch.is_grad_enabled() and h0.dtype == dt:
             return y.view(G, T, B, -1), state
         return y.view(G, T, B, -1), (torch.stack(hs, 0), torch.stack(cs, 0))
@@ -540,9 +540,24 @@ def init_from_modules(fp: FlatParams, R: int, seeds: Sequence[int]) -> None:
     fp.refresh()
 
 
+_OLD_NAMES = (("trunk.features.", "features_extractor."), ("trunk.lstm.", "lstm."))   # "cat-mappo-2" checkpoints (round 2)
+
+
+def _reference_key(kind: str, name: str) -> str:
+    """A round-2 checkpoint's key -> the reference modules' key (identity for keys that already are)."""
+    for old, new in _OLD_NAMES:
+        if name.startswith(old):
+            return new + name[len(old):]
+    if name.startswith("head."):
+        return f"{kind}_head." + name[len("head."):]
+    return name
+
+
 @torch.no_grad()
 def agent_state_dict(fp: FlatParams, g: int) -> Dict[str, Dict[str, torch.Tensor]]:
-    """{"policy": state_dict, "value": state_dict} of agent g, loadable by models.LSTMPolicy / LSTMValue."""
+    """{"policy": state_dict, "value": state_dict} of agent g with the REFERENCE modules' keys
+    (``features_extractor.N.*``, ``lstm.*``, ``policy_head.N.*`` / ``value_head.N.*``: lstm_policy_net.py:28-53,
+    lstm_value_net.py:46-75), loadable by them and by models.LSTMPolicy / LSTMValue alike."""
     out = {"policy": {}, "value": {}}
     for n in fp.names:
         kind, name = n.split(".", 1)
@@ -552,7 +567,51 @@ def agent_state_dict(fp: FlatParams, g: int) -> Dict[str, Dict[str, torch.Tensor
 
 @torch.no_grad()
 def load_agent_state_dict(fp: FlatParams, g: int, sd: Dict[str, Dict[str, torch.Tensor]], kinds=("policy", "value")) -> None:
+    """Inverse of ``agent_state_dict``; also takes state dicts saved by the reference's own modules (same keys; a
+    ``torch.compile`` wrapper's ``_orig_mod.`` prefix is dropped) and round-2 checkpoints (old key names)."""
     for kind in kinds:
+        seen = set()
         for name, v in sd[kind].items():
-            fp.master_view(f"{kind}.{name}")[g].copy_(v.to(fp.master.device, torch.float32))
+            name = _reference_key(kind, name[len("_orig_mod."):] if name.startswith("_orig_mod.") else name)
+            dst = fp.master_view(f"{kind}.{name}")[g]
+            if tuple(v.shape) != tuple(dst.shape):
+                raise ValueError(f"{kind}.{name}: checkpoint shape {tuple(v.shape)} != {tuple(dst.shape)} "
+                                 f"(a different ray count? the reference's modules are built for 90 rays)")
+            dst.copy_(v.to(fp.master.device, torch.float32))
+            seen.add(f"{kind}.{name}")
+        missing = [n for n in fp.names if n.startswith(kind + ".") and n not in seen]
+        if missing:
+            raise KeyError(f"checkpoint lacks {missing[:3]}{'...' if len(missing) > 3 else ''}")
     fp.refresh()
+
+
+@torch.no_grad()
+def adam_state_dict(fp: FlatParams, g: int, m: torch.Tensor, v: torch.Tensor, steps: torch.Tensor, lr: float,
+                    betas=(0.9, 0.999), eps: float = 1e-8) -> dict:
+    """Agent g's Adam state in ``torch.optim.Adam.state_dict()`` form over ``chain(policy.parameters(), value.parameters())``
+    -- the optimiser skrl's MAPPO builds per agent and writes under "optimizer" -- so the reference can resume from it.
+    Parameter order = registration order of the modules = ``fp.names``."""
+    state = {}
+    for i, n in enumerate(fp.names):
+        o, k, shp = fp.offsets[n]
+        state[i] = {"step": steps[g, o:o + k].max().to(torch.float32).cpu() if k else torch.tensor(0.0),
+                    "exp_avg": m[g, o:o + k].view(*shp).clone(), "exp_avg_sq": v[g, o:o + k].view(*shp).clone()}
+    group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+             "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+             "params": list(range(len(fp.names)))}
+    return {"state": state, "param_groups": [group]}
+
+
+@torch.no_grad()
+def load_adam_state_dict(fp: FlatParams, g: int, m: torch.Tensor, v: torch.Tensor, steps: torch.Tensor, sd: dict) -> None:
+    if "state" not in sd:                      # round-2 layout: flat rows
+        m[g].copy_(sd["m"]); v[g].copy_(sd["v"]); steps[g].copy_(sd["steps"])
+        return
+    m[g].zero_(); v[g].zero_(); steps[g].zero_()
+    for i, n in enumerate(fp.names):
+        st = sd["state"].get(i)
+        if st is None:                         # a parameter that never received a gradient has no entry in torch's Adam
+            continue
+        o, k, _ = fp.offsets[n]
+        m[g, o:o + k].copy_(st["exp_avg"].reshape(-1)); v[g, o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+        steps[g, o:o + k].fill_(float(st["step"]))

@@ -31,6 +31,23 @@ def algorithmic_bytes_per_env_step(A: int, R: int) -> int:
     return 108 * A + 3 * A * R + 6 * R + 8
 
 
+def host_cpu_share() -> int:
+    """Threads for the all-cores leg: the smallest of the scheduler affinity, the cgroup CPU quota (cpu.max) and 16 -- a GPU
+    box exposes all 256 host threads to every tenant but gives one GPU's job a 16-core share (256 threads on 256 envs
+    measured 1 k env-steps/s against 0.47 M with 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(cfg, cmap, budget_s: float = 12.0):
     """Times the CPU oracle (a port, not Pymunk: pymunk is not installable here) on this host:
     single thread (the like-for-like of the reference's single process), then all cores."""
@@ -40,11 +57,7 @@ def cpu_baseline(cfg, cmap, budget_s: float = 12.0):
     n = 256
     c = replace(cfg, n_envs=n)
     res = {}
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
-    ncores = max(1, min(ncores, 16))  # the GPU box's CPU share for one GPU is 16
+    ncores = host_cpu_share()
     for label, threads in (("1core", 1), ("allcores", ncores)):
         cat_oracle.lib().cato_set_threads(threads)
         sim = cat_oracle.OracleSim(c, [cmap])
@@ -66,7 +79,10 @@ def cpu_baseline(cfg, cmap, budget_s: float = 12.0):
             "allcores": {"value": va, "cores": ca}}
 
 
-EVENT_EVERY = 8   # every 8th tick_kernel launch of the timed region is timed with HIP events
+def event_stride(steps: int) -> int:
+    """Which tick_kernel launches of the timed region carry HIP events: every 8th on a long run (each pair costs a
+    little host time), every 2nd when K <= 40 so that the driver's --steps 20 still times 10 launches."""
+    return 2 if steps <= 40 else 8
 
 
 class HipEvents:
@@ -130,13 +146,13 @@ def build_sim(map_name: str, cops: int, thieves: int, envs: int, rays: int, rank
 
 def timed_steps(sim, steps: int, warmup: int, fence, hip: "HipEvents", first_tick: int = 0):
     """W untimed + K timed rollout steps (cat_step_fused: in-kernel Philox actions + tick + auto-reset, ONE launch per
-    step).  Every EVENT_EVERY-th tick_kernel launch of the timed region carries a pair of HIP events attached to the
+    step).  Every event_stride(K)-th tick_kernel launch of the timed region carries a pair of HIP events attached to the
     dispatch itself (hipExtLaunchKernelGGL start/stop events, on the stream the kernel is launched on), so kernel_ms is
     the kernel's own duration, as in a rocprofv3 kernel trace; events recorded AROUND the call would add the
     inter-kernel dispatch gap (~5 us here).  Returns (seconds of the timed region on this rank, mean kernel ms, launches timed)."""
     for t in range(warmup):
         sim.step_fused(None, tick=first_tick + t, auto_reset=True)
-    ev = {k: (hip.create(), hip.create()) for k in range(0, steps, EVENT_EVERY)}
+    ev = {k: (hip.create(), hip.create()) for k in range(0, steps, event_stride(steps))}
     fence()
     t0 = time.perf_counter()
     for k in range(steps):
@@ -178,6 +194,24 @@ def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16)
         return {"value": None, "error": repr(exc)[:200]}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` typed as a plain command: this process has not touched the GPU (torch is not even imported
+    yet) and starts N fresh rank processes, one per GPU, through torch.distributed.run as a CHILD process (never an exec);
+    rank 0's JSON line goes straight to the inherited stdout.  Returns the launcher's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +229,10 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE shapes (the `extra` object)")
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and (world_env is None or (world_env == "1" and "RANK" not in os.environ)):
+        sys.exit(launch_ranks(args.gpus))          # plain `python bench.py --gpus N`: start the N ranks ourselves
+
     import torch
     from as_cops_and_thieves_amd.sharding import max_over_ranks
 
@@ -202,11 +240,12 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        sys.exit(f"bench.py --gpus {args.gpus} needs {args.gpus} ranks: launch with python -m torch.distributed.run "
-                 f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ... "
-                 f"(WORLD_SIZE is {world})")
+        sys.exit(f"bench.py --gpus {args.gpus} was started inside a {world}-rank group (WORLD_SIZE={world}): the rank count "
+                 f"must equal --gpus; run plain `python bench.py --gpus {args.gpus}` (it starts its own ranks) or "
+                 f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}")
     rehearse = os.environ.get("CAT_BENCH_REHEARSE") == "1"   # flow check on a 1-GPU box: gloo, ranks share the GPU
     timing_backend = None
+    rccl_ranks = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -219,10 +258,13 @@ def main() -> None:
             torch.cuda.set_device(local_rank)
             try:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
-                probe = torch.zeros(1, device=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
                 dist.all_reduce(probe)                                                        # fails here if RCCL cannot start
                 torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"RCCL all-reduce of ones over {world} ranks returned {probe.item()}")
                 timing_backend = "nccl (RCCL)"
+                rccl_ranks = dist.get_world_size()    # what the RCCL group itself reports (and the sum above confirmed)
             except Exception as exc:   # the simulator needs no collective: only the timing barrier / MAX does
                 print(f"[bench] RCCL unavailable ({exc!r}); timing reductions over gloo", file=sys.stderr, flush=True)
                 if dist.is_initialized():
@@ -265,19 +307,25 @@ def main() -> None:
         c1.record(); torch.cuda.synchronize(dev)
         copy_gbs = 10 * 2 * a.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del a, b
+    def measure_extra(w: dict) -> dict:
+        """One of the other BASELINE shapes, on every rank of the job (its own env shard), same fence + MAX-over-ranks rule."""
+        s2, c2, m2 = build_sim(w["map"], w["cops"], w["thieves"], w["envs"], w.get("rays", args.rays), rank, dev)
+        s2.reset()
+        k_steps = 300                                   # own step counts: the driver's --steps 20 --warmup 5 would only
+        e2, k2, _ = timed_steps(s2, k_steps, 100, fence, hip)   # see the first ticks after the reset
+        e2 = max_over_ranks(e2, device=None if rehearse else dev)
+        bytes2 = algorithmic_bytes_per_env_step(c2.n_agents, c2.n_rays) * c2.n_envs
+        s2.close()
+        return {"value": world * c2.n_envs * k_steps / e2, "unit": "env-steps/s", "steps": k_steps,
+                "ms_per_step": 1e3 * e2 / k_steps, "kernel_ms": k2, "envs_per_gpu": c2.n_envs,
+                "roofline_frac": bytes2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
     extra = None
+    if world > 1 and not args.no_extras:    # BASELINE configs[2]: agh-map, 32768 envs over 8 GPUs = 4096 per GPU, all ranks
+        label, w = EXTRA_WORKLOADS[0]
+        extra = {f"agh-map 2v1 x4096 per GPU (configs[2]), {world} GPUs": measure_extra(w)}
     if rank == 0 and world == 1 and not args.no_extras:   # the other BASELINE shapes, same process, same box
-        extra = {}
-        for label, w in EXTRA_WORKLOADS:
-            s2, c2, m2 = build_sim(w["map"], w["cops"], w["thieves"], w["envs"], w.get("rays", args.rays), 0, dev)
-            s2.reset()
-            k_steps = 300                                   # own step counts: the driver's --steps 20 --warmup 5 would only
-            e2, k2, _ = timed_steps(s2, k_steps, 100, fence, hip)   # see the first ticks after the reset
-            bytes2 = algorithmic_bytes_per_env_step(c2.n_agents, c2.n_rays) * c2.n_envs
-            extra[label] = {"value": c2.n_envs * k_steps / e2, "unit": "env-steps/s", "steps": k_steps,
-                            "ms_per_step": 1e3 * e2 / k_steps, "kernel_ms": k2,
-                            "roofline_frac": bytes2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            s2.close()
+        extra = {label: measure_extra(w) for label, w in EXTRA_WORKLOADS}
         extra["learner_collect_plus_update"] = learner_throughput(args.map, cfg.n_envs, args.rays)
         extra["learner_collect_plus_update, 90 rays"] = learner_throughput(args.map, cfg.n_envs, 90)
         # 128-tick rollouts (8 BPTT windows per env and update): the setting with which the cops learn to catch random
@@ -289,12 +337,17 @@ def main() -> None:
         achieved = bytes_launch / (tick_ms * 1e-3) / 1e9
         # HBM bytes per launch / VALU figures: NOT measured in this run (PMC counters need rocprofv3 passes of their own);
         # replayed from the committed PMC summary of this exact workload and labelled as such
-        traffic = valu = traffic_source = None
-        for tfile in sorted((ROOT / "profiles").glob("r*_traffic.json"), reverse=True):
-            if (args.map, cfg.n_envs, R, args.cops, args.thieves) == ("labyrinth", 4096, 64, 2, 1):
-                prof = json.loads(tfile.read_text())
-                traffic, valu = prof["hbm_bytes_per_launch"], prof.get("valu")
-                traffic_source = f"profiles/{tfile.name} (committed rocprofv3 --pmc passes of this command; replayed, not measured in this run)"
+        traffic = valu = traffic_source = traffic_regime = traffic_from_reset = None
+        wl = {"map": args.map, "envs": cfg.n_envs, "rays": R, "cops": args.cops, "thieves": args.thieves}
+        for tfile in sorted((ROOT / "profiles").glob("r*_traffic.json"), reverse=True):   # newest round whose workload matches
+            prof = json.loads(tfile.read_text())
+            if prof.get("workload_key", {"map": "labyrinth", "envs": 4096, "rays": 64, "cops": 2, "thieves": 1}) != wl:
+                continue
+            traffic, valu = prof["hbm_bytes_per_launch"], prof.get("valu")
+            traffic_regime = prof.get("regime", "from reset (--burn-in 0: 25 launches straight after the reset)")
+            traffic_from_reset = prof.get("hbm_bytes_per_launch_from_reset")
+            traffic_source = (f"profiles/{tfile.name} (committed rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 5 "
+                              f"--burn-in {prof.get('burn_in', 0)}`; replayed, not measured in this run)")
             break
         line = {
             "metric": "env-steps/sec (whole node) at 4096 parallel envs, 2v1 agents, 64-ray sensors",
@@ -311,7 +364,8 @@ def main() -> None:
                        "parallelism": f"env-sharded x{world}, no data-path collective",
                        "episodes_reset_per_gpu": episodes, "burn_in_steps": args.burn_in, "env_id_offsets": offsets},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_regime": traffic_regime,
+                         "traffic_from_reset": traffic_from_reset, "traffic_source": traffic_source,
                          "kernel": "tick_kernel", "kernel_ms": tick_ms, "kernel_launches_timed": n_timed,
                          "algorithmic_bytes_per_launch": bytes_launch, "valu": valu, "valu_source": traffic_source,
                          "hbm_stream_copy_GBs": copy_gbs,
@@ -320,6 +374,7 @@ def main() -> None:
         }
         if timing_backend:
             line["config"]["timing_reductions"] = timing_backend
+            line["config"]["rccl_ranks"] = rccl_ranks     # what the RCCL group reported; null = the timing went over gloo
         if extra is not None:
             line["extra"] = extra
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only

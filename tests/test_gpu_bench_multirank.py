@@ -33,13 +33,33 @@ def test_two_rank_bench_prints_one_aggregate_line():
     assert d["n_gpus"] == 2 and d["steps"] == steps and d["scaling"] == "weak"
     assert d["config"]["env_id_offsets"] == [0, envs]               # disjoint contiguous shards of the global env ids
     assert "gloo" in d["config"]["timing_reductions"]
-    assert "cpu_baseline" not in d and "extra" not in d             # N = 1 only
+    assert "cpu_baseline" not in d                                  # N = 1 only
+    (label, agh), = d["extra"].items()                              # configs[2]'s per-GPU shard, measured on every rank
+    assert label.startswith("agh-map 2v1 x4096 per GPU") and agh["value"] > 1e6 and agh["envs_per_gpu"] == 4096
     # whole-job aggregate: both ranks' env-steps over the slowest rank's time
     assert d["value"] == pytest.approx(2 * envs * steps / (d["ms_per_step"] * 1e-3 * steps), rel=1e-9)
     assert d["roofline"]["kernel_ms"] > 0 and d["value"] > 1e6
 
 
-def test_bench_refuses_a_rank_count_mismatch():
+def test_plain_command_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` typed as a plain command (no launcher, no WORLD_SIZE): the parent starts two fresh rank
+    processes itself before anything touches the GPU and relays rank 0's single line -- the form the driver's SCALE runs may use."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CAT_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    envs, steps = 1024, 60
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "10",
+                          "--envs", str(envs), "--no-extras"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == steps
+    assert d["config"]["env_id_offsets"] == [0, envs]
+    assert d["config"]["rccl_ranks"] is None and "gloo" in d["config"]["timing_reductions"]   # rehearsal: no RCCL claim
+    assert d["roofline"]["kernel_launches_timed"] == steps // 8 + (1 if steps % 8 else 0)
+
+
+def test_a_rank_count_that_contradicts_the_launcher_is_refused():
     res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
-                         env=dict(os.environ, WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
-    assert res.returncode != 0 and "needs 2 ranks" in (res.stderr + res.stdout)
+                         env=dict(os.environ, WORLD_SIZE="4", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "rank count must equal --gpus" in (res.stderr + res.stdout)

@@ -193,9 +193,10 @@ def test_self_play_protocol_on_baseline_config_3(tmp_path):
     assert [h["iteration"] for h in res["iterations"]] == [3]
     assert sorted(p.name for p in (tmp_path / "cops").glob("cop_iter_*.pt")) == [f"cop_iter_{i}.pt" for i in range(4)]
     assert sorted(p.name for p in (tmp_path / "thieves").glob("thief_iter_*.pt")) == [f"thief_iter_{i}.pt" for i in range(4)]
-    sd = torch.load(tmp_path / "joint_iter_3_full_agent.pt", weights_only=False)
-    assert set(sd["models"]) == {"cop_0", "cop_1", "cop_2", "thief_0", "thief_1"} and set(sd["optimizers"]) == set(sd["models"])
-    assert float(sd["optimizers"]["cop_0"]["steps"].max()) > 0
+    sd = torch.load(tmp_path / "joint_iter_3_full_agent.pt", weights_only=True)
+    assert set(sd) == {"cop_0", "cop_1", "cop_2", "thief_0", "thief_1", "__cat__"}
+    assert all(set(sd[a]) == {"policy", "value", "optimizer"} for a in sd if a != "__cat__")
+    assert max(float(st["step"]) for st in sd["cop_0"]["optimizer"]["state"].values()) > 0
     ev = res["iterations"][0]["evaluations"]
     assert len(ev["cop"]) == 3 and len(ev["thief"]) == 3               # every archived opponent once: 3 distinct ones exist
     for role in ("cops", "thieves"):

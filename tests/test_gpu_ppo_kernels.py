@@ -98,3 +98,28 @@ def test_gae_scan_equals_the_torch_recursion(G, T, N):
     torch.cuda.synchronize()
     scale = float(want_adv.abs().max())
     assert float((adv - want_adv).abs().max()) <= 1e-5 * scale and float((ret - want_ret).abs().max()) <= 1e-5 * max(scale, float(want_ret.abs().max()))
+
+
+def test_gae_scan_runs_on_a_side_stream():
+    """The stream handle is a 64-bit pointer: every entry point of libcat_learn.so declares it c_void_p (an untyped int
+    would be marshalled as a 32-bit C int and only the null stream would survive).  Same answer on a non-default stream."""
+    import torch
+    from as_cops_and_thieves_amd import _learn_native as ln
+    L = ln.lib()
+    for name in ("cat_ppo_gae_scan", "cat_ppo_loss_grad", "cat_ppo_adam_step"):
+        assert getattr(L, name).argtypes is not None and len(getattr(L, name).argtypes) == 2, name
+    G, T, N = 2, 16, 512
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    rew = torch.randn(G, T, N, generator=gen, device="cuda"); val = torch.randn(G, T, N, generator=gen, device="cuda")
+    dones = torch.rand(T, N, generator=gen, device="cuda") < 0.1
+    last = torch.randn(G, N, generator=gen, device="cuda")
+    a0, r0 = torch.empty_like(rew), torch.empty_like(rew)
+    ln.ppo_gae(rew, val, dones, last, 0.99, 0.95, a0, r0)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    assert side.cuda_stream != 0
+    a1, r1 = torch.empty_like(rew), torch.empty_like(rew)
+    with torch.cuda.stream(side):
+        ln.ppo_gae(rew, val, dones, last, 0.99, 0.95, a1, r1)
+    side.synchronize()
+    assert torch.equal(a0, a1) and torch.equal(r0, r1)

@@ -155,6 +155,18 @@ def test_timestep_schedule_random_phase_learning_starts_and_freeze_durations():
     assert float((d2 * rl2.col_value).abs().max()) > 0
 
 
+def test_random_and_learning_thresholds_act_per_role():
+    """skrl reads random_timesteps / learning_starts from each agent's own cfg: with CFG_AGENT_COP / CFG_AGENT_THIEF-style
+    per-role values the thief starts updating two rollouts before the cop does (one update = 1 epoch x 2 minibatches)."""
+    cop, thief = _rc(random_timesteps=8, learning_starts=16), _rc(random_timesteps=0, learning_starts=8, learning_rate=2e-4)
+    tr = MAPPOTrainer(_env(), {"cop": cop, "thief": thief}, TrainerConfig(horizon=4, timesteps=24, policy_freeze_duration=0,
+                                                                         opponent_freeze_duration=0), seed=1)
+    tr.train()
+    # rollouts end at t = 4, 8, ..., 24: thief updates at 8..24 (5 rollouts), cop from 16 (t0 >= 8 and t >= 16: 3 rollouts)
+    nb = cop.learning_epochs * cop.mini_batches
+    assert float(tr.roles["thief"].steps.max()) == 5 * nb and float(tr.roles["cop"].steps.max()) == 3 * nb
+
+
 def test_masked_adam_equals_torch_adam_and_frozen_entries_do_not_move():
     """The flat masked Adam against torch.optim.Adam on the same gradients (what skrl constructs), with the policy
     half frozen for the first steps: frozen entries keep their value, their moments and their step count."""
@@ -209,6 +221,34 @@ def test_kl_early_stop_skips_the_rest_of_the_epoch_per_agent():
     assert tuple((rl.steps - s0).amax(dim=1).tolist()) == (1.0, 1.0)
 
 
+class _RefShapedPolicy(torch.nn.Module):
+    """A module written with the attribute names and layer list of the reference's LSTMPolicy (lstm_policy_net.py:28-53), NOT
+    imported from the product: what the reference's own class registers, minus skrl's mixins (which add no parameters)."""
+
+    def __init__(self, L2):
+        super().__init__()
+        nn = torch.nn
+        self.features_extractor = nn.Sequential(nn.Conv1d(2, 64, kernel_size=5, stride=2, padding=0), nn.ReLU(),
+                                                nn.Conv1d(64, 32, kernel_size=5, stride=3, padding=0), nn.ReLU(), nn.Flatten(),
+                                                nn.Linear(32 * L2, 256), nn.Tanh())
+        self.lstm = nn.LSTM(input_size=256, hidden_size=128, num_layers=1, batch_first=True)
+        self.policy_head = nn.Sequential(nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 4))
+
+
+class _RefShapedValue(torch.nn.Module):
+    """lstm_value_net.py:46-75 likewise."""
+
+    def __init__(self, L2):
+        super().__init__()
+        nn = torch.nn
+        self.features_extractor = nn.Sequential(nn.Conv1d(4, 64, kernel_size=5, stride=2, padding=0), nn.ReLU(),
+                                                nn.Conv1d(64, 32, kernel_size=5, stride=3, padding=0), nn.ReLU(), nn.Flatten(),
+                                                nn.Linear(32 * L2, 256), nn.Tanh())
+        self.lstm = nn.LSTM(input_size=256, hidden_size=128, num_layers=2, batch_first=True)
+        self.value_head = nn.Sequential(nn.Linear(128, 256), nn.ReLU(), nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
+                                        nn.Linear(64, 1))
+
+
 def test_checkpoints_use_the_reference_module_names_and_resume_exactly(tmp_path):
     rc = _rc()
     tr = MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=4, timesteps=8, policy_freeze_duration=0,
@@ -216,10 +256,31 @@ def test_checkpoints_use_the_reference_module_names_and_resume_exactly(tmp_path)
     tr.train()
     sd = tr.state_dict()
     torch.save(sd, tmp_path / "joint_iter_0_full_agent.pt")
-    sd = torch.load(tmp_path / "joint_iter_0_full_agent.pt", weights_only=False)
-    assert set(sd["models"]) == {"cop_0", "cop_1", "thief_0"} and set(sd["optimizers"]) == {"cop_0", "cop_1", "thief_0"}
-    LSTMPolicy(16).load_state_dict(sd["models"]["cop_1"]["policy"])          # loadable by the reference-shaped modules
-    LSTMValue(16).load_state_dict(sd["models"]["thief_0"]["value"])
+    sd = torch.load(tmp_path / "joint_iter_0_full_agent.pt", weights_only=True)     # tensors, numbers, strings only
+    # skrl's MAPPO.save layout: {agent: {"policy", "value", "optimizer"}} (+ the trainer position under a non-agent key)
+    assert set(sd) == {"cop_0", "cop_1", "thief_0", "__cat__"} and all(set(sd[a]) == {"policy", "value", "optimizer"} for a in tr.agents)
+    LSTMPolicy(16).load_state_dict(sd["cop_1"]["policy"])
+    LSTMValue(16).load_state_dict(sd["thief_0"]["value"])
+    # strict load into modules carrying the REFERENCE's attribute names, and their own Adam accepts the optimiser entry
+    L2 = conv_out_len(16)
+    ref_p, ref_v = _RefShapedPolicy(L2), _RefShapedValue(L2)
+    ref_p.load_state_dict(sd["cop_1"]["policy"], strict=True)
+    ref_v.load_state_dict(sd["cop_1"]["value"], strict=True)
+    opt = torch.optim.Adam(list(ref_p.parameters()) + list(ref_v.parameters()), lr=1e-4)
+    opt.load_state_dict(sd["cop_1"]["optimizer"])
+    rl, g = tr.learner_of("cop_1")
+    o, k, shp = rl.fp.offsets["value.value_head.6.weight"]
+    assert torch.equal(opt.state[ref_v.value_head[6].weight]["exp_avg"], rl.m[g, o:o + k].view(shp))
+    # ... and the way back: a checkpoint the reference would write (module state dicts + torch Adam state, no "__cat__")
+    with torch.no_grad():
+        for q in list(ref_p.parameters()) + list(ref_v.parameters()):
+            q.add_(0.25)
+    theirs = {a: {"policy": ref_p.state_dict(), "value": ref_v.state_dict(), "optimizer": opt.state_dict()} for a in tr.agents}
+    torch.save(theirs, tmp_path / "from_reference.pt")
+    tr3 = MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=4), seed=5)
+    tr3.load_state_dict(torch.load(tmp_path / "from_reference.pt", weights_only=True))
+    assert torch.equal(tr3.agent_models("thief_0")["policy"]["lstm.weight_hh_l0"], ref_p.lstm.weight_hh_l0.detach())
+    assert torch.equal(tr3.agent_models("cop_0")["value"]["value_head.0.bias"], ref_v.value_head[0].bias.detach())
     # resume into a trainer whose agents are stacked DIFFERENTLY (one learner per role): checkpoints are per agent
     tr2 = MAPPOTrainer(_env(), {"cop": rc, "thief": _rc(learning_rate=5e-4)}, TrainerConfig(horizon=4), seed=99)
     assert sorted(tr2.roles) == ["cop", "thief"]
@@ -229,14 +290,14 @@ def test_checkpoints_use_the_reference_module_names_and_resume_exactly(tmp_path)
         assert torch.equal(l1.fp.master[g1], l2.fp.master[g2]) and torch.equal(l1.m[g1], l2.m[g2])
         assert torch.equal(l1.steps[g1], l2.steps[g2])
     assert tr2.timestep == tr.timestep
-    tr3 = MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=4), seed=98)
-    rl3 = tr3.roles["cop+thief"]
-    before = rl3.fp.master.clone()
-    tr3.load_state_dict(sd, roles=["cop"], optimizer=False)                  # copy_role_models: one role's weights only
-    for a in ("cop_0", "cop_1"):
-        assert torch.equal(rl3.fp.master[rl3.agents.index(a)], tr.learner_of(a)[0].fp.master[tr.learner_of(a)[1]])
-    g = rl3.agents.index("thief_0")
-    assert torch.equal(rl3.fp.master[g], before[g]) and float(rl3.m.abs().max()) == 0.0
+    # round-2 files ("cat-mappo-2": models / optimizers at the top, trunk.* / head.* keys) still load
+    old = {"format": "cat-mappo-2", "timestep": 8, "num_rays": 16, "optimizers": {}, "models": {
+        a: {kind: {(("trunk.features." + n[len("features_extractor."):]) if n.startswith("features_extractor.") else
+                    ("trunk." + n) if n.startswith("lstm.") else "head." + n.split(".", 1)[1]): v for n, v in sd[a][kind].items()}
+            for kind in ("policy", "value")} for a in tr.agents}}
+    tr4 = MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=4), seed=6)
+    tr4.load_state_dict(old)
+    assert all(torch.equal(tr4.learner_of(a)[0].fp.master[tr4.learner_of(a)[1]], tr.learner_of(a)[0].fp.master[tr.learner_of(a)[1]]) for a in tr.agents)
 
 
 def _ddp_worker(rank, world, port, q, kl):

@@ -37,10 +37,10 @@ def test_self_play_iterations_archives_checkpoints_and_resume(tmp_path):
     assert len(res["iterations"][2]["evaluations"]["cop"]) == 2                 # two distinct archived thieves
     for role, d in (("cop", "cops"), ("thief", "thieves")):
         assert sorted(p.name for p in (tmp_path / d).glob("*.pt")) == [f"{role}_iter_{i}.pt" for i in range(3)]
-    sd = torch.load(tmp_path / "joint_iter_2_full_agent.pt", weights_only=False)
-    assert set(sd["models"]) == {"cop_0", "cop_1", "thief_0"} and float(sd["optimizers"]["thief_0"]["steps"].max()) > 0
-    assert torch.equal(torch.load(tmp_path / "cops" / "cop_iter_2.pt", weights_only=False)["models"]["cop_0"]["policy"]["head.0.weight"],
-                       sd["models"]["cop_0"]["policy"]["head.0.weight"])         # the archive entry IS the joint checkpoint
+    sd = torch.load(tmp_path / "joint_iter_2_full_agent.pt", weights_only=True)
+    assert set(sd) == {"cop_0", "cop_1", "thief_0", "__cat__"} and float(sd["thief_0"]["optimizer"]["state"][0]["step"]) > 0
+    assert torch.equal(torch.load(tmp_path / "cops" / "cop_iter_2.pt", weights_only=True)["cop_0"]["policy"]["policy_head.0.weight"],
+                       sd["cop_0"]["policy"]["policy_head.0.weight"])            # the archive entry IS the joint checkpoint
     wr = json.loads((tmp_path / "thieves" / "win_rates.json").read_text())
     assert set(wr) <= {"thief_iter_0.pt", "thief_iter_1.pt"} and all(v["games"] >= 1 for v in wr.values())
     # a second call continues after the highest archived iteration ("latest")
@@ -61,8 +61,8 @@ def test_default_trainer_configuration_uses_128_tick_rollouts(tmp_path):
     res = run_self_play("squarinth", 2, tmp_path, iterations=1, env_factory=factory, log=lambda *a: None, role_cfg={"cop": rc, "thief": rc},
                         training=TrainingConfig(training_timesteps_per_role_training=128, n_trial_episodes=1, num_opponents_to_evaluate=1))
     assert [h["iteration"] for h in res["iterations"]] == [0]
-    sd = torch.load(tmp_path / "joint_iter_0_full_agent.pt", weights_only=False)
-    assert float(sd["optimizers"]["cop_0"]["steps"].max()) == 2.0      # ONE update of 1 epoch x 2 minibatches after 128 ticks
+    sd = torch.load(tmp_path / "joint_iter_0_full_agent.pt", weights_only=True)
+    assert max(float(st["step"]) for st in sd["cop_0"]["optimizer"]["state"].values()) == 2.0      # ONE update of 1 epoch x 2 minibatches after 128 ticks
 
 
 def test_evaluation_books_one_outcome_for_each_of_five_distinct_opponents(tmp_path):
@@ -75,18 +75,18 @@ def test_evaluation_books_one_outcome_for_each_of_five_distinct_opponents(tmp_pa
         ck = tmp_path / "ck.pt"
         torch.save(other.state_dict(), ck)
         archive.add_policy_to_archive(str(ck), arch, it, "thief")
-    before = {a: learned.agent_models(a)["policy"]["head.0.weight"].clone() for a in learned.agents}
+    before = {a: learned.agent_models(a)["policy"]["policy_head.0.weight"].clone() for a in learned.agents}
     out = evaluate_agent(ev, evaluator, learned, "cop", "thief", arch, TrainingConfig(n_trial_episodes=6), random.Random(3),
                          log=lambda *a: None)
     assert len(out) == 5 and len(set(out)) == 5                                  # five DISTINCT opponents
     wr = json.loads((arch / "win_rates.json").read_text())
     assert set(wr) == set(out) and all(v["games"] == 1 and v["recent_outcomes"] == [int(out[k])] for k, v in wr.items())
     # the evaluation ran on a copy: the trained weights are untouched (the reference overwrites them, quirk Q16)
-    assert all(torch.equal(before[a], learned.agent_models(a)["policy"]["head.0.weight"]) for a in learned.agents)
+    assert all(torch.equal(before[a], learned.agent_models(a)["policy"]["policy_head.0.weight"]) for a in learned.agents)
     # the evaluator really played the archived opponent, not the learner's thief
-    last = torch.load(arch / list(out)[-1], weights_only=False)
-    assert torch.equal(evaluator.agent_models("thief_0")["policy"]["head.0.weight"], last["models"]["thief_0"]["policy"]["head.0.weight"])
-    assert torch.equal(evaluator.agent_models("cop_0")["policy"]["head.0.weight"], before["cop_0"])
+    last = torch.load(arch / list(out)[-1], weights_only=True)
+    assert torch.equal(evaluator.agent_models("thief_0")["policy"]["policy_head.0.weight"], last["thief_0"]["policy"]["policy_head.0.weight"])
+    assert torch.equal(evaluator.agent_models("cop_0")["policy"]["policy_head.0.weight"], before["cop_0"])
 
 
 def test_evaluate_agents_counts_first_episodes_only():
