@@ -104,6 +104,7 @@ class CompiledMap:
     regions: np.ndarray       # [Rg,4] x y w h
     n_cops: int
     n_thieves: int
+    spec: Optional[dict] = None   # the INPUTS this map was compiled from (parsed JSON + Map's override arguments), as plain data
 
     @property
     def n_agents(self) -> int:
@@ -174,11 +175,18 @@ class Map:
         self.name = Path(map_path).name.split(".")[0]
         self._scale = scale
         self._parse_json_map(str(map_path), roster, start_positions, spawn_regions)
+        # what was asked for, kept as data: a checker can rebuild the geometry from these with its own code
+        self.spec = {"name": self.name, "map_data": self._map_data, "bundled": Path(map_path).resolve().parent == MAPS_DIR,
+                     "roster": None if roster is None else list(roster),
+                     "start_positions": None if start_positions is None else [tuple(p) for p in start_positions],
+                     "spawn_regions": None if spawn_regions is None else dict(spawn_regions),
+                     "scale": None if scale is None else tuple(scale)}
 
     # -- parsing ------------------------------------------------------------------------
     def _parse_json_map(self, map_path, roster, start_positions, spawn_regions) -> None:
         with open(map_path, "r") as f:
             map_data = json.load(f)
+        self._map_data = map_data
         self.window_dimensions = tuple(map_data["window"].values())
         self.canvas_dimensions = tuple(map_data["canvas"].values())
         if "rings" in map_data:  # bundled compact schema (tools/import_reference_maps.py)
@@ -265,6 +273,7 @@ class Map:
             regions=np.asarray(regs, dtype=np.float64).reshape(-1, 4),
             n_cops=self.cops_count,
             n_thieves=self.thieves_count,
+            spec=dict(self.spec, wall_radius=wall_radius),
         )
 
 

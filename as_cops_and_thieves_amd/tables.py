@@ -12,8 +12,6 @@
 """
 from __future__ import annotations
 
-import warnings
-
 import numpy as np
 
 from .constants import DEFAULT_SENSOR, SensorParams
@@ -29,24 +27,36 @@ def _all_nonneg_f16() -> np.ndarray:
     return np.arange(32768, dtype=np.uint16).view(np.float16)
 
 
+def _h(x: np.ndarray) -> np.ndarray:
+    """One float16 operation's result: the exact (float64) value rounded once to float16, widened again."""
+    return x.astype(np.float16).astype(np.float64)
+
+
 def cop_reward_lut() -> np.ndarray:
-    """``-0.02 + 1.5 * np.exp(-d / 50.0)`` with ``d`` float16 (cop.py:69-72), widened to f32."""
-    d = _all_nonneg_f16()
-    with warnings.catch_warnings(), np.errstate(all="ignore"):
-        warnings.simplefilter("ignore")
-        reward = -0.02
-        reward = reward + 1.5 * np.exp(-d / 50.0)
-    assert reward.dtype == np.float16
+    """``reward = -0.02; reward += 1.5 * np.exp(-d / 50.0)`` with ``d`` a float16 SCALAR (cop.py:63-72), widened to f32.
+
+    NumPy evaluates every operation of a float16 scalar expression by widening, operating and rounding back to float16 (Python
+    floats are "weak": they become float16 first).  The table restates exactly that with float64 intermediates -- one rounding
+    to float16 per operation -- so it does not depend on the host's SIMD paths: NumPy's vectorised float16 ``exp`` (AVX512
+    float32 kernel, then a second rounding) is off by one float16 ulp for 2 of the 32768 distances on this image's CPUs, while
+    the scalar call the reference makes is not (tests/test_oracle_independent_host.py compares with NumPy's scalar results)."""
+    d = _all_nonneg_f16().astype(np.float64)
+    with np.errstate(all="ignore"):
+        t = _h(-d / 50.0)
+        e = _h(np.exp(t))
+        m = _h(1.5 * e)
+        reward = _h(float(np.float16(-0.02)) + m)
     return np.ascontiguousarray(reward.astype(np.float32))
 
 
 def thief_reward_lut() -> np.ndarray:
-    """``np.tanh((d - 100.0) / 50.0) / 10.0`` with ``d`` float16 (thief.py:65-66)."""
-    d = _all_nonneg_f16()
-    with warnings.catch_warnings(), np.errstate(all="ignore"):
-        warnings.simplefilter("ignore")
-        reward = np.tanh((d - 100.0) / 50.0) / 10.0
-    assert reward.dtype == np.float16
+    """``np.tanh((d - 100.0) / 50.0) / 10.0`` with ``d`` a float16 scalar (thief.py:65-66); see ``cop_reward_lut``."""
+    d = _all_nonneg_f16().astype(np.float64)
+    with np.errstate(all="ignore"):
+        u = _h(d - 100.0)
+        v = _h(u / 50.0)
+        w = _h(np.tanh(v))
+        reward = _h(w / 10.0)
     return np.ascontiguousarray(reward.astype(np.float32))
 
 

@@ -12,9 +12,9 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from as_cops_and_thieves_amd.config import C_FIELDS_F64, C_FIELDS_I32, SimConfig
-from as_cops_and_thieves_amd.maps import CompiledMap
-from as_cops_and_thieves_amd import tables
+from . import cat_oracle_host as host
+
+C_FIELDS_I32, C_FIELDS_F64 = host.CONFIG_I32, host.CONFIG_F64
 
 HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "_build" / "libcat_oracle.so"
@@ -106,17 +106,21 @@ def alloc_state(N: int, A: int) -> dict:
 class OracleSim:
     """N independent envs advanced by the scalar CPU restatement."""
 
-    def __init__(self, cfg: SimConfig, maps: Sequence[CompiledMap], slot_map_ids: Optional[np.ndarray] = None):
+    def __init__(self, cfg, maps: Sequence, slot_map_ids: Optional[np.ndarray] = None):
+        """``cfg``: any record with the workload fields (a product SimConfig is read field by field; ``bias_coef`` is recomputed
+        here).  ``maps``: product CompiledMaps are used only for their ``spec`` (the inputs): the geometry blob, the ray table and
+        the reward tables are built by cat_oracle_host.py, not taken from the product."""
         L = lib()
-        self.cfg, self.N, self.A, self.R = cfg, cfg.n_envs, cfg.n_agents, cfg.n_rays
+        v = host.config_values(cfg)
+        self.cfg, self.N, self.A, self.R = cfg, v["n_envs"], v["n_cops"] + v["n_thieves"], v["n_rays"]
         c = _Config()
         for n in C_FIELDS_I32 + C_FIELDS_F64:
-            setattr(c, n, getattr(cfg, n))
-        c.env_id_offset, c.seed = cfg.env_id_offset, cfg.seed
-        dx, dy = tables.ray_table(cfg.sensor)
-        self._keep = [dx, dy, tables.cop_reward_lut(), tables.thief_reward_lut()]
+            setattr(c, n, v[n])
+        c.env_id_offset, c.seed = v["env_id_offset"], v["seed"]
+        dx, dy = host.ray_table(v["n_rays"], v["ray_length"])
+        self._keep = [dx, dy, *host.reward_tables()]
         t = _Tables(*[_ptr(a) for a in self._keep])
-        blobs = [m.to_blob() for m in maps]
+        blobs = [m if isinstance(m, (bytes, bytearray)) else host.blob_for(m) for m in maps]
         arr = (C.c_char_p * len(blobs))(*blobs)
         sizes = (C.c_size_t * len(blobs))(*[len(b) for b in blobs])
         ids = None if slot_map_ids is None else np.ascontiguousarray(slot_map_ids, np.int32)

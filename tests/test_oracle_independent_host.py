@@ -1,0 +1,120 @@
+"""CPU: the oracle's host side (oracle/cat_oracle_host.py) shares no code with the product's (maps.py, tables.py, config.py,
+constants.py) -- and both must produce the same bytes.  The oracle parses the reference's own map files (tests/golden/maps_raw),
+hulls them with Chipmunk's QuickHull scheme and evaluates the reward tables as float16 SCALARS; the product reads its bundled
+compact maps, uses a monotone chain and vectorised NumPy.  A disagreement is a bug on one side, which a shared implementation
+would have hidden (VERDICT r2 "common-mode code")."""
+import ast
+import dataclasses
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from as_cops_and_thieves_amd import tables
+from as_cops_and_thieves_amd.config import C_FIELDS_F64, C_FIELDS_I32, SimConfig
+from as_cops_and_thieves_amd.constants import DEFAULT_SENSOR, SensorParams
+from as_cops_and_thieves_amd.maps import Map, load_preset
+from oracle import cat_oracle_host as host
+
+ROOT = Path(__file__).resolve().parents[1]
+MAPS = ("agh-map", "grandbyrinth", "labyrinth", "lbirinth", "squarinth")
+
+
+def test_oracle_python_imports_nothing_from_the_product():
+    for f in ("cat_oracle.py", "cat_oracle_host.py", "__init__.py"):
+        tree = ast.parse((ROOT / "oracle" / f).read_text())
+        for node in ast.walk(tree):
+            names = [a.name for a in node.names] if isinstance(node, ast.Import) else \
+                    [node.module or ""] if isinstance(node, ast.ImportFrom) else []
+            assert not any("as_cops_and_thieves_amd" in n for n in names), (f, names)
+        assert "as_cops_and_thieves_amd" not in (ROOT / "oracle" / f).read_text().replace("``as_cops_and_thieves_amd.{maps,tables,config,constants}``", "")
+
+
+@pytest.mark.parametrize("name", MAPS)
+@pytest.mark.parametrize("roster", [(None, None), (2, 1), (3, 2)])
+def test_geometry_blobs_are_byte_identical(name, roster):
+    try:
+        cm = load_preset(name, *roster).compile()
+    except ValueError:
+        pytest.skip("the preset holds no start positions for this roster")
+    theirs = host.blob_for(cm)
+    ours = cm.to_blob()
+    assert len(theirs) == len(ours)
+    if theirs != ours:
+        a, b = np.frombuffer(ours, np.uint8), np.frombuffer(theirs, np.uint8)
+        raise AssertionError(f"{name} {roster}: blobs differ at byte {int(np.argmax(a != b))} ({int((a != b).sum())} bytes)")
+
+
+def test_raw_fixture_files_are_what_the_index_says():
+    import hashlib
+    idx = json.loads((host.RAW_MAPS / "INDEX.json").read_text())["files"]
+    assert set(idx) == {f"{n}.json" for n in MAPS}
+    for f, meta in idx.items():
+        assert hashlib.sha256((host.RAW_MAPS / f).read_bytes()).hexdigest() == meta["sha256"]
+
+
+def test_user_map_in_the_reference_schema(tmp_path):
+    """A map that is not bundled: both sides parse the same file (rect defaults, negative sizes, an open and a closed poly ring,
+    a non-convex poly whose hull drops a vertex, duplicate vertices, singular and plural spawn keys)."""
+    blocks = [{"x": 10, "y": 10, "w": 100}, {"type": "rect", "x": 300, "y": 300, "w": -50, "h": -80},
+              {"type": "poly", "vs": [{"x": 400, "y": 100}, {"x": 500, "y": 100}, {"x": 450, "y": 120}, {"x": 500, "y": 200}, {"x": 400, "y": 200}]},
+              {"type": "poly", "vs": [{"x": 0, "y": 500}, {"x": 60, "y": 500}, {"x": 60, "y": 500}, {"x": 30, "y": 560}, {"x": 0, "y": 500}]},
+              {"type": "poly", "vs": [{"x": 600, "y": 600}, {"x": 700, "y": 600}, {"x": 650, "y": 600}, {"x": 700, "y": 700}, {"x": 600.5, "y": 650.25}]}]
+    agents = [{"type": "thief", "x": 200, "y": 200, "spawn_regions": [{"x": 1, "y": 2, "w": 3, "h": 4}, {"x": 5, "y": 6, "w": 7, "h": 8}]},
+              {"type": "cop", "x": 220, "y": 240, "spawn_region": {"x": 9, "y": 10, "w": 11, "h": 12}}, {"type": "cop", "x": 250, "y": 260}]
+    f = tmp_path / "user.json"
+    f.write_text(json.dumps({"window": {"w_px": 800, "h_px": 800}, "canvas": {"w": 800, "h": 800}, "objects": {"blocks": blocks},
+                             "agents": agents}))
+    for kw in ({}, {"scale": (1.5, 0.75)}):
+        cm = Map(f, **kw).compile()
+        assert host.blob_for(cm) == cm.to_blob()
+    assert cm.n_cops == 2 and cm.n_thieves == 1 and cm.shape_count.tolist() == [4, 4, 4, 3, 4]
+
+
+def test_quickhull_against_the_strict_hull():
+    """Random integer clouds (many collinear triples and duplicates): Chipmunk's QuickHull as restated by the oracle gives the
+    product's strict hull, except for redundant vertices that lie ON a hull edge (the tie quirk in convex_hull's docstring, D7)."""
+    from as_cops_and_thieves_amd.maps import convex_hull as strict_hull
+    rng = np.random.default_rng(0)
+    cross = lambda o, a, b: (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+    extra_seen = 0
+    for _ in range(3000):
+        pts = [tuple(map(float, p)) for p in rng.integers(0, 7, size=(int(rng.integers(3, 14)), 2))]
+        want = strict_hull(pts)
+        if len(want) < 3:
+            continue                                                     # a point or a line
+        got = host.convex_hull(pts)
+        assert got[0] == want[0] == min(pts)                             # starts at the (x, y)-minimum
+        k = len(got)
+        assert all(cross(got[i - 1], got[i], got[(i + 1) % k]) >= 0 for i in range(k))    # convex, counter-clockwise
+        core = [p for i, p in enumerate(got) if cross(got[i - 1], p, got[(i + 1) % k]) > 0]
+        assert core == want, (pts, got, want)
+        extra_seen += len(got) - len(core)
+    assert extra_seen > 0                                                # the quirk exists (and only adds on-edge vertices)
+    for name in MAPS:                                                    # ... and none of the five maps has it
+        data = json.loads((host.RAW_MAPS / f"{name}.json").read_text())
+        assert all(host.convex_hull(r) == strict_hull(r) for r in host.map_rings(data)), name
+
+
+def test_tables_and_config_agree():
+    for R in (16, 64, 90, 200):
+        a = tables.ray_table(SensorParams(num_rays=R))
+        b = host.ray_table(R)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # reward tables: NumPy's own float16 SCALAR evaluation of the reference's expressions (oracle) against the product's
+    # "one rounding per operation" restatement, for every finite distance and +inf (beyond that: NaN on both sides)
+    cop, thief = host.reward_tables()
+    for theirs, ours in ((cop, tables.cop_reward_lut()), (thief, tables.thief_reward_lut())):
+        assert np.array_equal(theirs.view(np.uint32)[:0x7C01], ours.view(np.uint32)[:0x7C01])
+        assert np.isnan(theirs[0x7C01:]).all() and np.isnan(ours[0x7C01:]).all()
+    assert (C_FIELDS_I32, C_FIELDS_F64) == (host.CONFIG_I32, host.CONFIG_F64)
+    cfg = SimConfig()
+    v = host.config_values(cfg)
+    for k in C_FIELDS_I32 + C_FIELDS_F64:
+        assert v[k] == getattr(cfg, k), k                               # incl. bias_coef, which the oracle derives itself
+    # the oracle's own defaults (literals with citations) equal the product's, field by field
+    blank = host.config_values(object())
+    for f in dataclasses.fields(SimConfig):
+        assert blank[f.name] == getattr(cfg, f.name), f.name
+    assert host.NUM_RAYS == DEFAULT_SENSOR.num_rays and host.FOV == DEFAULT_SENSOR.fov
