@@ -74,9 +74,24 @@ def cpu_baseline(cfg, cmap, budget_s: float = 12.0):
     cat_oracle.lib().cato_set_threads(1)
     v1, _, ticks1 = res["1core"]
     va, ca, _ = res["allcores"]
-    return {"value": v1, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} envs x {ticks1} ticks of the same workload, CPU restatement (not Pymunk), 1 thread",
-            "allcores": {"value": va, "cores": ca}}
+    out = {"value": v1, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{n} envs x {ticks1} ticks of the same workload, CPU restatement (not Pymunk), 1 thread",
+           "allcores": {"value": va, "cores": ca}}
+    # the single-process Pymunk figure, when this host has the package (this image does not: the
+    # attempt is recorded either way).  oracle/pymunk_double.py drives Pymunk with the reference's own call sequence.
+    from oracle import pymunk_double
+    if pymunk_double.available():
+        spec = cmap.spec
+        try:
+            rate, ticks = pymunk_double.time_random_rollout(spec["map_data"], cfg.n_rays, 6.0, roster=spec.get("roster"),
+                                                            start_positions=spec.get("start_positions"), scale=spec.get("scale"))
+            out["pymunk_1core"] = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "reference dependency (Pymunk) through "
+                                   "oracle/pymunk_double.py", "sample": f"1 env x {ticks} ticks, random actions"}
+        except Exception as exc:   # noqa: BLE001
+            out["pymunk_1core"] = {"value": None, "error": repr(exc)[:200]}
+    else:
+        out["pymunk_1core"] = {"value": None, "error": "import pymunk failed: not installed on this host"}
+    return out
 
 
 def event_stride(steps: int) -> int:
