@@ -11,7 +11,9 @@
  * Stated deviations from Chipmunk (all far below the 1e-5 position tolerance):
  *   D1  bodies do not rotate: angular velocity terms (O(1e-12)) are dropped.
  *   D2  the spatial index is a linear list: shapes are visited in index order (walls, then
- *       agents), which fixes tie-breaks and solver order.
+ *       agents), which fixes tie-breaks and solver order.  The BBTree's pruning rule is kept
+ *       (visit iff the bb entry value is below the best alpha so far); its visiting ORDER (nearer child first) is
+ *       available as a diagnostic (cato_set_index_order(0)): see segment_query_first.
  *   D3  bb slab test multiplies by 1/delta instead of dividing (gate decision only).
  *   D4  centre-inside-hull contacts use least-penetration instead of EPA (unreachable in
  *       play: needs > 5 px penetration).
@@ -267,10 +269,32 @@ typedef struct {
 static inline const double *TC(const cato_sim *s, int env, int j) { return s->tc + 2 * ((size_t)env * s->A + j); }
 static inline const double *LEAF(const cato_sim *s, int env, int j) { return s->leaf_bb + 4 * ((size_t)env * s->A + j); }
 
-/* [CP cpSpaceSegmentQueryFirst] over a linear index (D2): walls in index order, then agents
-   j != self in index order (the ray filter shares the agent's group, so only its own circle is
-   rejected [REF entity.py:118-123]); los: mask excludes both agent categories
-   [REF base_env.py:536-538], so walls only.  Strict '<' keeps the first of equal alphas. */
+/* one candidate of a segment query: its spatial-index gate value and its place in the shape list */
+typedef struct { double tbb; int id; } seg_cand;
+
+static int g_index_order = 1;   /* 1 = visit in index order (D2, what the HIP kernels do); 0 = nearest-bb-first (diagnostic) */
+void cato_set_index_order(int on) { g_index_order = on; }
+
+/* ascending (tbb, id): insertion sort, the lists are short and nearly sorted */
+static void sort_cands(seg_cand *c, int n)
+{
+    for (int i = 1; i < n; i++) {
+        seg_cand x = c[i];
+        int j = i - 1;
+        while (j >= 0 && (c[j].tbb > x.tbb || (c[j].tbb == x.tbb && c[j].id > x.id))) { c[j + 1] = c[j]; j--; }
+        c[j + 1] = x;
+    }
+}
+
+/* [CP cpSpaceSegmentQueryFirst]: the static index is queried first (t_exit = 1), then the dynamic index with
+   t_exit = the best alpha so far; the ray filter shares the agent's group, so only its own circle is rejected
+   [REF entity.py:118-123]; los: the mask excludes both agent categories [REF base_env.py:536-538], so walls only.
+   A shape is visited iff the value t_bb at which the thin segment enters its bb is below the best alpha so far, and
+   strict '<' keeps the first of equal alphas.  ORDER of the visits (D2): index order.  Chipmunk's BBTree
+   ([CP SubtreeSegmentQuery]) descends into the child whose bb the segment enters first, which for sibling leaves is
+   ascending t_bb; cato_set_index_order(0) switches to that order (ascending t_bb, index on equal values) so that
+   tools/query_order_diff.py can count the observations that depend on it (0.003 - 0.2 % of the rays, by map: two walls
+   whose hits lie less than the ray radius apart, DESIGN D2). */
 static int segment_query_first(const cato_sim *s, int env, int self, double ax, double ay,
                                double bx, double by, double r2, int los, seg_info *out)
 {
@@ -281,11 +305,16 @@ static int segment_query_first(const cato_sim *s, int env, int self, double ax, 
     double dx = bx - ax, dy = by - ay;
     double idx = 1.0 / dx, idy = 1.0 / dy;
     double t_exit = 1.0;
+    seg_cand cand[256 + CATO_MAX_AGENTS];
+    int n = 0;
     for (int sh = 0; sh < m->S; sh++) {
-        if (c->bbtree_gate) {
-            double tbb = bb_segment_query(m->bb + 4 * (size_t)sh, ax, ay, dx, dy, idx, idy);
-            if (!(tbb < t_exit)) continue;
-        }
+        double tbb = c->bbtree_gate ? bb_segment_query(m->bb + 4 * (size_t)sh, ax, ay, dx, dy, idx, idy) : 0.0;
+        if (tbb < 1.0 || !c->bbtree_gate) { cand[n].tbb = tbb; cand[n].id = sh; n++; }
+    }
+    if (!g_index_order) sort_cands(cand, n);
+    for (int q = 0; q < n; q++) {
+        const int sh = cand[q].id;
+        if (c->bbtree_gate && !(cand[q].tbb < t_exit)) { if (g_index_order) continue; else break; }
         seg_info info = {0, 1.0, bx, by};
         /* [CP cpShapeSegmentQuery]: start point within `radius` of the shape -> alpha 0,
            point stays at the segment end */
@@ -298,13 +327,17 @@ static int segment_query_first(const cato_sim *s, int env, int self, double ax, 
         t_exit = fmin2(t_exit, out->alpha);
     }
     if (!los) {
+        n = 0;
         for (int j = 0; j < s->A; j++) {
             if (j == self) continue;
+            double tbb = c->bbtree_gate ? bb_segment_query(LEAF(s, env, j), ax, ay, dx, dy, idx, idy) : 0.0;
+            if (tbb < 1.0 || !c->bbtree_gate) { cand[n].tbb = tbb; cand[n].id = j; n++; }
+        }
+        if (!g_index_order) sort_cands(cand, n);
+        for (int q = 0; q < n; q++) {
+            const int j = cand[q].id;
+            if (c->bbtree_gate && !(cand[q].tbb < t_exit)) { if (g_index_order) continue; else break; }
             const double *tc = TC(s, env, j);
-            if (c->bbtree_gate) {
-                double tbb = bb_segment_query(LEAF(s, env, j), ax, ay, dx, dy, idx, idy);
-                if (!(tbb < t_exit)) continue;
-            }
             seg_info info = {0, 1.0, bx, by};
             double ex = ax - tc[0], ey = ay - tc[1];
             if (sqrt(ex * ex + ey * ey) - c->agent_radius <= r2) { /* [CP cpCircleShapePointQuery] */

@@ -112,6 +112,7 @@ int cato_set_state(cato_sim *s, const cato_state *src);
 /* synthetic uniform actions in {0..3}: Philox(key=seed, ctr=(env_global, tick, agent, 0xAC710)) */
 int cato_random_actions(cato_sim *s, uint64_t tick, int32_t *actions);
 void cato_set_threads(int n);     /* OpenMP threads over envs; 1 = scalar port */
+void cato_set_index_order(int on);/* 1 (default): segment queries visit shapes in index order (D2); 0: nearest-bb-first (diagnostic) */
 
 /* ---- elementary pieces, exported so tests can pin them individually ---- */
 uint16_t cato_f64_to_f16(double x);

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""CPU diagnostic: how many observations depend on the ORDER in which a segment query visits the shapes whose bb it enters
+(DESIGN D2): the oracle with nearest-bb-first order (the order Chipmunk's BBTree descent produces) against index order (the
+convention of rounds 1-2), same seeds, same actions, every ray of every tick compared.  usage: tools/query_order_diff.py [envs] [ticks]"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from as_cops_and_thieves_amd.config import SimConfig              # noqa: E402
+from as_cops_and_thieves_amd.maps import load_preset              # noqa: E402
+from oracle import cat_oracle                                      # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+L = cat_oracle.lib()
+L.cato_set_threads(8)
+for name in ("labyrinth", "agh-map", "squarinth", "lbirinth", "grandbyrinth"):
+    cmap = load_preset(name).compile()
+    cfg = SimConfig(n_envs=N, n_rays=64, max_step_count=100, seed=5)
+    a, b = cat_oracle.OracleSim(cfg, [cmap]), cat_oracle.OracleSim(cfg, [cmap])
+    L.cato_set_index_order(0); a.reset()
+    L.cato_set_index_order(1); b.reset()
+    rays = diff_shape = diff_obs = 0
+    for t in range(T):
+        acts = a.random_actions(t)
+        before = a.get_state()                       # same state on both sides every tick: only the query order differs
+        L.cato_set_index_order(0); oa = {k: v.copy() for k, v in a.step(acts).items()}
+        L.cato_set_index_order(1)
+        b.set_state(**before)
+        ob = b.step(acts)
+        L.cato_set_index_order(0); a.reset(mask=oa["terminated"].copy())
+        rays += oa["obs_type"].size
+        diff_shape += int((oa["hit_shape"] != ob["hit_shape"]).sum())
+        diff_obs += int(((oa["obs_type"] != ob["obs_type"]) | (oa["obs_distance"] != ob["obs_distance"])).sum())
+    L.cato_set_index_order(1)
+    print(f"{name}: {rays} rays, winning shape differs on {diff_shape}, observation (class or f16 distance) differs on {diff_obs}")
