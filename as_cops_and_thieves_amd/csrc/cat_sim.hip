@@ -1938,6 +1938,39 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
     g.rows_of.push_back(d.nx * d.ny * R);
 }
 
+// The most wall bounding boxes the bb of ONE agent circle can overlap at once, anywhere on the map: an upper bound on the wall
+// arbiters an agent can hold in one step ([CP cpSpaceCollideShapes] makes one only on a real contact), to be held against the
+// CAT_WALL_CACHE slots of the state record at cat_create instead of being discovered at run time (CAT_DEVERR_CONTACT_DROPPED).
+// The circle's bb overlaps a wall's iff its centre lies in the wall's bb grown by the radius (closed rectangles): the deepest point
+// of such an arrangement is the left edge of one rectangle and the bottom edge of one.
+static int max_wall_bb_depth(const double *bb, int S, double rc)
+{
+    int best = 0;
+    for (int a = 0; a < S; a++) {
+        const double x = bb[4 * a] - rc;
+        for (int b = 0; b < S; b++) {
+            const double y = bb[4 * b + 1] - rc;
+            int n = 0;
+            for (int s = 0; s < S; s++)
+                n += (bb[4 * s] - rc <= x && x <= bb[4 * s + 2] + rc && bb[4 * s + 1] - rc <= y && y <= bb[4 * s + 3] + rc) ? 1 : 0;
+            best = n > best ? n : best;
+        }
+    }
+    return best;
+}
+
+extern "C" int cat_map_wall_bb_depth_host(const void *blob, size_t size, double agent_radius)
+{
+    if (!blob || size < 64) return CAT_ERR_BAD_ARG;
+    int32_t h[16];
+    memcpy(h, blob, 64);
+    const int S = h[2];
+    if ((unsigned)h[0] != kBlobMagic || S < 1 || S > CAT_MAX_SHAPES || size < 64 + (2 + 4 * (size_t)S) * 8) return CAT_ERR_BAD_MAP;
+    std::vector<double> bb(4 * (size_t)S);
+    memcpy(bb.data(), static_cast<const unsigned char *>(blob) + 64 + 16, bb.size() * 8);
+    return max_wall_bb_depth(bb.data(), S, agent_radius);
+}
+
 // Packed rows, one per (cell, ray): byte 0 = count (saturating at 255), then the first 8*row_words - 1
 // candidate ids; row_words (1, 2 or 4 eight-byte words) is the smallest that holds the longest list of
 // any map of the sim, lists beyond 31 ids continue in the CSR arrays (slow path on the device).
@@ -2091,6 +2124,14 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
                 snprintf(g_create_err, sizeof g_create_err, "map blob %d: wall %d has %d hull edges (1..%d supported)", m, sidx, iv[d.S + sidx], CAT_MAX_HULL_EDGES);
                 return CAT_ERR_BAD_MAP;
             }
+        {
+            const int depth = max_wall_bb_depth(f.data() + 2, d.S, cfg->agent_radius);
+            if (depth > CAT_WALL_CACHE) {
+                snprintf(g_create_err, sizeof g_create_err, "map blob %d: an agent can touch the bounding boxes of %d walls at once; the state record "
+                         "caches %d wall contacts per agent (CAT_WALL_CACHE)", m, depth, CAT_WALL_CACHE);
+                return CAT_ERR_BAD_MAP;
+            }
+        }
         d.f64_off = (int)geo_f.size();
         const size_t n_geo = 4 * (size_t)d.S + 8 * (size_t)d.P;
         geo_f.insert(geo_f.end(), f.begin() + 2, f.begin() + 2 + n_geo);  // drop window w,h: [bb][planes]

@@ -25,7 +25,7 @@ extern "C" {
 #define CAT_MAX_RAYS 512
 #define CAT_MAX_SHAPES 256
 #define CAT_MAX_HULL_EDGES 31   /* edges of one convex wall */
-#define CAT_WALL_CACHE 8        /* cached wall arbiters per agent */
+#define CAT_WALL_CACHE 8        /* cached wall arbiters per agent; cat_create refuses a map on which an agent could need more */
 
 enum {
     CAT_OK = 0,
@@ -195,6 +195,11 @@ int cat_grid_build_host(const cat_config *cfg, const cat_tables *tables, const v
 int cat_grid_lookup_host(const cat_grid_host *grid, double x, double y, int k, int *out, int max_out);
 long long cat_grid_bytes_host(const cat_grid_host *grid);
 void cat_grid_free_host(cat_grid_host *grid);
+
+/* The most wall bounding boxes the bb of one agent circle (radius agent_radius) can overlap at once on this map (host only): the
+   bound cat_create holds against CAT_WALL_CACHE -- a map where it is larger is refused (CAT_ERR_BAD_MAP) instead of dropping a
+   contact at run time (CAT_DEVERR_CONTACT_DROPPED stays as the backstop).  Negative: an error code. */
+int cat_map_wall_bb_depth_host(const void *map_blob, size_t blob_size, double agent_radius);
 
 /* Device arithmetic self-test used by tests: out[i] = op(in_a[i], in_b[i]) evaluated on the GPU
    with the same primitives the kernels use (op 0 sqrt(a), 1 a/b, 2 f64->f16 bits of a,

@@ -901,6 +901,23 @@ int cato_create(const cato_config *cfg, const cato_tables *tab, const void *cons
             snprintf(g_err, sizeof g_err, "map blob %d invalid or roster mismatch", i);
             return -2;
         }
+        /* the arbiter cache holds K_WALL wall contacts per agent: a map on which the bb of one agent circle can overlap more wall bbs
+           than that at once is refused here, as the HIP library refuses it (deepest point of the grown bbs: a left and a bottom edge) */
+        const cato_map *mp = &s->maps[i];
+        const double rc = cfg->agent_radius;
+        int depth = 0;
+        for (int a = 0; a < mp->S; a++)
+            for (int b = 0; b < mp->S; b++) {
+                const double x = mp->bb[4 * a] - rc, y = mp->bb[4 * b + 1] - rc;
+                int n = 0;
+                for (int q = 0; q < mp->S; q++)
+                    n += (mp->bb[4 * q] - rc <= x && x <= mp->bb[4 * q + 2] + rc && mp->bb[4 * q + 1] - rc <= y && y <= mp->bb[4 * q + 3] + rc);
+                if (n > depth) depth = n;
+            }
+        if (depth > K_WALL) {
+            snprintf(g_err, sizeof g_err, "map blob %d: an agent can touch the bounding boxes of %d walls at once; %d wall contacts are cached per agent", i, depth, K_WALL);
+            return -2;
+        }
     }
     size_t N = (size_t)s->N;
     s->slot_map = (int32_t *)calloc(N, 4);

@@ -262,6 +262,19 @@ def test_wall_with_too_many_hull_edges_is_rejected(tmp_path):
         CatSim(SimConfig(n_envs=4, n_rays=16), [Map(f).compile()], device="cuda:0")
 
 
+def test_map_needing_more_than_eight_cached_wall_contacts_is_rejected(tmp_path):
+    """cat_create holds the map against CAT_WALL_CACHE (tests/test_maps_and_constants.py has the bound itself): 9 thin walls
+    meeting at a point are refused with a message, 8 are accepted and run."""
+    from tests.test_maps_and_constants import _star_junction
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.sim import CatSim
+    with pytest.raises(RuntimeError, match="9 walls at once"):
+        CatSim(SimConfig(n_envs=4, n_rays=16), [_star_junction(tmp_path, 9)], device="cuda:0")
+    m = _star_junction(tmp_path, 8)
+    cfg = SimConfig(n_envs=8, n_rays=32, max_step_count=30, seed=4)
+    _run(cfg, [m], np.zeros(8, np.int32), ticks=40, rng=np.random.default_rng(1), auto_reset=True)
+
+
 @pytest.mark.parametrize("wpb", [1, 2, 4, 8, 16])
 def test_every_workgroup_size_gives_the_same_bits(wpb, monkeypatch):
     """The waves of a workgroup share ray chunks and physics steps through LDS counters; the workgroup size is

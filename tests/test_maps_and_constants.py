@@ -144,3 +144,43 @@ def test_presets_and_roster_overrides():
     sq = Map(bundled_map_path("squarinth"))
     assert sq.cops_positions == [(350, 350), (300, 300)] and sq.thieves_positions == [(450, 330)]
     assert set(sq.agent_spawn_regions) == {"cop_0", "cop_1", "thief_0"} and len(sq.agent_spawn_regions["thief_0"]) == 4
+
+
+def _star_junction(tmp_path, arms):
+    """`arms` thin walls meeting at one point: an agent circle at the hub overlaps the bounding box of every one of them."""
+    import json, math
+    hub = (300.0, 300.0)
+    blocks = []
+    for q in range(arms):
+        a = 2 * math.pi * q / arms
+        dx, dy = math.cos(a), math.sin(a)
+        p0 = (hub[0] + 3 * dx, hub[1] + 3 * dy)
+        p1 = (hub[0] + 120 * dx, hub[1] + 120 * dy)
+        blocks.append({"type": "poly", "vs": [{"x": p0[0] - dy, "y": p0[1] + dx}, {"x": p1[0] - dy, "y": p1[1] + dx},
+                                              {"x": p1[0] + dy, "y": p1[1] - dx}, {"x": p0[0] + dy, "y": p0[1] - dx}]})
+    agents = [{"type": "cop", "x": 50, "y": 50}, {"type": "cop", "x": 80, "y": 50}, {"type": "thief", "x": 50, "y": 550}]
+    f = tmp_path / f"star{arms}.json"
+    f.write_text(json.dumps({"window": {"w_px": 640, "h_px": 640}, "canvas": {"w": 640, "h": 640}, "objects": {"blocks": blocks},
+                             "agents": agents}))
+    return Map(f).compile()
+
+
+def test_contact_cache_is_sized_against_the_map_at_create(tmp_path):
+    """CAT_WALL_CACHE = 8 cached wall contacts per agent.  The bound held against it -- the most wall bbs one agent circle's bb can
+    overlap at once -- is computed from the map at create time (library: cat_map_wall_bb_depth_host / cat_create; oracle:
+    cato_create), so a 9-wall star junction is refused up front instead of dropping a contact at run time.  The five maps need
+    at most 5."""
+    from as_cops_and_thieves_amd import _native as nat
+    from as_cops_and_thieves_amd.config import SimConfig
+    from oracle.cat_oracle import OracleSim
+    import ctypes as C
+    lib = C.CDLL(str(nat.LIB_PATH))                     # host-only entry point: no torch / device needed
+    lib.cat_map_wall_bb_depth_host.argtypes = [C.c_void_p, C.c_size_t, C.c_double]
+    depth = lambda cm: lib.cat_map_wall_bb_depth_host(cm.to_blob(), len(cm.to_blob()), 5.0)
+    assert {n: depth(load_preset(n).compile()) for n in ("agh-map", "grandbyrinth", "labyrinth", "lbirinth", "squarinth")} == \
+        {"agh-map": 5, "grandbyrinth": 2, "labyrinth": 3, "lbirinth": 2, "squarinth": 2}
+    ok, bad = _star_junction(tmp_path, 8), _star_junction(tmp_path, 9)
+    assert depth(ok) == 8 and depth(bad) == 9
+    OracleSim(SimConfig(n_envs=2, n_rays=16), [ok])
+    with pytest.raises(RuntimeError, match="9 walls at once"):
+        OracleSim(SimConfig(n_envs=2, n_rays=16), [bad])
