@@ -5,11 +5,11 @@ from .config import SimConfig  # noqa: F401
 from .maps import CompiledMap, Map, load_preset, bundled_map_path  # noqa: F401
 
 __all__ = ["ObjectType", "PhysicalParams", "SensorParams", "SpaceParams", "load_physical_params", "SimConfig",
-           "CompiledMap", "Map", "load_preset", "bundled_map_path", "BaseEnv", "SimpleEnv", "VecCopsEnv", "CatSim"]
+           "CompiledMap", "Map", "load_preset", "bundled_map_path", "BaseEnv", "SimpleEnv", "VecCopsEnv", "raw_env", "CatSim"]
 
 
 def __getattr__(name):  # torch-dependent parts are imported lazily
-    if name in ("BaseEnv", "SimpleEnv", "VecCopsEnv"):
+    if name in ("BaseEnv", "SimpleEnv", "VecCopsEnv", "raw_env"):
         from . import environments
         return getattr(environments, name)
     if name == "CatSim":

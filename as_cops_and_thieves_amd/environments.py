@@ -251,6 +251,18 @@ class SimpleEnv(BaseEnv):
         return info
 
 
+def raw_env(map: Map, render_mode: str = "rgb_array", **kw):
+    """reference ``raw_env`` (base_env.py:555-569): the single env wrapped for PettingZoo's AEC API with
+    ``pettingzoo.utils.conversions.parallel_to_aec``.  Needs pettingzoo (the conversion is its code, not restated here): without
+    it an ImportError says so.  ``kw`` goes to ``BaseEnv`` (device, num_rays, ...)."""
+    try:
+        from pettingzoo.utils.conversions import parallel_to_aec
+    except ImportError as exc:
+        raise ImportError("raw_env() returns pettingzoo's AEC wrapper of BaseEnv and needs the pettingzoo package "
+                          "(BaseEnv / SimpleEnv / VecCopsEnv work without it)") from exc
+    return parallel_to_aec(BaseEnv(map=map, render_mode=render_mode, **kw))
+
+
 class VecCopsEnv:
     """Batched env: ``num_envs`` independent envs advanced in lock-step on one GPU.
 

@@ -117,3 +117,51 @@ class LSTMValue(_Recurrent):
     def forward(self, x, state, starts=None):
         out, state = self.recur(x, state, starts)
         return self.value_head(out).squeeze(-1), state   # values [B, T]
+
+
+class Policy(nn.Module):
+    """The reference's non-recurrent policy (``src/models/policy_net.py:9-45``): the same conv trunk, then ``net`` 256->128->64->4.
+    Input ``[B, 2R]`` in the sorted-key layout of ``packing.pack_policy_input``; output: logits ``[B, 4]``."""
+
+    def __init__(self, num_rays: int, num_actions: int = 4):
+        super().__init__()
+        self.num_rays = num_rays
+        self.features_extractor = nn.Sequential(
+            nn.Conv1d(2, 64, kernel_size=5, stride=2), nn.ReLU(),
+            nn.Conv1d(64, 32, kernel_size=5, stride=3), nn.ReLU(),
+            nn.Flatten(), nn.Linear(32 * conv_out_len(num_rays), 256), nn.Tanh())
+        self.net = nn.Sequential(nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, num_actions))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.net(self.features_extractor(x.view(x.size(0), 2, self.num_rays)))
+
+
+class Value(nn.Module):
+    """The reference's non-recurrent critic (``src/models/value_net.py:8-34``): an MLP over the WHOLE flattened shared state
+    (``packing.pack_value_input``: every agent's four ray channels and team positions), 512-256-128-64-1."""
+
+    def __init__(self, num_observations: int):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(num_observations, 512), nn.ReLU(), nn.Linear(512, 256), nn.ReLU(),
+                                 nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 1))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.net(x)
+
+
+def state_width(num_agents: int, n_cops: int, num_rays: int) -> int:
+    """Width of ``packing.pack_value_input``: per agent four ray channels and the f16 positions of its team (x, y each)."""
+    n_thieves = num_agents - n_cops
+    return sum(4 * num_rays + 2 * (n_cops if i < n_cops else n_thieves) for i in range(num_agents))
+
+
+def initialize_models_for_mappo(possible_agents, num_rays: int, n_cops: int, device="cpu") -> dict:
+    """``src/utils/model_utils.py:45-77``: ``{agent: {"policy": Policy, "value": Value}}`` (no torch.compile: the reference
+    wraps them when available, which changes no parameter)."""
+    width = state_width(len(possible_agents), n_cops, num_rays)
+    return {a: {"policy": Policy(num_rays).to(device), "value": Value(width).to(device)} for a in possible_agents}
+
+
+def initialize_lstm_models_for_mappo(possible_agents, num_rays: int, device="cpu") -> dict:
+    """``src/utils/model_utils.py:80-121``: the recurrent pair the reference's drivers use (orchestration.py:52,121)."""
+    return {a: {"policy": LSTMPolicy(num_rays).to(device), "value": LSTMValue(num_rays).to(device)} for a in possible_agents}

@@ -220,3 +220,24 @@ def test_full_size_other_baseline_configs(label, names, cops, thieves, N):
             cpu.reset(mask=c["terminated"].copy())
         assert np.array_equal(cpu.get_state()["pos"][0], s1["pos"][k].cpu().numpy()), (label, k)
         assert np.array_equal(cpu.out["obs_distance"][0].view(np.uint16), o1["obs_distance"][k].cpu().numpy().view(np.uint16)), (label, k)
+
+
+def test_raw_env_is_the_aec_wrapper_of_the_single_env():
+    """reference base_env.py:555-569: raw_env = parallel_to_aec(BaseEnv(map)).  pettingzoo's conversion is used as is; this
+    image has no pettingzoo, where raw_env must say so instead of returning something else."""
+    from as_cops_and_thieves_amd import load_preset, raw_env
+    try:
+        import pettingzoo  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="pettingzoo"):
+            raw_env(load_preset("squarinth"), device="cuda:0")
+        pytest.skip("pettingzoo is not installed: the AEC path itself cannot run here")
+    env = raw_env(load_preset("squarinth"), device="cuda:0", num_rays=16)
+    env.reset(seed=0)
+    seen = []
+    for agent in env.agent_iter(max_iter=9):              # three rounds of the three agents, in roster order
+        obs, rew, term, trunc, info = env.last()
+        seen.append(agent)
+        env.step(None if term or trunc else 1)
+    assert seen[:3] == ["cop_0", "cop_1", "thief_0"] and set(obs) == {"distance", "object_type"}
+    env.close()

@@ -363,3 +363,27 @@ def test_rollout_of_several_bptt_windows_trains_on_window_sequences():
         assert torch.equal(rl.start[:, sl], tr._start_buf[w * 4:(w + 1) * 4])
         assert torch.equal(rl.p0[0][:, :, sl], h_at_window_1[0][w]) and torch.equal(rl.v0[1][:, :, sl], rl.v0w[1][w])
     assert float(rl.steps.max()) == 2                                # 1 epoch x 2 minibatches
+
+
+def test_non_recurrent_pair_and_the_two_model_initialisers():
+    """src/models/policy_net.py:9-45, value_net.py:8-34 and src/utils/model_utils.py:45-121: the non-recurrent Policy / Value with
+    the reference's attribute names (features_extractor + net; net), fed with the packed layouts of packing.py."""
+    from as_cops_and_thieves_amd import packing
+    from as_cops_and_thieves_amd.selfplay.models import (Policy, Value, initialize_lstm_models_for_mappo, initialize_models_for_mappo,
+                                                         state_width)
+    env = _env()
+    obs, _ = env.reset()
+    state = env.state()
+    agents, R, nc = env.possible_agents, 16, env.nc
+    models = initialize_models_for_mappo(agents, R, nc)
+    assert set(models) == set(agents) and all(set(m) == {"policy", "value"} for m in models.values())
+    pol, val = models["cop_0"]["policy"], models["thief_0"]["value"]
+    assert isinstance(pol, Policy) and isinstance(val, Value)
+    assert [n for n, _ in pol.named_children()] == ["features_extractor", "net"] and [n for n, _ in val.named_children()] == ["net"]
+    logits = pol(packing.pack_policy_input(obs["cop_0"]))
+    vin = packing.pack_value_input(state)
+    assert vin.shape[1] == state_width(len(agents), nc, R) == val.net[0].in_features     # the critic sees the WHOLE shared state
+    assert logits.shape == (env.num_envs, 4) and val(vin).shape == (env.num_envs, 1)
+    assert [m.out_features for m in val.net if isinstance(m, torch.nn.Linear)] == [512, 256, 128, 64, 1]
+    rec = initialize_lstm_models_for_mappo(agents, R)
+    assert isinstance(rec["cop_1"]["policy"], LSTMPolicy) and isinstance(rec["cop_1"]["value"], LSTMValue)
