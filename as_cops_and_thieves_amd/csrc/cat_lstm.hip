@@ -81,7 +81,10 @@ __global__ __launch_bounds__(NWT *LANES, 2) void lstm_seq_fwd_kernel(const cat_l
                     wf[gt][hh][ks] = *(const bf16x8 *)(wg + (size_t)(gt * H + 16 * HHT * w + 16 * hh + r) * H + 32 * ks + 8 * q);
     }
     constexpr bool save = SAVE;
-    bf16x4 bias[4][HHT];                                     // kept packed: registers are what limits this kernel to two per CU
+    // The summed gate biases: in registers in the training instantiation; in LDS in the inference one (a rollout tick), whose 128
+    // registers of W_hh fragments + accumulators left 8 values spilled to scratch at the 256 registers two workgroups per CU allow.
+    bf16x4 bias[SAVE ? 4 : 1][SAVE ? HHT : 1];
+    __shared__ __attribute__((aligned(16))) __bf16 sbias[SAVE ? 4 : 4 * H];
 #pragma unroll
     for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
@@ -90,7 +93,9 @@ __global__ __launch_bounds__(NWT *LANES, 2) void lstm_seq_fwd_kernel(const cat_l
             f32x4 bsum = a.bias ? widen(*(const bf16x4 *)((const __bf16 *)a.bias + (size_t)g * a.sb_g + gt * H + hid0 + 16 * hh))
                                 : f32x4{0.f, 0.f, 0.f, 0.f};
             if (a.bias2) bsum += widen(*(const bf16x4 *)((const __bf16 *)a.bias2 + (size_t)g * a.sb2_g + gt * H + hid0 + 16 * hh));
-            bias[gt][hh] = narrow(bsum);           // one rounding of the sum, as the bf16 addition of the two vectors gives
+            // one rounding of the sum, as the bf16 addition of the two vectors gives
+            if constexpr (SAVE) bias[gt][hh] = narrow(bsum);
+            else if (r == 0) *(bf16x4 *)&sbias[gt * H + hid0 + 16 * hh] = narrow(bsum);   // the 16 sequence rows of a lane group hold the same units
         }
     // a workgroup takes the 16-sequence blocks blk, blk + gridDim.x, ...: one each in training (the grid covers them), several
     // when there are more blocks than the device holds at once (a rollout tick of thousands of envs) -- W_hh is loaded once
@@ -155,7 +160,10 @@ __global__ __launch_bounds__(NWT *LANES, 2) void lstm_seq_fwd_kernel(const cat_l
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt)
 #pragma unroll
-            for (int hh = 0; hh < HHT; ++hh) acc[gt][hh] = widen(xn[gt][hh]) + widen(bias[gt][hh]);
+            for (int hh = 0; hh < HHT; ++hh) {
+                if constexpr (SAVE) acc[gt][hh] = widen(xn[gt][hh]) + widen(bias[gt][hh]);
+                else acc[gt][hh] = widen(xn[gt][hh]) + widen(*(const bf16x4 *)&sbias[gt * H + hid0 + 16 * hh]);
+            }
         const float kn = kn_next;
         // The next step's loads must be ISSUED after this step's values have been waited for: hoisted above the lines before
         // (as the scheduler does), the wait for xn also waits for the loads just issued, and every step of the chain sits out

@@ -154,6 +154,27 @@ def _dist_ready() -> bool:
     return dist.get_world_size() > 1 or os.environ.get("CAT_FORCE_ALLREDUCE") == "1"
 
 
+def advantage_moments(adv: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-agent mean and (unbiased) standard deviation of ``adv`` [G, T, N] over the WHOLE batch: with data-parallel ranks, over
+    every rank's shard -- what one process holding all envs would normalise with (skrl: per agent, whole memory).  Two passes, as
+    ``Tensor.std``: the mean first, then the squared deviations from it.  One rank: exactly ``adv.mean`` / ``adv.std``."""
+    import torch.distributed as dist
+    if not (_dist_ready() and dist.get_world_size() > 1):
+        return adv.mean(dim=(1, 2), keepdim=True), adv.std(dim=(1, 2), keepdim=True)
+
+    def total(t):
+        if dist.get_backend() == "gloo" and t.is_cuda:
+            host = t.cpu(); dist.all_reduce(host); return host.to(t.device)
+        dist.all_reduce(t)
+        return t
+    n_local = float(adv.shape[1] * adv.shape[2])
+    m1 = total(torch.stack([adv.sum(dim=(1, 2), dtype=torch.float64),
+                            torch.full((adv.shape[0],), n_local, dtype=torch.float64, device=adv.device)]))
+    n, mean64 = m1[1], m1[0] / m1[1]
+    dev2 = total(((adv.double() - mean64.view(-1, 1, 1)) ** 2).sum(dim=(1, 2)))
+    return mean64.float().view(-1, 1, 1), (dev2 / (n - 1)).sqrt().float().view(-1, 1, 1)
+
+
 class RoleLearner:
     """G agents that share one ``RoleConfig`` -- the agents of a role, or of both roles when the roles are configured
     alike (the reference's driver: ``CFG_AGENT`` for everyone) -- as stacked policy + value networks over one flat
@@ -352,22 +373,7 @@ class RoleLearner:
         else:
             adv, ret = compute_gae(b["rew"], b["val"], dones, last_values, cfg.discount_factor, cfg.gae_lambda)
             b["ret"].copy_(ret)
-        if _dist_ready():   # data-parallel ranks: the statistics of the WHOLE batch, as one process holding every shard would use
-            import torch.distributed as dist
-            n_local = adv.shape[1] * adv.shape[2]
-            mom = torch.stack([adv.sum(dim=(1, 2), dtype=torch.float64), (adv.double() ** 2).sum(dim=(1, 2)),
-                               torch.full((adv.shape[0],), float(n_local), dtype=torch.float64, device=adv.device)])
-            if dist.get_backend() == "gloo" and mom.is_cuda:
-                host = mom.cpu(); dist.all_reduce(host); mom = host.to(adv.device)
-            else:
-                dist.all_reduce(mom)
-            n = mom[2]
-            mean64 = mom[0] / n
-            var64 = ((mom[1] - n * mean64 ** 2) / (n - 1)).clamp_min(0.0)                 # unbiased, as Tensor.std
-            mean, std = mean64.float().view(-1, 1, 1), var64.sqrt().float().view(-1, 1, 1)
-        else:
-            mean = adv.mean(dim=(1, 2), keepdim=True)
-            std = adv.std(dim=(1, 2), keepdim=True)
+        mean, std = advantage_moments(adv)
         b["adv"].copy_((adv - mean) / (std + 1e-8))                                     # skrl: per agent, whole memory
         if self.W == 1:
             self.start = starts

@@ -237,9 +237,10 @@ def main() -> None:
     ap.add_argument("--map", default="labyrinth")
     ap.add_argument("--cops", type=int, default=2)
     ap.add_argument("--thieves", type=int, default=1)
-    ap.add_argument("--burn-in", type=int, default=400, help="untimed ticks after the reset and BEFORE the warm-up: one episode length, "
-                    "so that a short timed region (the driver's --steps 20 --warmup 5) does not measure the cold start of 4096 "
-                    "synchronised fresh episodes but the running batch, auto-resets included")
+    ap.add_argument("--burn-in", type=int, default=600, help="untimed ticks after the reset and BEFORE the warm-up: one and a half episode "
+                    "lengths, so that a short timed region (the driver's --steps 20 --warmup 5) sees the batch in the middle of an episode, "
+                    "agents spread over the map, and not the ticks after a reset (every env of a random-action labyrinth batch times out at "
+                    "tick 400 together: 400 would land on the next reset); kernel time there = the whole-episode average (DESIGN 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE shapes (the `extra` object)")
     args = ap.parse_args()

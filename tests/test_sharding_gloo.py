@@ -77,3 +77,42 @@ def test_two_rank_shards_equal_one_batch():
     assert np.array_equal(pos, sim.get_state()["pos"]) and np.array_equal(obs, out["obs_distance"])
     assert all(g[4] == 2.0 for g in got)          # MAX over ranks
     assert all(g[5] == total * ticks for g in got)  # whole-job env-steps
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _adv_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+    from as_cops_and_thieves_amd.selfplay.mappo import advantage_moments
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    gen = torch.Generator().manual_seed(7)
+    full = torch.randn(3, 16, 64, generator=gen) * torch.tensor([1.0, 5.0, 0.1]).view(3, 1, 1) + torch.tensor([0.0, 2.0, -1.0]).view(3, 1, 1)
+    shard = full[:, :, rank * 32:(rank + 1) * 32].contiguous()           # env shards: the N axis
+    mean, std = advantage_moments(shard)
+    q.put((rank, mean.flatten().tolist(), std.flatten().tolist(), full.mean(dim=(1, 2)).tolist(), full.std(dim=(1, 2)).tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_ranks_normalise_advantages_with_the_whole_batch_statistics():
+    """with env shards on several ranks the advantage mean / std must be those of the WHOLE batch (what one process with
+    all envs computes), not rank-local ones: two gloo ranks, half the envs each."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_adv_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    for rank, mean, std, want_mean, want_std in res:
+        assert np.allclose(mean, want_mean, rtol=1e-6, atol=1e-7) and np.allclose(std, want_std, rtol=1e-6), rank
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]            # every rank uses the same numbers
