@@ -130,6 +130,22 @@ template <int TA, int TR, int TC> struct FixDims {
     static __device__ __forceinline__ constexpr int hot_bytes(const Params &) { return kHotBytes; }
 };
 
+// Which form of the ray fan an instantiation carries: 0 = fan_chunk (one 64-ray chunk of one agent per work unit: any map),
+// 1 = fan_group (the agents of a group per unit, only the rays that have a candidate on the lanes: maps whose rays meet few walls).
+template <class Base, int F> struct WithFan : Base { static constexpr int kFan = F; };
+// fan_group: agents per work unit (their rays fill at most four 64-ray chunks)
+template <class D> __device__ __forceinline__ int group_agents(const Params &p)
+{
+    const int cpa = (D::R(p) + 63) / 64;
+    return cpa == 1 ? 4 : (cpa == 2 ? 2 : 1);
+}
+// ray-fan work units of an env slot
+template <class D> __device__ __forceinline__ int fan_units(const Params &p)
+{
+    if constexpr (D::kFan == 1) { const int g = group_agents<D>(p); return (D::A(p) + g - 1) / g; }
+    else return D::A(p) * ((D::R(p) + 63) / 64);
+}
+
 // Diagnostic build only (-DCAT_PHASE_TIMING): per-phase shader-clock totals, summed over waves
 // into a debug buffer no other kernel code reads.  The shipped library is built without it.
 #ifdef CAT_PHASE_TIMING
@@ -295,10 +311,15 @@ struct Lds {
     const double *rayd;  // [R][2]  ray offsets (workgroup-shared)
     int *acell, *anear;     // [A], [A][2]  grid cell and "origin inside" wall ids per agent
     int *dk0, *dcnt;        // [A*A]  ray cone (start, count | near << 16) of agent j seen from agent i
+    int *adn;               // [A]    bit j: the origin of agent i lies within the ray radius of agent j's cached circle
     // ray-fan scratch (overlays the contact arrays: disjoint phases)
     double *itbb, *ialpha;  // [kItemCap] per item: BBTree gate value, hit alpha (2.0 = none)
     unsigned short *itm;    // [kItemCap] in: ray lane | id << 6   out: id << 6 | feature
     unsigned short *itemidx;  // [kPassJ][64] item index of (candidate position, ray lane)
+    // fan_group only (light maps): the rays of an agent group that have any candidate, compacted
+    unsigned long long *arow; // [kGroupRays] the active ray's packed candidate row
+    unsigned char *alist;     // [kGroupRays] the active ray: chunk slot of the group << 6 | lane
+    unsigned char *adyn;      // [kGroupRays] its cone mask of the other agents
     unsigned short *od;  // [A*R]
     unsigned char *ot;   // [A*R]
     double *spawn;  // [8A] reset: spawn points [2A]; every kernel: pre-step pos[2A] tc[2A] leaf[4A] snapshot
@@ -457,6 +478,9 @@ __device__ __forceinline__ double poly_point_distance(const Lds &L, int sh, doub
 constexpr int kFeatNear = 63;       // alpha = 0 hit ([CP cpShapeSegmentQuery] start-inside rule)
 constexpr int kItemCap = 160;       // live items per pass (a sweep over 160..224 x 8..12 positions was flat)
 constexpr int kPassJ = 8;           // candidate positions per ray per pass
+constexpr int kFanBytes = 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;   // itbb, ialpha, itm, itemidx
+constexpr int kGroupRays = 256;     // fan_group: rays of one agent group (<= 4 chunks)
+constexpr int kGroupBytes = kGroupRays * (8 + 1 + 1);
 
 // [CP cpPolyShapeSegmentQuery] returning (alpha, feature): plane i -> i, bevel of vertex i -> count + i.
 // Planes overwrite unconditionally, bevels replace on strictly smaller alpha; tracking both separately
@@ -712,6 +736,10 @@ __device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, i
         }
         my_dk0 = k0; my_dcnt = cnt | (near << 16);
     }
+    {
+        const unsigned long long nearbits = __ballot((my_dcnt >> 16) & 1);   // lane i * A + j
+        if (lane < A) L.adn[lane] = (int)((nearbits >> (lane * A)) & ((1ull << A) - 1ull));
+    }
     if (lane < A) { L.acell[lane] = my_cell; L.anear[2 * lane] = my_near0; L.anear[2 * lane + 1] = my_near1; L.dmin[lane] = 0x10000u; }
     if (lane < A * A) { L.dk0[lane] = my_dk0; L.dcnt[lane] = my_dcnt; }
     wave_sync();
@@ -908,6 +936,209 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
             dmin = o2 < dmin ? o2 : dmin;
         }
         if (lane == 0 && dmin < 0x10000u) __hip_atomic_fetch_min(&L.dmin[i], dmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// The ray fan of an agent GROUP (work unit g: agents g * gsz ..., at most four 64-ray chunks in all), for maps whose rays meet few
+// walls -- on the labyrinth 38 of the 64 rays of a chunk have no candidate wall at all, and chunk by chunk every phase still runs
+// over all 64 lanes.  Here the rays are first sorted out with lane = ray (packed row loaded, candidate count, cone mask of the other
+// agents): a ray without a candidate gets its EMPTY observation at once, the others go into a compact list; then rounds of 64
+// ACTIVE rays run the position-major fan of fan_chunk with the origin, the "inside" walls and the roster side per lane.
+// Requires (cat_create): every candidate list fits one packed row word, shape ids S + A fit 6 bits, R <= kGroupRays.
+template <class D>
+__device__ void fan_group(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, int env, int lane,
+                          int S, float cmax, int rew_mode, int g, PhaseClock &pc)
+{
+    const int A = D::A(p), R = D::R(p);
+    const double r2 = p.ray_radius;
+    const unsigned d_empty = f64_to_f16(p.ray_length);  // np.full(R, ray_length, float16) entity.py:200
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int cpa = (R + kLanes - 1) / kLanes;   // chunks per agent
+    const int gsz = group_agents<D>(p), i0 = g * gsz, i1 = (i0 + gsz < A) ? i0 + gsz : A;
+    const int gate = launder(uni(p.gate)), n_cops = launder(uni(D::n_cops(p)));
+    const double wall_r = launder(p.wall_r), rc = launder(p.rc);
+    const int my_cell = lane < A ? L.acell[lane] : -1;
+    const int my_dk0 = lane < A * A ? L.dk0[lane] : 0, my_dcnt = lane < A * A ? L.dcnt[lane] : 0;
+    // ---- lane = ray: the packed rows of the group's chunks (all requested before the first is looked at), then the sorting
+    const int nslots = (i1 - i0) * cpa;          // <= 4
+    unsigned long long wrow[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++) {
+        if (sl < nslots) {
+            const int i = i0 + sl / cpa, k = (sl % cpa) * kLanes + lane;
+            const int cell = __builtin_amdgcn_readlane(my_cell, i);
+            const size_t r = (cell < 0 || k >= R) ? 0 : (size_t)cell * R + k;
+            wrow[sl] = G(p.grid_rows)[gd.row_base + r];
+        }
+    }
+    int n_act = 0;
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++) {
+        if (sl < nslots) {
+            const int i = i0 + sl / cpa, k = (sl % cpa) * kLanes + lane;
+            const int cell = __builtin_amdgcn_readlane(my_cell, i);
+            const bool in = k < R;
+            const int cnt_w = (in && cell >= 0) ? (int)(wrow[sl] & 0xFF) : 0;
+            unsigned dynmask = 0;
+            if (in)
+                for (int j = 0; j < A; j++) {
+                    if (j == i) continue;
+                    const int dc = __builtin_amdgcn_readlane(my_dcnt, i * A + j) & 0xFFFF, dk = __builtin_amdgcn_readlane(my_dk0, i * A + j);
+                    int rel = k - dk; if (rel < 0) rel += R;
+                    if (rel < dc) dynmask |= 1u << j;
+                }
+            const bool act = cnt_w != 0 || dynmask != 0u;
+            const unsigned long long m = __ballot(act);
+            if (act) {
+                const int a = n_act + __popcll(m & lt_mask);
+                L.alist[a] = (unsigned char)((sl << 6) | lane);
+                L.arow[a] = wrow[sl];
+                L.adyn[a] = (unsigned char)dynmask;
+            } else if (in) {   // nothing along this ray: its observation is final
+                const int q = i * R + k;
+                L.od[q] = (unsigned short)d_empty;
+                L.ot[q] = (unsigned char)CAT_EMPTY;
+                if (la.out.hit_shape) la.out.hit_shape[(size_t)env * A * R + q] = -1;  // parity/debug only
+            }
+            n_act += __popcll(m);
+        }
+    }
+    n_act = uni(n_act);
+    wave_sync();
+    PHASE(pc, 20);
+    // ---- rounds of 64 active rays
+    for (int r0 = 0; r0 < n_act; r0 += kLanes) {
+        const bool on = r0 + lane < n_act;
+        const int gr = on ? (int)L.alist[r0 + lane] : 0;
+        const int sl = gr >> 6;
+        const int i = i0 + (cpa == 1 ? sl : (cpa == 2 ? (sl >> 1) : 0));          // this lane's agent
+        const int k = (sl - (i - i0) * cpa) * kLanes + (gr & 63);                    // ... and ray
+        const double2 org = *reinterpret_cast<const double2 *>(L.fpos + 2 * i);     // fresh body.position (entity.py:186)
+        const double ax = org.x, ay = org.y;
+        const int near0 = L.anear[2 * i], near1 = L.anear[2 * i + 1];
+        const unsigned dnear_mask = (unsigned)L.adn[i];
+        const unsigned long long w0 = on ? L.arow[r0 + lane] : 0ull;
+        const unsigned dynmask = on ? (unsigned)L.adyn[r0 + lane] : 0u;
+        const int cnt_w = (int)(w0 & 0xFF);
+        const int cnt = cnt_w + __popc(dynmask);
+        double rdx, rdy, rix, riy;
+        {
+            const double bx = ax + L.rayd[2 * k], by = ay + L.rayd[2 * k + 1];  // entity.py:191-193
+            rdx = bx - ax; rdy = by - ay; rix = 1.0 / rdx; riy = 1.0 / rdy;
+        }
+        double best_a = 1.0;
+        int best_fi = -1;   // id << 6 | feature of the accepted item
+        int jj0 = 0;
+        while (__ballot(cnt > jj0) != 0ull) {
+            // ---- pack the items (ray, jj) for jj in [jj0, jj1) j-major
+            int n_items = 0, jj = jj0;
+            for (; jj < jj0 + kPassJ; jj++) {
+                const bool has = cnt > jj;
+                if (__ballot(has) == 0ull) break;
+                int id = 0;
+                double tbb = 0.0;
+                if (has) {
+                    if (jj < cnt_w) id = (int)((w0 >> (8 * (jj + 1))) & 0xFF);      // jj < 7: the row word holds the whole list
+                    else {
+                        unsigned dj = dynmask;
+                        for (int q = jj - cnt_w; q > 0; q--) dj &= dj - 1;
+                        id = S + __builtin_ctz(dj);
+                    }
+                    // the BBTree gate value, by the ray's own lane.  A candidate whose t_bb is not below the
+                    // ray's best alpha NOW can never be visited (best only decreases): it gets no item.
+                    if (gate) tbb = bb_segment_query((id < S) ? (L.bb + kBB * id) : (L.fleaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy);
+                }
+                const bool live = has && tbb < best_a;
+                const unsigned long long m = __ballot(live);
+                const int c = __popcll(m);
+                if (n_items + c > kItemCap) break;
+                int t = 0xFFFF;
+                if (live) {
+                    t = n_items + __popcll(m & lt_mask);
+                    L.itm[t] = (unsigned short)(lane | (id << 6) | ((i - i0) << 12));
+                    L.itbb[t] = tbb;
+                }
+                L.itemidx[(jj - jj0) * kLanes + lane] = (unsigned short)t;
+                n_items += c;
+            }
+            const int jj1 = jj;
+            wave_sync();
+            PHASE(pc, 5);
+            // ---- one item per lane
+            for (int t0 = 0; t0 < n_items; t0 += kLanes) {
+                const int t = t0 + lane;
+                if (t < n_items) {
+                    const int d = L.itm[t];
+                    const int il = d & 63, id = (d >> 6) & 63, ia = i0 + (d >> 12);
+                    const int g2 = L.alist[r0 + il];
+                    const int k2 = ((g2 >> 6) - (ia - i0) * cpa) * kLanes + (g2 & 63);
+                    const double2 o2 = *reinterpret_cast<const double2 *>(L.fpos + 2 * ia);
+                    const double cbx = o2.x + L.rayd[2 * k2], cby = o2.y + L.rayd[2 * k2 + 1];
+                    double alpha = 2.0;   // 2.0 = no hit (never below a best alpha <= 1)
+                    int feat = 0;
+                    {
+                        const bool wall = id < S;
+                        const int j = wall ? 0 : id - S;
+                        const bool inside = wall ? (id == L.anear[2 * ia] || id == L.anear[2 * ia + 1]) : ((((unsigned)L.adn[ia] >> j) & 1u) != 0u);
+                        if (inside) { alpha = 0.0; feat = kFeatNear; }
+                        else {   // an accepted circle hit at alpha == 1 could never beat the initial best of 1: "t < 1" is equivalent
+                            int f;
+                            poly_query_feat(L, cmax, wall, wall ? id : 0, wall ? wall_r : rc, L.ftc[2 * j], L.ftc[2 * j + 1], o2.x, o2.y, cbx, cby, r2, alpha, f);
+                            feat = f < 0 ? 0 : f;
+                        }
+                    }
+                    L.ialpha[t] = alpha; L.itm[t] = (unsigned short)((id << 6) | feat);
+                }
+            }
+            wave_sync();
+            PHASE(pc, 6);
+            // ---- each ray walks its own items in index order
+            for (int q = jj0; q < jj1; q++) {
+                const int t = cnt > q ? (int)L.itemidx[(q - jj0) * kLanes + lane] : 0xFFFF;
+                if (t != 0xFFFF) {
+                    const double al = L.ialpha[t];
+                    if (al < best_a && L.itbb[t] < best_a) { best_a = al; best_fi = L.itm[t]; }   // t_exit == best alpha
+                }
+            }
+            wave_sync();
+            PHASE(pc, 7);
+            jj0 = jj1;
+        }
+        // ---- hit point -> f16 distance and class (entity.py:200-215, :222-241)
+        unsigned d16 = d_empty, ty = CAT_EMPTY;
+        int best = -1;
+        if (best_fi >= 0) {
+            const double bx = ax + L.rayd[2 * k], by = ay + L.rayd[2 * k + 1];
+            best = best_fi >> 6;
+            const int f = best_fi & 63;
+            const double t = best_a;
+            double px = bx, py = by;  // alpha = 0 hits keep the segment end as their point
+            if (f != kFeatNear) {
+                const bool wall = best < S;
+                const int fc = wall ? L.fc[best] : 0, first = fc & 0xFFFF, count = fc >> 16;
+                if (wall && f < count) {
+                    const double2 n = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + f));
+                    px = (ax * (1.0 - t) + bx * t) - n.x * r2;
+                    py = (ay * (1.0 - t) + by * t) - n.y * r2;
+                } else {   // corner circle of the hull or the agent's circle: the same formula around a different centre
+                    double2 v = *reinterpret_cast<const double2 *>(L.planes + 8 * (first + (wall ? f - count : 0)) + 2);
+                    if (!wall) { v.x = L.ftc[2 * (best - S)]; v.y = L.ftc[2 * (best - S) + 1]; }
+                    circle_hit_point(v.x, v.y, ax, ay, bx, by, t, r2, px, py);
+                }
+            }
+            d16 = obs_distance_f16(px, py, ax, ay);
+            ty = (best < S) ? CAT_WALL : ((best - S) >= n_cops ? CAT_THIEF : CAT_COP);
+        }
+        if (on) {  // observations go to LDS; one coalesced burst to HBM at the write-back
+            const int q = i * R + k;
+            L.od[q] = (unsigned short)d16;
+            L.ot[q] = (unsigned char)ty;
+            if (la.out.hit_shape) la.out.hit_shape[(size_t)env * A * R + q] = best;  // parity/debug only
+            const unsigned want = i < n_cops ? CAT_THIEF : CAT_COP;
+            // min over the agent's rays (other groups / rounds add theirs); non-negative f16: bit order = value order
+            if (rew_mode && ty == want) __hip_atomic_fetch_min(&L.dmin[i], d16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        PHASE(pc, 8);
     }
 }
 
@@ -1364,7 +1595,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     d = reinterpret_cast<double *>(w + D::rec_bytes(p));
     L.spawn = d; L.fpos = d; L.ftc = d + 2 * A; L.fleaf = d + 4 * A; d += 8 * A;
     int *iv = reinterpret_cast<int *>(d);
-    L.acell = iv; iv += A; L.anear = iv; iv += 2 * A; L.dk0 = iv; iv += A * A; L.dcnt = iv; iv += A * A;
+    L.acell = iv; iv += A; L.anear = iv; iv += 2 * A; L.dk0 = iv; iv += A * A; L.dcnt = iv; iv += A * A; L.adn = iv; iv += A;
     L.dmin = reinterpret_cast<unsigned *>(iv); iv += A;
     L.flags = iv; iv += 4;
     {   // output staging, every array 16-byte aligned
@@ -1383,6 +1614,9 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.ialpha = L.itbb + kItemCap;
     L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
     L.itemidx = L.itm + kItemCap;
+    L.arow = reinterpret_cast<unsigned long long *>(u + kFanBytes);
+    L.alist = reinterpret_cast<unsigned char *>(L.arow + kGroupRays);
+    L.adyn = L.alist + kGroupRays;
     return L;
 }
 
@@ -1527,7 +1761,7 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
                                           const GridDesc &gd, char *smem, int wave, int lane, int tick, PhaseClock &pc)
 {
     const int W = p.wpb, S = md.S;
-    const int nchunks = D::A(p) * ((D::R(p) + kLanes - 1) / kLanes);
+    const int nchunks = fan_units<D>(p);
     // fetched now, used at the write-back: the reward lookup then costs one global round trip, not two
     GAS const float *cop_lut = launder(G(p.cop_lut)), *thief_lut = launder(G(p.thief_lut));
     unsigned fin_mask = 0u;
@@ -1562,7 +1796,11 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         const Lds Ls = carve<D>(p, smem, md, slot, wave);
         int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
         while (c <= last_unit) {
-            if (c < nchunks) fan_chunk<D>(Ls, p, la, gd, e_s, lane, S, md.cmax, tick, c, pc);   // entity.py:143-144, base_env.py:388-390 / :334-344
+            const int unit = c;
+            if (unit < nchunks) {   // entity.py:143-144, base_env.py:388-390 / :334-344
+                if constexpr (D::kFan == 1) fan_group<D>(Ls, p, la, gd, e_s, lane, S, md.cmax, tick, unit, pc);
+                else fan_chunk<D>(Ls, p, la, gd, e_s, lane, S, md.cmax, tick, unit, pc);
+            }
             else {
                 PHASE(pc, 9);
                 physics_env<D>(Ls, p, S, lane, pc);                                // base_env.py:392
@@ -1645,7 +1883,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
     stage_map<D>(p, smem, md);   // ends with the workgroup barrier
     PHASE(pc, 0);
     const int S = md.S, A = D::A(p);
-    const int nchunks = A * ((D::R(p) + kLanes - 1) / kLanes);
+    const int nchunks = fan_units<D>(p);
     const bool has = env >= 0;
     int captured = 0, timeout = 0, step = 0;
     if (has) {
@@ -1746,7 +1984,7 @@ __device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const 
     copy_snapshot(L, A, lane);   // fresh positions, stale circle caches and leaf bbs (Q1); overwrites the spawn points
     agent_setup<D>(L, p, gd, lane);                                  // :334-344 (setup part)
     if (lane == 0) { L.flags[0] = 0; L.flags[1] = 0; L.flags[2] = 0; L.flags[3] = (int)rc; }  // :350
-    publish_slot(L, wave, lane, A * ((D::R(p) + kLanes - 1) / kLanes));
+    publish_slot(L, wave, lane, fan_units<D>(p));
 }
 
 // _get_non_colliding_position + Entity.reset for every agent of the env in L (base_env.py:313-332, 123-166;
@@ -1997,15 +2235,20 @@ static void finalize_rows(GridHost &g)
 // Kernel instantiations: fixed dimensions for the rosters / ray counts of the BASELINE configurations and of the
 // reference's defaults, the generic one for everything else (CAT_GENERIC_KERNEL=1 forces it: A/B tests).
 using KernelFn = void (*)(const Params *, const LaunchArgs);
-template <class D> static void kernels_of(KernelFn &tick, KernelFn &reset) { tick = tick_kernel<D>; reset = reset_kernel<D>; }
-static const char *select_kernels(int A, int R, int n_cops, KernelFn &tick, KernelFn &reset)
+template <class D> static void kernels_of(int fan, KernelFn &tick, KernelFn &reset)
+{
+    if (fan == 1) { tick = tick_kernel<WithFan<D, 1>>; reset = reset_kernel<WithFan<D, 1>>; }
+    else { tick = tick_kernel<WithFan<D, 0>>; reset = reset_kernel<WithFan<D, 0>>; }
+}
+// fan: 0 = chunk by chunk, 1 = agent groups with compacted rays (cat_create decides from the maps; CAT_FAN=chunks forces 0)
+static const char *select_kernels(int A, int R, int n_cops, int fan, KernelFn &tick, KernelFn &reset)
 {
     const char *e = getenv("CAT_GENERIC_KERNEL");
     const bool generic = e && atoi(e) != 0;
-    if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(tick, reset); return "3 agents (2 cops), 64 rays"; }
-    if (!generic && A == 3 && n_cops == 2 && R == 90) { kernels_of<FixDims<3, 90, 2>>(tick, reset); return "3 agents (2 cops), 90 rays"; }
-    if (!generic && A == 5 && n_cops == 3 && R == 64) { kernels_of<FixDims<5, 64, 3>>(tick, reset); return "5 agents (3 cops), 64 rays"; }
-    kernels_of<DynDims>(tick, reset);
+    if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(fan, tick, reset); return "3 agents (2 cops), 64 rays"; }
+    if (!generic && A == 3 && n_cops == 2 && R == 90) { kernels_of<FixDims<3, 90, 2>>(fan, tick, reset); return "3 agents (2 cops), 90 rays"; }
+    if (!generic && A == 5 && n_cops == 3 && R == 64) { kernels_of<FixDims<5, 64, 3>>(fan, tick, reset); return "5 agents (3 cops), 64 rays"; }
+    kernels_of<DynDims>(fan, tick, reset);
     return "generic";
 }
 
@@ -2014,18 +2257,18 @@ struct LdsSizes {
     int map, env, uni;
     size_t total(int wpb) const { return (size_t)map + 16 * (size_t)wpb + (size_t)wpb * ((size_t)env + (size_t)uni); }
 };
-static LdsSizes lds_sizes(int A, int R, int maxS, int maxP)
+static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, bool group_fan)
 {
     auto up = [](int x, int a) { return (x + a - 1) / a * a; };
     const int NP = A * (A - 1) / 2, NPs = NP > 0 ? NP : 1, maxc = A * kK + NP;
     LdsSizes z;
     z.map = up((kBB * maxS + kGeoPerPlane * maxP) * 8 + maxS * 4, 16) + 16 * R;
     const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
-    const int fan_bytes = 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;
+    const int fan_bytes = kFanBytes + (group_fan ? kGroupBytes : 0);
     z.uni = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 16);
     const int rec_bytes = 96 * A + 16 + ((A * kK + NPs) * 8 + (2 * A * kK + NPs) * 4 + 15) / 16 * 16;
     int eb = rec_bytes + 8 * A * 8;                                // record, spawn/snapshot
-    eb += (3 * A + 2 * A * A + A + 4) * 4;                         // acell, anear, dk0, dcnt, dmin, flags
+    eb += (3 * A + 2 * A * A + A + A + 4) * 4;                     // acell, anear, dk0, dcnt, adn, dmin, flags
     eb = up(eb, 16) + up(A * R * 2, 16) + up(A * R, 16) + up(2 * R * 2, 16) + up(2 * R, 16);   // output staging
     z.env = up(eb, 16);
     return z;
@@ -2169,8 +2412,24 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
             return CAT_ERR_BAD_SLOT_MAP;
         }
     }
+    // ---- spatial-hash grids per map (cell size: CAT_GRID_CELL px, default 16); their longest candidate list picks the ray fan
+    GridHost grid_host;
+    {
+        double cell = 16.0;
+        if (const char *e = getenv("CAT_GRID_CELL")) { double v = atof(e); if (v >= 4.0 && v <= 512.0) cell = v; }
+        const double reach = cfg->ray_length + cfg->ray_radius + 1e-3;
+        const double m_ray = cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6;
+        for (int m = 0; m < n_maps; m++)
+            build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, cfg->n_rays, tab->ray_dx, tab->ray_dy, reach, m_ray,
+                        cfg->agent_radius + 1e-6, cell, grid_host);
+        finalize_rows(grid_host);
+    }
+    // Rays that meet few walls (every list fits one packed row word, ids and agents fit 6 bits, an agent's rays fit four chunks):
+    // the group form of the ray fan, which compacts the rays that have any candidate across the agents of a group.  Else chunk by chunk.
+    int fan = (grid_host.max_row <= 7 && maxS + A <= 63 && cfg->n_rays <= kGroupRays) ? 1 : 0;
+    if (const char *e = getenv("CAT_FAN")) { if (!strcmp(e, "chunks")) fan = 0; }
     // ---- LDS carve sizes (must match carve()) and the workgroup size
-    LdsSizes ls = lds_sizes(A, cfg->n_rays, maxS, maxP);
+    LdsSizes ls = lds_sizes(A, cfg->n_rays, maxS, maxP, fan == 1);
     int wpb = 0;
     {   // waves (= env slots) per workgroup.  Most resident waves per CU first (cap 16 = 4 per SIMD at <= 128 VGPRs);
         // among equals a launch of at most two rounds takes the LARGEST workgroup (its waves share ray chunks, which
@@ -2265,15 +2524,8 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     TRY_ALLOC(dev_alloc(s, const_cast<MapDesc **>(&p.maps), descs.size(), descs.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<double **>(&p.geo_f64), geo_f.size(), geo_f.data()));
     TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.geo_i32), geo_i.size(), geo_i.data()));
-    {   // spatial-hash grids per map (cell size: CAT_GRID_CELL px, default 16)
-        double cell = 16.0;
-        if (const char *e = getenv("CAT_GRID_CELL")) { double v = atof(e); if (v >= 4.0 && v <= 512.0) cell = v; }
-        const double reach = cfg->ray_length + cfg->ray_radius + 1e-3;
-        const double m_ray = cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6;
-        for (int m = 0; m < n_maps; m++)
-            build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, p.R, tab->ray_dx, tab->ray_dy, reach, m_ray,
-                        cfg->agent_radius + 1e-6, cell, s->grid);
-        finalize_rows(s->grid);
+    {
+        s->grid = std::move(grid_host);
         p.row_words = s->grid.row_words;
         TRY_ALLOC(dev_alloc(s, const_cast<GridDesc **>(&p.grids), s->grid.desc.size(), s->grid.desc.data()));
         TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.grid_rows), s->grid.rows.size(), s->grid.rows.data()));
@@ -2315,7 +2567,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     p.lds_map_bytes = ls.map; p.lds_env_bytes = ls.env; p.lds_union_bytes = ls.uni; p.wpb = wpb;
     s->wpb = wpb;
     s->lds_bytes = ls.total(wpb);
-    s->kernel_variant = select_kernels(A, p.R, p.n_cops, s->tick_fn, s->reset_fn);
+    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, s->tick_fn, s->reset_fn);
     if (s->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->tick_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);

@@ -75,6 +75,19 @@ def test_step_parity_injected_positions(name, rays):
     assert stats["done"] > 0          # timeouts reached (and rewards/winner paths exercised)
 
 
+@pytest.mark.parametrize("name,rays", [("labyrinth", 64), ("squarinth", 90)])
+def test_chunk_form_of_the_ray_fan_on_the_light_maps(name, rays, monkeypatch):
+    """cat_create picks the form of the ray fan from the maps: rays that meet few walls (all but the agh-map) -> agent groups with
+    the candidate-less rays sorted out first (fan_group); else one 64-ray chunk per work unit (fan_chunk).  The other parity tests
+    therefore run fan_group on the four small maps and fan_chunk on the agh-map and on the mixed batches; this one forces
+    fan_chunk on small maps (CAT_FAN=chunks), so that each form is held against the oracle on each kind of map."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    monkeypatch.setenv("CAT_FAN", "chunks")
+    cfg = SimConfig(n_envs=32, n_rays=rays, max_step_count=40, seed=17)
+    stats = _run(cfg, [compiled(name)], np.zeros(32, np.int32), ticks=60, rng=np.random.default_rng(2), auto_reset=True)
+    assert stats["done"] >= 32
+
+
 def test_contacts_and_captures_are_exercised():
     from as_cops_and_thieves_amd.config import SimConfig
     rng = np.random.default_rng(3)
