@@ -172,7 +172,7 @@ def test_cops_learn_to_catch_random_thieves_on_squarinth():
         tr.collect(); tr.update()
     after = cop_win_rate()
     print(f"cop win rate against random thieves on squarinth: {before:.3f} -> {after:.3f} after 1000 updates ({1000 * 128 * 512 / 1e6:.0f} M env-steps)")
-    assert before < 0.16 and after > 0.20
+    assert before < 0.16 and after > 0.24     # 0.299 and 0.39 after 1000 updates with two builds of round 3 / round 2
     assert env._sim.device_errors() == 0           # no out-of-range action, no dropped contact in 66 M env-steps
     env.close(); ev.close()
 
