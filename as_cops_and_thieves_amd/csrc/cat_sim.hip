@@ -133,11 +133,14 @@ template <int TA, int TR, int TC> struct FixDims {
 // Which form of the ray fan an instantiation carries: 0 = fan_chunk (one 64-ray chunk of one agent per work unit: any map),
 // 1 = fan_group (the agents of a group per unit, only the rays that have a candidate on the lanes: maps whose rays meet few walls).
 template <class Base, int F> struct WithFan : Base { static constexpr int kFan = F; };
-// fan_group: agents per work unit (their rays fill at most four 64-ray chunks)
+// fan_group: agents per work unit
 template <class D> __device__ __forceinline__ int group_agents(const Params &p)
 {
+    // Two agents per unit when their rays fill at most four chunks: compaction across the pair (two cops in the open: ~40 active
+    // rays of 128 -> one round) while a slot still has several units for the waves of the workgroup to share.  (All three agents of
+    // a 2v1 roster in ONE unit: 40.3 us against 37.9 on the labyrinth x4096; one agent per unit: 42.0.)
     const int cpa = (D::R(p) + 63) / 64;
-    return cpa == 1 ? 4 : (cpa == 2 ? 2 : 1);
+    return cpa <= 2 ? 2 : 1;
 }
 // ray-fan work units of an env slot
 template <class D> __device__ __forceinline__ int fan_units(const Params &p)
