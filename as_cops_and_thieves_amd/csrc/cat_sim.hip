@@ -320,9 +320,9 @@ struct Lds {
     unsigned short *itm;    // [kItemCap] in: ray lane | id << 6   out: id << 6 | feature
     unsigned short *itemidx;  // [kPassJ][64] item index of (candidate position, ray lane)
     // fan_group only (light maps): the rays of an agent group that have any candidate, compacted
-    unsigned long long *arow; // [kGroupRays] the active ray's packed candidate row
-    unsigned char *alist;     // [kGroupRays] the active ray: chunk slot of the group << 6 | lane
-    unsigned char *adyn;      // [kGroupRays] its cone mask of the other agents
+    unsigned long long *arow; // [rays of a group] the active ray's packed candidate row
+    unsigned char *alist;     // [rays of a group] the active ray: chunk slot of the group << 6 | lane
+    unsigned char *adyn;      // [rays of a group] its cone mask of the other agents
     unsigned short *od;  // [A*R]
     unsigned char *ot;   // [A*R]
     double *spawn;  // [8A] reset: spawn points [2A]; every kernel: pre-step pos[2A] tc[2A] leaf[4A] snapshot
@@ -482,8 +482,7 @@ constexpr int kFeatNear = 63;       // alpha = 0 hit ([CP cpShapeSegmentQuery] s
 constexpr int kItemCap = 160;       // live items per pass (a sweep over 160..224 x 8..12 positions was flat)
 constexpr int kPassJ = 8;           // candidate positions per ray per pass
 constexpr int kFanBytes = 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;   // itbb, ialpha, itm, itemidx
-constexpr int kGroupRays = 256;     // fan_group: rays of one agent group (<= 4 chunks)
-constexpr int kGroupBytes = kGroupRays * (8 + 1 + 1);
+constexpr int kGroupRays = 256;     // fan_group: most rays of one agent (R) it is built for; a group holds <= 4 chunks
 
 // [CP cpPolyShapeSegmentQuery] returning (alpha, feature): plane i -> i, bevel of vertex i -> count + i.
 // Planes overwrite unconditionally, bevels replace on strictly smaller alpha; tracking both separately
@@ -1618,8 +1617,9 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
     L.itemidx = L.itm + kItemCap;
     L.arow = reinterpret_cast<unsigned long long *>(u + kFanBytes);
-    L.alist = reinterpret_cast<unsigned char *>(L.arow + kGroupRays);
-    L.adyn = L.alist + kGroupRays;
+    const int grays = group_agents<D>(p) * ((D::R(p) + 63) / 64) * 64;   // rays of one agent group: what the arrays are sized for
+    L.alist = reinterpret_cast<unsigned char *>(L.arow + grays);
+    L.adyn = L.alist + grays;
     return L;
 }
 
@@ -2267,7 +2267,8 @@ static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, bool group_fan)
     LdsSizes z;
     z.map = up((kBB * maxS + kGeoPerPlane * maxP) * 8 + maxS * 4, 16) + 16 * R;
     const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
-    const int fan_bytes = kFanBytes + (group_fan ? kGroupBytes : 0);
+    const int cpa = (R + 63) / 64;
+    const int fan_bytes = kFanBytes + (group_fan ? (cpa <= 2 ? 2 : 1) * cpa * 64 * (8 + 1 + 1) : 0);   // group_agents() x cpa x 64 rays
     z.uni = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 16);
     const int rec_bytes = 96 * A + 16 + ((A * kK + NPs) * 8 + (2 * A * kK + NPs) * 4 + 15) / 16 * 16;
     int eb = rec_bytes + 8 * A * 8;                                // record, spawn/snapshot
