@@ -2416,10 +2416,10 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
             return CAT_ERR_BAD_SLOT_MAP;
         }
     }
-    // ---- spatial-hash grids per map (cell size: CAT_GRID_CELL px, default 16); their longest candidate list picks the ray fan
+    // ---- spatial-hash grids per map (cell size: CAT_GRID_CELL px, default 8); their longest candidate list picks the ray fan
     GridHost grid_host;
     {
-        double cell = 16.0;
+        double cell = 8.0;   // 16 -> 8 px: lists 15 % shorter, tables 2 - 4 x larger (labyrinth 39 MB, agh-map 66 MB), kernel 2 - 3 % faster
         if (const char *e = getenv("CAT_GRID_CELL")) { double v = atof(e); if (v >= 4.0 && v <= 512.0) cell = v; }
         const double reach = cfg->ray_length + cfg->ray_radius + 1e-3;
         const double m_ray = cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6;
@@ -2798,7 +2798,7 @@ extern "C" int cat_grid_build_host(const cat_config *cfg, const cat_tables *tab,
     cat_grid_host *gh = new cat_grid_host();
     gh->R = cfg->n_rays;
     build_grids(f.data() + 2, S, cfg->n_rays, tab->ray_dx, tab->ray_dy, cfg->ray_length + cfg->ray_radius + 1e-3,
-                cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6, cfg->agent_radius + 1e-6, cell > 0 ? cell : 16.0, gh->g);
+                cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6, cfg->agent_radius + 1e-6, cell > 0 ? cell : 8.0, gh->g);
     finalize_rows(gh->g);
     *out = gh;
     return CAT_OK;

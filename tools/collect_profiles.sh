@@ -10,7 +10,6 @@ out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --no-cpu-baseline --no-extras > $out/bench_under_rocprof.json 2> $out/trace.err
-python3 bench.py > $out/bench.json 2> $out/bench.err
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
          "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
@@ -29,6 +28,7 @@ head -4 $out/trace/t_kernel_stats.csv > profiles/${tag}_final_kernel_stats.csv
 python3 tools/pmc_summary.py --last 25 $out/pmc*/p_counter_collection.csv > profiles/${tag}_final_pmc_summary.txt
 python3 tools/pmc_summary.py $out/reset*/p_counter_collection.csv > profiles/${tag}_pmc_from_reset.txt
 python3 tools/make_traffic_json.py $tag > /dev/null
+python3 bench.py > $out/bench.json 2> $out/bench.err     # after the passes: the line replays the traffic figure just collected
 grep -v amdgpu.ids $out/bench.json | tail -1 > profiles/${tag}_final_bench.json
 grep -v amdgpu.ids $out/bench_under_rocprof.json | tail -1 > profiles/${tag}_final_bench_under_rocprof.json
 cp profiles/${tag}_* $out/
