@@ -2459,6 +2459,9 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     }
     // ---- work list: workgroups are map-homogeneous; env slots grouped by map, padded with -1
     std::vector<int> work, block_map;
+    int helpers = 0;   // CAT_HELPERS (diagnostic): that many waves of every workgroup own no env slot and only take work units
+    if (const char *e = getenv("CAT_HELPERS")) { helpers = atoi(e); if (helpers < 0 || helpers >= wpb) helpers = 0; }
+    const int epb = wpb - helpers;
     for (int m = 0; m < n_maps; m++) {
         int cnt = 0;
         for (int e = 0; e < N; e++)
@@ -2466,6 +2469,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
                 if (cnt % wpb == 0) block_map.push_back(m);
                 work.push_back(e);
                 cnt++;
+                if (cnt % wpb == epb) for (int h = 0; h < helpers; h++) { work.push_back(-1); cnt++; }
             }
         while (cnt % wpb) { work.push_back(-1); cnt++; }
     }
