@@ -41,6 +41,9 @@ from .stacked import (FlatParams, StackedNet, adam_state_dict, agent_state_dict,
 @dataclasses.dataclass
 class RoleConfig:
     """skrl MAPPO agent configuration of one role (``src/configs/mappo_config.py:5-50``)."""
+    rollouts: int = 4096                   # mappo_config.py:8: ticks of the (single) env per update.  The trainer's rollout length is
+                                           # ``TrainerConfig.horizon`` (default 128 ticks of thousands of envs); pass horizon=cfg.rollouts
+                                           # for the reference's own setting (tests/test_gpu_mappo.py runs it at 32 envs)
     learning_epochs: int = 4
     mini_batches: int = 4
     discount_factor: float = 0.99          # skrl MAPPO_DEFAULT_CONFIG

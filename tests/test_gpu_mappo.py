@@ -302,3 +302,27 @@ def test_critics_run_per_window_after_the_rollout_give_the_tick_by_tick_values()
     assert float((a["val"] - b["val"]).abs().max()) <= 3e-2 * max(scale, 1.0)
     for x, y in zip(a["v_state"] + a["v0w"], b["v_state"] + b["v0w"]):
         assert float((x.float() - y.float()).abs().max()) <= 2.0 ** -6 * max(1.0, float(x.float().abs().max()))   # two bf16 ulps of the largest cell state
+
+
+def test_the_reference_rollout_length_of_4096_ticks_is_reachable():
+    """mappo_config.py:8 `rollouts = 4096`: one PPO update per 4096 ticks of the env.  The build's default is 128-tick rollouts of
+    thousands of envs (the rollout buffers are [agents, ticks, envs, ...]); the reference's own setting runs too, at the env counts
+    where it fits: 32 envs x 4096 ticks = 256 BPTT windows of 16 per env, 8192 training sequences, the 4 x 4 minibatch schedule of
+    CFG_AGENT, statistics finite, the policies moved."""
+    import torch
+    from as_cops_and_thieves_amd import VecCopsEnv, load_preset
+    from as_cops_and_thieves_amd.selfplay.mappo import CFG_AGENT, MAPPOTrainer, TrainerConfig
+    import dataclasses
+    env = VecCopsEnv(load_preset("squarinth"), num_envs=32, num_rays=64, max_step_count=400, seed=5)
+    rc = dataclasses.replace(CFG_AGENT, random_timesteps=0, learning_starts=0)
+    assert rc.rollouts == 4096
+    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(horizon=rc.rollouts, policy_freeze_duration=0, opponent_freeze_duration=0,
+                                                                  graph_rollout=False), seed=2)
+    before = {a: tr.agent_models(a)["policy"]["policy_head.4.weight"].clone() for a in tr.agents}
+    tr.collect(); tr.update()
+    torch.cuda.synchronize()
+    st = tr.read_stats()
+    assert tr.timestep == 4096 and all(torch.isfinite(torch.tensor(v)) for v in st.values()), st
+    assert all(not torch.equal(before[a], tr.agent_models(a)["policy"]["policy_head.4.weight"]) for a in tr.agents)
+    assert env._sim.device_errors() == 0
+    env.close()
