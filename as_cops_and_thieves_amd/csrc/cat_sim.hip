@@ -479,7 +479,8 @@ __device__ __forceinline__ double poly_point_distance(const Lds &L, int sh, doub
 // order with [CP cpSpaceSegmentQueryFirst]'s sequential rule "visit iff t_bb < best alpha so far, accept
 // iff alpha < best": identical to visiting every shape one after the other.
 constexpr int kFeatNear = 63;       // alpha = 0 hit ([CP cpShapeSegmentQuery] start-inside rule)
-constexpr int kItemCap = 160;       // live items per pass (a sweep over 160..224 x 8..12 positions was flat)
+constexpr int kItemCap = 128;       // live items per pass: two FULL 64-lane rounds of shape queries (160: a third round of 32; agh-map 110.0 -> 107.1 us;
+                                    // 96 and 64 are slower again: 112)
 constexpr int kPassJ = 8;           // candidate positions per ray per pass
 constexpr int kFanBytes = 2 * kItemCap * 8 + kItemCap * 2 + kPassJ * kLanes * 2;   // itbb, ialpha, itm, itemidx
 constexpr int kGroupRays = 256;     // fan_group: most rays of one agent (R) it is built for; a group holds <= 4 chunks
