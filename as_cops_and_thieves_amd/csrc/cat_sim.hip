@@ -44,7 +44,14 @@ constexpr int kK = CAT_WALL_CACHE;
 #endif
 constexpr int kBB = CAT_BB_DOUBLES;     // doubles per wall bb record in LDS: 4 used (l b r t); 6 (48 B) for the same reason
 constexpr int kP32F = CAT_P32_FLOATS;   // floats per f32 plane record: 8 used; 12 (48 B) spreads 16 lanes' b128 reads over all 64 banks
-constexpr int kGeoPerPlane = 8 + kP32F / 2;   // doubles of LDS geometry per plane: the f64 record + the f32 record
+constexpr int kGeoPerPlane = 8 + kP32F / 2;   // doubles of LDS geometry per plane: the f64 record + the f32 record (CAT_EDGE_PAIRS == 0)
+#ifndef CAT_EDGE_PAIRS
+#define CAT_EDGE_PAIRS 1
+#endif
+// CAT_EDGE_PAIRS: the f32 records of TWO consecutive hull edges interleaved component by component (pre-classification on packed
+// f32 arithmetic, v_pk_*_f32: one instruction for both edges).  20 floats (80 B) per pair: 14 used, and 16 lanes reading 16
+// different records with ds_read_b128 still cover all 64 banks.  [nx0 nx1 ny0 ny1 | c0 c1 dtMin0 dtMin1 | dtMax0 dtMax1 vx0 vx1 | vy0 vy1 - - | pad]
+constexpr int kPairF = 20;
 constexpr unsigned kBlobMagic = 0x31544143u;
 
 struct MapDesc {
@@ -52,7 +59,7 @@ struct MapDesc {
     int f64_off;   // into geo_f64: [bb 4S][planes 8P][planes32 (kP32F/2) P][start 2A][regions 4Rg]
     int i32_off;   // into geo_i32: [first S][count S][region_off A+1]
     float cmax;    // max over the planes of |dot(v0, n) + wall radius + ray radius| (error bound of the f32 pre-classification)
-    int pad1;
+    int PP;        // edge-pair records (sum over the walls of ceil(edges / 2)); 0 when CAT_EDGE_PAIRS == 0
 };
 
 // Spatial-hash grids, built once per (map, ray table) on the host (build_grids):
@@ -69,6 +76,9 @@ struct GridDesc {
     int crow_base, pad2;        // into cgrid_rows (one packed 8-byte row per cell)
     int row_base, pad1;         // into grid_rows, in rows of Params::row_words words
 };
+
+// doubles of geometry after the wall bbs: the f64 plane records, then the f32 records
+__host__ __device__ inline int geo_rest_doubles(const MapDesc &md) { return CAT_EDGE_PAIRS ? 8 * md.P + (kPairF / 2) * md.PP : kGeoPerPlane * md.P; }
 
 struct BlockDesc { MapDesc md; GridDesc gd; };   // per workgroup: one load instead of block_map -> maps / grids
 
@@ -297,6 +307,7 @@ struct Lds {
     const double *planes;  // [P][8]
     const float *p32;      // [P][kP32F] f32 copy for the conservative pre-classification: n.x n.y c dtMin | dtMax v0.x v0.y - | pad
     const int *fc;         // [S] first plane | plane count << 16
+    const int *fp;         // [S] first edge-pair record of the wall (CAT_EDGE_PAIRS)
     // per env slot
     double *pos, *vel, *vb, *tc, *leaf;  // [A][2] x4, [A][4]
     const double *fpos, *ftc, *fleaf;    // what the ray fan reads: the tick-start snapshot of pos / tc / leaf
@@ -516,6 +527,37 @@ __device__ __forceinline__ void poly_query_feat(const Lds &L, float cmax, bool w
     const bool bevels = rsum > 0.0;
     unsigned pm = 0u, vm = wall ? 0u : 1u;
     const double *pl0 = L.planes + 8 * first;
+#if CAT_EDGE_PAIRS
+    {   // two edges per iteration on packed f32 arithmetic (the pair records interleave the two edges' components)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const float *q = L.p32 + kPairF * (wall ? L.fp[sh] : 0);
+        const f32x2 ax2 = {axf, axf}, ay2 = {ayf, ayf}, dx2 = {dxf, dxf}, dy2 = {dyf, dyf};
+        const f32x2 len3 = {3.0f * len, 3.0f * len}, four = {4.0f, 4.0f};
+        for (int i = 0; i < count; i += 2, q += kPairF) {
+            const float4 r0 = *reinterpret_cast<const float4 *>(q);        // n.x n.x' n.y n.y'
+            const float4 r1 = *reinterpret_cast<const float4 *>(q + 4);    // c c' dtMin dtMin'
+            const float4 r2 = *reinterpret_cast<const float4 *>(q + 8);    // dtMax dtMax' v0.x v0.x'
+            const float2 r3 = *reinterpret_cast<const float2 *>(q + 12);   // v0.y v0.y'
+            const f32x2 nx = {r0.x, r0.y}, ny = {r0.z, r0.w}, cc = {r1.x, r1.y}, vx = {r2.z, r2.w}, vy = {r3.x, r3.y};
+            const f32x2 d = __builtin_elementwise_fma(ay2, ny, ax2 * nx) - cc;
+            const f32x2 den = -__builtin_elementwise_fma(dy2, ny, dx2 * nx);
+            // where the crossing point falls along the face (skipped for a ray almost parallel to it: ill-conditioned)
+            const f32x2 ri = {__builtin_amdgcn_rcpf(fmaxf(den.x, 0.25f)), __builtin_amdgcn_rcpf(fmaxf(den.y, 0.25f))};
+            const f32x2 t = d * ri;
+            const f32x2 ptx = __builtin_elementwise_fma(t, dx2, ax2), pty = __builtin_elementwise_fma(t, dy2, ay2);
+            const f32x2 dt = __builtin_elementwise_fma(nx, pty, -(ny * ptx));
+            const f32x2 e2 = e1 * __builtin_elementwise_fma(len3, ri, four);
+            const bool f0 = (d.x >= -e1) && (d.x <= den.x + e1) && ((den.x < 0.25f) || ((dt.x >= r1.z - e2.x) && (dt.x <= r2.x + e2.x)));
+            const bool f1 = (d.y >= -e1) && (d.y <= den.y + e1) && ((den.y < 0.25f) || ((dt.y >= r1.w - e2.y) && (dt.y <= r2.y + e2.y)));
+            pm |= ((unsigned)f0 | ((unsigned)f1 << 1)) << i;
+            const f32x2 ex = vx - ax2, ey = vy - ay2;
+            const f32x2 cr = __builtin_elementwise_fma(dx2, ey, -(dy2 * ex)), sp = __builtin_elementwise_fma(dx2, ex, dy2 * ey);
+            const bool v0 = bevels && !(fabsf(cr.x) > thr) && (sp.x >= s_lo) && (sp.x <= s_hi);
+            const bool v1 = bevels && !(fabsf(cr.y) > thr) && (sp.y >= s_lo) && (sp.y <= s_hi);
+            vm |= ((unsigned)v0 | ((unsigned)v1 << 1)) << i;
+        }
+    }
+#else
     {
         const float *q = L.p32 + kP32F * first;
         for (int i = 0; i < count; i++, q += kP32F) {
@@ -538,6 +580,7 @@ __device__ __forceinline__ void poly_query_feat(const Lds &L, float cmax, bool w
             vm |= (unsigned)(bevels && !(fabsf(cr) > thr) && (sp >= s_lo) && (sp <= s_hi)) << i;
         }
     }
+#endif
     double pa = 1.0, va = 1.0;
     int pf = -1, vf = -1;
     while (pm) {   // exact face test
@@ -1579,7 +1622,8 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.bb = reinterpret_cast<const double *>(smem);
     L.planes = L.bb + kBB * S;
     L.p32 = reinterpret_cast<const float *>(L.planes + 8 * P);
-    L.fc = reinterpret_cast<const int *>(L.planes + kGeoPerPlane * P);
+    L.fc = reinterpret_cast<const int *>(L.planes + geo_rest_doubles(md));
+    L.fp = L.fc + S;
     L.rayd = reinterpret_cast<const double *>(smem + p.lds_map_bytes - 16 * D::R(p));
     L.ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
     char *w = smem + p.lds_map_bytes + 16 * W + slot * p.lds_env_bytes;
@@ -1627,7 +1671,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
 template <class D>
 __device__ __forceinline__ void stage_map(const Params &p, char *smem, const MapDesc &md)
 {
-    const int nrest = kGeoPerPlane * md.P, nf = kBB * md.S + nrest;      // doubles of geometry in LDS
+    const int nrest = geo_rest_doubles(md), nf = kBB * md.S + nrest;      // doubles of geometry in LDS
     double *dst = reinterpret_cast<double *>(smem);
     GAS const double *src = G(p.geo_f64) + md.f64_off;
     {   // wall bbs: 32-byte records in memory, kBB doubles apart in LDS (16-byte copies)
@@ -1653,7 +1697,10 @@ __device__ __forceinline__ void stage_map(const Params &p, char *smem, const Map
     }
     int *di = reinterpret_cast<int *>(dst + nf);
     GAS const int *si = G(p.geo_i32) + md.i32_off;
-    for (int i = threadIdx.x; i < md.S; i += blockDim.x) di[i] = si[i] | (si[md.S + i] << 16);
+    for (int i = threadIdx.x; i < md.S; i += blockDim.x) {
+        di[i] = si[i] | (si[md.S + i] << 16);
+        di[md.S + i] = si[2 * md.S + md.A + 1 + i];        // first edge-pair record
+    }
     double *rd = reinterpret_cast<double *>(smem + p.lds_map_bytes - 16 * D::R(p));
     for (int i = threadIdx.x; i < D::R(p); i += blockDim.x) { rd[2 * i] = G(p.ray_dx)[i]; rd[2 * i + 1] = G(p.ray_dy)[i]; }
     __syncthreads();
@@ -1998,7 +2045,7 @@ __device__ __forceinline__ void spawn_and_reset(const Lds &L, const Params &p, c
                                                 int env, unsigned rc, int lane)
 {
     const int S = md.S, A = D::A(p);
-    GAS const double *start = G(p.geo_f64) + md.f64_off + 4 * md.S + kGeoPerPlane * md.P;
+    GAS const double *start = G(p.geo_f64) + md.f64_off + 4 * md.S + geo_rest_doubles(md);
     GAS const double *regions = start + 2 * md.A;
     GAS const int *region_off = G(p.geo_i32) + md.i32_off + 2 * md.S;
 
@@ -2261,12 +2308,13 @@ struct LdsSizes {
     int map, env, uni;
     size_t total(int wpb) const { return (size_t)map + 16 * (size_t)wpb + (size_t)wpb * ((size_t)env + (size_t)uni); }
 };
-static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, bool group_fan)
+static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool group_fan)
 {
     auto up = [](int x, int a) { return (x + a - 1) / a * a; };
     const int NP = A * (A - 1) / 2, NPs = NP > 0 ? NP : 1, maxc = A * kK + NP;
     LdsSizes z;
-    z.map = up((kBB * maxS + kGeoPerPlane * maxP) * 8 + maxS * 4, 16) + 16 * R;
+    const int rest = CAT_EDGE_PAIRS ? 8 * maxP + (kPairF / 2) * maxPP : kGeoPerPlane * maxP;
+    z.map = up((kBB * maxS + rest) * 8 + 2 * maxS * 4, 16) + 16 * R;
     const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
     const int cpa = (R + 63) / 64;
     const int fan_bytes = kFanBytes + (group_fan ? (cpa <= 2 ? 2 : 1) * cpa * 64 * (8 + 1 + 1) : 0);   // group_agents() x cpa x 64 rays
@@ -2348,7 +2396,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     std::vector<MapDesc> descs((size_t)n_maps);
     std::vector<double> geo_f;
     std::vector<int> geo_i;
-    int maxS = 0, maxP = 0;
+    int maxS = 0, maxP = 0, maxPP = 0;
     for (int m = 0; m < n_maps; m++) {
         const unsigned char *b = static_cast<const unsigned char *>(blobs[m]);
         int32_t h[16];
@@ -2383,30 +2431,54 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         d.f64_off = (int)geo_f.size();
         const size_t n_geo = 4 * (size_t)d.S + 8 * (size_t)d.P;
         geo_f.insert(geo_f.end(), f.begin() + 2, f.begin() + 2 + n_geo);  // drop window w,h: [bb][planes]
+        std::vector<int> first_pair((size_t)d.S, 0);
         {   // f32 copy of the plane records for the ray fan's conservative pre-classification (poly_query_feat)
             const double rsum = cfg->wall_radius + cfg->ray_radius;
             const double *pl = f.data() + 2 + 4 * (size_t)d.S;
-            std::vector<float> p32(kP32F * (size_t)d.P, 0.0f);
             float cmax = 0.0f;
-            for (int q = 0; q < d.P; q++) {
+            auto rec8 = [&](int q, float *o) {   // n.x n.y c dtMin | dtMax v0.x v0.y -
                 const double *r = pl + 8 * (size_t)q;   // n.x n.y v0.x v0.y dot(v0,n) dtMin dtMax -
-                float *o = p32.data() + kP32F * (size_t)q;
                 o[0] = (float)r[0]; o[1] = (float)r[1]; o[2] = (float)(r[4] + rsum); o[3] = (float)r[5];
                 o[4] = (float)r[6]; o[5] = (float)r[2]; o[6] = (float)r[3];
                 cmax = std::fmax(cmax, std::fabs(o[2]));
+            };
+#if CAT_EDGE_PAIRS
+            std::vector<float> prs;
+            int pp = 0;
+            for (int sidx = 0; sidx < d.S; sidx++) {
+                const int first = iv[sidx], count = iv[d.S + sidx];
+                first_pair[sidx] = pp;
+                for (int e = 0; e < count; e += 2, pp++) {
+                    float a[8] = {0}, b[8] = {0.f, 0.f, 1e30f, 1e30f, -1e30f, 1e18f, 1e18f, 0.f};   // b: an edge nothing can reach
+                    rec8(first + e, a);
+                    if (e + 1 < count) rec8(first + e + 1, b);
+                    const float rec[kPairF] = {a[0], b[0], a[1], b[1], a[2], b[2], a[3], b[3], a[4], b[4], a[5], b[5], a[6], b[6], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    prs.insert(prs.end(), rec, rec + kPairF);
+                }
             }
-            d.cmax = cmax;
+            d.PP = pp;
+            const size_t at = geo_f.size();
+            geo_f.resize(at + (kPairF / 2) * (size_t)pp);
+            memcpy(geo_f.data() + at, prs.data(), prs.size() * sizeof(float));
+#else
+            std::vector<float> p32(kP32F * (size_t)d.P, 0.0f);
+            for (int q = 0; q < d.P; q++) rec8(q, p32.data() + kP32F * (size_t)q);
+            d.PP = 0;
             const size_t at = geo_f.size();
             geo_f.resize(at + (kP32F / 2) * (size_t)d.P);
             memcpy(geo_f.data() + at, p32.data(), p32.size() * sizeof(float));
+#endif
+            d.cmax = cmax;
         }
         geo_f.insert(geo_f.end(), f.begin() + 2 + n_geo, f.end());        // [start][regions]
         d.i32_off = (int)geo_i.size();
         geo_i.insert(geo_i.end(), iv.begin(), iv.end());
+        geo_i.insert(geo_i.end(), first_pair.begin(), first_pair.end());   // [first S][count S][region_off A+1][first pair S]
         if (geo_f.size() & 1) geo_f.push_back(0.0);  // keep 16-byte alignment of each map's base
         descs[m] = d;
         maxS = d.S > maxS ? d.S : maxS;
         maxP = d.P > maxP ? d.P : maxP;
+        maxPP = d.PP > maxPP ? d.PP : maxPP;
     }
     const int N = cfg->n_envs;
     std::vector<int> slot((size_t)N, 0);
@@ -2434,7 +2506,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     int fan = (grid_host.max_row <= 7 && maxS + A <= 63 && cfg->n_rays <= kGroupRays) ? 1 : 0;
     if (const char *e = getenv("CAT_FAN")) { if (!strcmp(e, "chunks")) fan = 0; }
     // ---- LDS carve sizes (must match carve()) and the workgroup size
-    LdsSizes ls = lds_sizes(A, cfg->n_rays, maxS, maxP, fan == 1);
+    LdsSizes ls = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, fan == 1);
     int wpb = 0;
     {   // waves (= env slots) per workgroup.  Most resident waves per CU first (cap 16 = 4 per SIMD at <= 128 VGPRs);
         // among equals a launch of at most two rounds takes the LARGEST workgroup (its waves share ray chunks, which
@@ -2508,7 +2580,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     std::vector<char> rec0((size_t)N * p.rec_bytes, 0);
     for (int e = 0; e < N; e++) {
         const MapDesc &d = descs[slot[e]];
-        const double *start = geo_f.data() + d.f64_off + 4 * d.S + kGeoPerPlane * d.P;
+        const double *start = geo_f.data() + d.f64_off + 4 * d.S + geo_rest_doubles(d);
         double *rd = reinterpret_cast<double *>(rec0.data() + (size_t)e * p.rec_bytes);
         int *ri = reinterpret_cast<int *>(rec0.data() + (size_t)e * p.rec_bytes + p.hot_bytes + (A * kK + NPs_rec) * 8);   // cold ints
         for (int i = 0; i < A; i++) {
