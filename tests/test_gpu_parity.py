@@ -88,6 +88,16 @@ def test_chunk_form_of_the_ray_fan_on_the_light_maps(name, rays, monkeypatch):
     assert stats["done"] >= 32
 
 
+@pytest.mark.parametrize("rays", [100, 130, 200, 256, 300])
+def test_group_form_of_the_ray_fan_across_ray_counts(rays):
+    """fan_group groups two agents while their rays fill at most four 64-ray chunks (R <= 128) and one agent beyond (R <= 256: three
+    or four chunks per agent); above 256 rays cat_create falls back to fan_chunk.  Every branch against the oracle."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    cfg = SimConfig(n_envs=8, n_rays=rays, max_step_count=30, seed=rays)
+    stats = _run(cfg, [compiled("lbirinth")], np.zeros(8, np.int32), ticks=40, rng=np.random.default_rng(rays), auto_reset=True)
+    assert stats["done"] >= 8
+
+
 def test_contacts_and_captures_are_exercised():
     from as_cops_and_thieves_amd.config import SimConfig
     rng = np.random.default_rng(3)
