@@ -2,7 +2,8 @@
 //
 // A workgroup of 1..16 wavefronts advances as many envs that share one map, whose geometry (hull planes +
 // shape bbs) is staged once per workgroup in LDS.  A wavefront owns one env for the serial part of the tick;
-// the 64-ray chunks of the ray fan and the physics step are work units any wave of the workgroup may claim.
+// the ray fan -- cut into 64-ray chunks (fan_chunk), or into agent groups whose candidate-less rays are sorted out first
+// (fan_group: maps whose rays meet few walls) -- and the physics step are work units any wave of the workgroup may claim.
 // All body state and ray arithmetic is FP64 with contraction off, so results are bit-comparable with a non-FMA
 // CPU evaluation of the same formulas.  No MFMA: the path is geometry/indexing, bounded by FP64 VALU issue and
 // LDS latency (DESIGN.md "Kernels").
