@@ -21,7 +21,15 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-RAW_MAPS = HERE.parent / "tests" / "golden" / "maps_raw"      # the reference's own map files (data), tools/make_golden_maps_raw.py
+RAW_MAPS = HERE.parent / "tests" / "golden" / "reference_maps.json"   # the reference's own map data, tools/make_golden_maps_raw.py
+_raw_cache: Dict[str, dict] = {}
+
+
+def raw_map(name: str) -> Optional[dict]:
+    """The reference's map file `name`.json as parsed JSON (None: not one of its maps)."""
+    if not _raw_cache and RAW_MAPS.exists():
+        _raw_cache.update(json.loads(RAW_MAPS.read_text())["maps"])
+    return _raw_cache.get(name)
 
 # ---- constants, each with the place the reference (or Chipmunk) states it ------------------------------------------------
 UNIT_VELOCITY = 10.0          # pyproject.toml:13  impulse per action
@@ -247,12 +255,11 @@ def compile_blob(map_data: dict, roster=None, start_positions=None, spawn_region
 def blob_for(cmap) -> bytes:
     """A product ``CompiledMap`` is taken only as a pointer to its INPUTS (``cmap.spec``: the parsed map JSON and the override
     arguments ``Map`` was given); nothing it computed is read.  For the five bundled maps the JSON is re-read from the reference's
-    own file under tests/golden/maps_raw/, so the rect / poly block rules run here too."""
+    own file (tests/golden/reference_maps.json), so the rect / poly block rules run here too."""
     spec = cmap.spec
     data = spec["map_data"]
-    raw = RAW_MAPS / f"{spec['name']}.json"
-    if spec.get("bundled") and raw.exists():
-        data = json.loads(raw.read_text())
+    if spec.get("bundled") and raw_map(spec["name"]) is not None:
+        data = raw_map(spec["name"])
     return compile_blob(data, spec.get("roster"), spec.get("start_positions"), spec.get("spawn_regions"), spec.get("scale"),
                         spec.get("wall_radius", WALL_RADIUS))
 

@@ -48,7 +48,7 @@ def _free_positions(scene: PymunkScene, rng, window, n):
 @pytest.mark.parametrize("name", sorted(MAPS))
 def test_oracle_agrees_with_pymunk(name):
     roster, starts, scale = MAPS[name]
-    data = json.loads((host.RAW_MAPS / f"{name}.json").read_text())
+    data = host.raw_map(name)
     R, T, EPISODES = 90, 200, 6
     rng = np.random.default_rng(abs(hash(name)) % (1 << 31))
     compared = 0

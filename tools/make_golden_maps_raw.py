@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Copies the reference's map DATA files (maps_templates/*.json: window, canvas, blocks, agents) into tests/golden/maps_raw/
-unchanged, so that the CPU oracle can parse the maps from the reference's own schema with its own code
-(oracle/cat_oracle_host.py) on a box that has no /root/reference.  Data only: no reference source or script is copied.
+"""The reference's map DATA (maps_templates/*.json: window, canvas, blocks, agents) as ONE fixture, tests/golden/reference_maps.json
+= {map name: the parsed JSON of the reference's file, nothing added or removed}, so that the CPU oracle can parse the maps from the
+reference's own schema with its own code (oracle/cat_oracle_host.py) on a box that has no /root/reference.  Data only: no
+reference source or script is copied.  "sources" records the size and SHA-256 of each file the entry was parsed from.
 
 Run in the build container:  python3 -B tools/make_golden_maps_raw.py [/root/reference/maps_templates]
 """
@@ -15,17 +16,13 @@ ROOT = Path(__file__).resolve().parents[1]
 
 def main() -> None:
     src = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference/maps_templates")
-    dst = ROOT / "tests" / "golden" / "maps_raw"
-    dst.mkdir(parents=True, exist_ok=True)
-    index = {}
+    out = {"maps": {}, "sources": {}}
     for f in sorted(src.glob("*.json")):
         raw = f.read_bytes()
-        json.loads(raw)                                   # must be valid JSON
-        (dst / f.name).write_bytes(raw)
-        index[f.name] = {"bytes": len(raw), "sha256": hashlib.sha256(raw).hexdigest()}
+        out["maps"][f.stem] = json.loads(raw)
+        out["sources"][f.name] = {"bytes": len(raw), "sha256": hashlib.sha256(raw).hexdigest()}
         print(f"{f.name}: {len(raw)} bytes")
-    (dst / "INDEX.json").write_text(json.dumps({"source": "maps_templates/*.json of the reference, byte for byte", "files": index},
-                                               indent=1) + "\n")
+    (ROOT / "tests" / "golden" / "reference_maps.json").write_text(json.dumps(out, separators=(",", ":")) + "\n")
 
 
 if __name__ == "__main__":
