@@ -183,7 +183,16 @@ struct PhaseClock {   // accumulators live in LDS (one row per wave) to keep reg
     __device__ void flush(int lane) { if (lane < 24 && acc[lane]) atomicAdd(&g_phase_cycles[lane], acc[lane]); }
 };
 #define PHASE(pc, id) (pc).mark(id)
+// event counters (slots 24..31; -DCAT_EVENT_COUNTS on top: the atomics distort the cycle marks): the active lanes' leader adds
+// (1, number of active lanes) to slots (id, id + 1)
+#ifdef CAT_EVENT_COUNTS
+#define QCOUNT(id) do { const unsigned long long m_ = __ballot(true); if ((int)__builtin_ctzll(m_) == (int)(threadIdx.x % 64)) { \
+    atomicAdd(&g_phase_cycles[id], 1ull); atomicAdd(&g_phase_cycles[(id) + 1], (unsigned long long)__popcll(m_)); } } while (0)
 #else
+#define QCOUNT(id) do {} while (0)
+#endif
+#else
+#define QCOUNT(id) do {} while (0)
 struct PhaseClock { __device__ __forceinline__ void flush(int) {} };
 #define PHASE(pc, id) do {} while (0)
 #endif
@@ -534,7 +543,9 @@ __device__ __forceinline__ void poly_query_feat(const Lds &L, float cmax, bool w
         const float *q = L.p32 + kPairF * (wall ? L.fp[sh] : 0);
         const f32x2 ax2 = {axf, axf}, ay2 = {ayf, ayf}, dx2 = {dxf, dxf}, dy2 = {dyf, dyf};
         const f32x2 len3 = {3.0f * len, 3.0f * len}, four = {4.0f, 4.0f};
+        QCOUNT(24);
         for (int i = 0; i < count; i += 2, q += kPairF) {
+            QCOUNT(26);
             const float4 r0 = *reinterpret_cast<const float4 *>(q);        // n.x n.x' n.y n.y'
             const float4 r1 = *reinterpret_cast<const float4 *>(q + 4);    // c c' dtMin dtMin'
             const float4 r2 = *reinterpret_cast<const float4 *>(q + 8);    // dtMax dtMax' v0.x v0.x'
@@ -585,6 +596,7 @@ __device__ __forceinline__ void poly_query_feat(const Lds &L, float cmax, bool w
     double pa = 1.0, va = 1.0;
     int pf = -1, vf = -1;
     while (pm) {   // exact face test
+        QCOUNT(28);
         const int i = __builtin_ctz(pm);
         pm &= pm - 1;
         const double *pl = pl0 + 8 * i;
@@ -602,6 +614,7 @@ __device__ __forceinline__ void poly_query_feat(const Lds &L, float cmax, bool w
         }
     }
     while (vm) {   // [CP CircleSegmentQuery] on the corner circle
+        QCOUNT(30);
         const int i = __builtin_ctz(vm);
         vm &= vm - 1;
         double2 v = *reinterpret_cast<const double2 *>(pl0 + 8 * i + 2);
@@ -2827,11 +2840,16 @@ extern "C" int cat_get_state(cat_sim *s, const cat_state *dst, void *stream) { r
 extern "C" int cat_set_state(cat_sim *s, const cat_state *src, void *stream) { return copy_state(s, src, false, stream); }
 
 #ifdef CAT_PHASE_TIMING
+static unsigned long long g_last_counts[8];
+// event counters as of the last cat_debug_phase_cycles call: shape-query rounds / their lanes, classification iterations / lanes,
+// exact face iterations / lanes, exact corner iterations / lanes (the counting distorts the cycle marks of the same run)
+extern "C" void cat_debug_counts(unsigned long long *out8) { for (int i = 0; i < 8; i++) out8[i] = g_last_counts[i]; }
 extern "C" int cat_debug_phase_cycles(unsigned long long *out24, int reset)
 {
     unsigned long long h[32];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_cycles), sizeof h) != hipSuccess) return CAT_ERR_HIP;
     for (int i = 0; i < 24; i++) out24[i] = h[i];
+    for (int i = 24; i < 32; i++) g_last_counts[i - 24] = h[i];
     if (reset) { memset(h, 0, sizeof h); if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), h, sizeof h) != hipSuccess) return CAT_ERR_HIP; }
     return CAT_OK;
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase shader-cycle shares of tick_kernel (build with -DCAT_PHASE_TIMING into
-libcat_sim_timing.so; never the shipped library).  Usage: python tools/phase_timing.py [map] [envs] [rays]"""
+libcat_sim_timing.so; never the shipped library).  With -DCAT_EVENT_COUNTS on top the build also counts the shape-query rounds,
+the classification sweeps and the exact face / corner tests (and its cycle marks are then distorted by the counting).  Usage: python tools/phase_timing.py [map] [envs] [rays]"""
 import ctypes as C, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -40,3 +41,12 @@ for i in range(24):
     if buf[i]:
         print(f"{str(names.get(i, i)):46s} {buf[i] / T / N:10.0f} cycles/wave  {100.0 * buf[i] / tot:5.1f}%")
 print(f"{'total':22s} {tot / T / N:10.0f} cycles/wave")
+cnt = (C.c_ulonglong * 8)()
+if hasattr(L, "cat_debug_counts"):
+    L.cat_debug_counts(cnt)
+if any(cnt):
+    c = [x / T / N for x in cnt]
+    print("per env-step: shape-query rounds %.1f (items %.0f, %.1f lanes per round); classification iterations %.1f (lanes %.0f = %.1f per iteration);"
+          % (c[0], c[1], c[1] / max(c[0], 1e-9), c[2], c[3], c[3] / max(c[2], 1e-9)))
+    print("              exact face iterations %.1f (tests %.0f = %.1f lanes each, %.2f per item); exact corner iterations %.1f (tests %.0f = %.1f lanes each, %.2f per item)"
+          % (c[4], c[5], c[5] / max(c[4], 1e-9), c[5] / max(c[1], 1e-9), c[6], c[7], c[7] / max(c[6], 1e-9), c[7] / max(c[1], 1e-9)))
