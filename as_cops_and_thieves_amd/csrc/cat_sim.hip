@@ -1884,12 +1884,14 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
     }
     PHASE(pc, 16);
     if (fin_mask) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the other waves' units of those slots
+    PHASE(pc, 21);
     while (fin_mask) {
         const int slot = uni(__builtin_ctz(fin_mask));
         fin_mask &= fin_mask - 1;
         const Lds Ls = carve<D>(p, smem, md, slot, wave);
         const int e_s = uni(L.ctrl[4 * slot + 3]);
         const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
+        PHASE(pc, 22);
         LateOut late;
         rewards_and_positions<D>(Ls, p, la, lane, tick, captured2, timeout2, cop_lut, thief_lut, late);
         PHASE(pc, 17);
