@@ -2177,9 +2177,17 @@ struct GridHost {
 // of (cell, ray k) iff its bb, grown by `m_ray`, intersects the region swept by the thin segment
 // origin -> origin + d_k over all origins in the cell: conv(cell, cell + d_k), a hexagon whose edge
 // normals are x, y and perp(d_k) -- so a separating-axis test on those three axes is exact.
+// hull_first / hull_count / rsum: the walls' plane records follow the bbs (bb + 4 S: n.x n.y v0.x v0.y dot(v0, n) ...); a wall is
+// listed for (cell, ray) only if, beside the bb rule, some ray of the cell can come within rsum = wall radius + ray radius of its HULL:
+// a wall whose shape query cannot return a hit leaves no trace in [CP cpSpaceSegmentQueryFirst] whether it is visited or not
+// (agh-map: 21 % fewer entries than by the bbs alone -- triangles, slanted and merged blocks).  CAT_GRID_HULLS=0: the bb rule only.
 static void build_grids(const double *bb, int S, int R, const double *rdx, const double *rdy, double reach,
-                        double m_ray, double m_contact, double cell, GridHost &g)
+                        double m_ray, double m_contact, double cell, GridHost &g, const int *hull_first, const int *hull_count,
+                        double rsum)
 {
+    const double *planes = bb + 4 * (size_t)S;
+    bool by_hull = hull_first != nullptr;
+    if (const char *e = getenv("CAT_GRID_HULLS")) { if (atoi(e) == 0) by_hull = false; }
     double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
     for (int s = 0; s < S; s++) {
         lo[0] = std::fmin(lo[0], bb[4 * s]); lo[1] = std::fmin(lo[1], bb[4 * s + 1]);
@@ -2221,7 +2229,27 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                     if (!(l <= hx1 && hx0 <= r && b <= hy1 && hy0 <= t)) continue;
                     const double q0 = -dy * l + dx * b, q1 = -dy * r + dx * b, q2 = -dy * l + dx * t, q3 = -dy * r + dx * t;
                     const double qmin = std::fmin(std::fmin(q0, q1), std::fmin(q2, q3)), qmax = std::fmax(std::fmax(q0, q1), std::fmax(q2, q3));
-                    if (qmin <= pmax && pmin <= qmax) g.ent.push_back((unsigned char)s);
+                    if (!(qmin <= pmax && pmin <= qmax)) continue;
+                    if (by_hull) {
+                        // separating axes between the rounded hull and the cell swept along the ray (a hexagon): the ray's normal
+                        // with the hull's own vertices, then every face normal of the hull
+                        const double *pl = planes + 8 * (size_t)hull_first[s];
+                        const int ne = hull_count[s];
+                        const double grow = (rsum + eps) * std::sqrt(dx * dx + dy * dy);
+                        double vmin = 1e300, vmax = -1e300;
+                        for (int e = 0; e < ne; e++) {
+                            const double v = -dy * pl[8 * e + 2] + dx * pl[8 * e + 3];
+                            vmin = std::fmin(vmin, v); vmax = std::fmax(vmax, v);
+                        }
+                        bool apart = vmin - grow > pmax || vmax + grow < pmin;
+                        for (int e = 0; e < ne && !apart; e++) {
+                            const double nx = pl[8 * e], ny = pl[8 * e + 1];
+                            const double lowest = std::fmin(nx * X0, nx * X1) + std::fmin(ny * Y0, ny * Y1) + std::fmin(0.0, nx * dx + ny * dy);
+                            apart = lowest > pl[8 * e + 4] + rsum + eps;
+                        }
+                        if (apart) continue;
+                    }
+                    g.ent.push_back((unsigned char)s);
                 }
                 const int n = (int)g.ent.size() - d.ent_base - g.off.back();
                 if (n > g.max_row) g.max_row = n;
@@ -2514,7 +2542,8 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         const double m_ray = cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6;
         for (int m = 0; m < n_maps; m++)
             build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, cfg->n_rays, tab->ray_dx, tab->ray_dy, reach, m_ray,
-                        cfg->agent_radius + 1e-6, cell, grid_host);
+                        cfg->agent_radius + 1e-6, cell, grid_host, geo_i.data() + descs[m].i32_off, geo_i.data() + descs[m].i32_off + descs[m].S,
+                        cfg->wall_radius + cfg->ray_radius);
         finalize_rows(grid_host);
     }
     // Rays that meet few walls (every list fits one packed row word, ids and agents fit 6 bits, an agent's rays fit four chunks):
@@ -2890,13 +2919,16 @@ extern "C" int cat_grid_build_host(const cat_config *cfg, const cat_tables *tab,
     memcpy(h, blob, 64);
     const int S = h[2], P = h[3], A = h[4], Rg = h[7];
     const size_t nf = 2 + 4 * (size_t)S + 8 * (size_t)P + 2 * (size_t)A + 4 * (size_t)Rg;
-    if ((unsigned)h[0] != kBlobMagic || size < 64 + nf * 8 || S < 1 || S > CAT_MAX_SHAPES) return CAT_ERR_BAD_MAP;
+    if ((unsigned)h[0] != kBlobMagic || size < 64 + nf * 8 + 2 * (size_t)S * 4 || S < 1 || S > CAT_MAX_SHAPES) return CAT_ERR_BAD_MAP;
     std::vector<double> f(nf);
+    std::vector<int> iv(2 * (size_t)S);   // [first plane S][plane count S]
     memcpy(f.data(), static_cast<const unsigned char *>(blob) + 64, nf * 8);
+    memcpy(iv.data(), static_cast<const unsigned char *>(blob) + 64 + nf * 8, iv.size() * 4);
     cat_grid_host *gh = new cat_grid_host();
     gh->R = cfg->n_rays;
     build_grids(f.data() + 2, S, cfg->n_rays, tab->ray_dx, tab->ray_dy, cfg->ray_length + cfg->ray_radius + 1e-3,
-                cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6, cfg->agent_radius + 1e-6, cell > 0 ? cell : 8.0, gh->g);
+                cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6, cfg->agent_radius + 1e-6, cell > 0 ? cell : 8.0, gh->g,
+                iv.data(), iv.data() + S, cfg->wall_radius + cfg->ray_radius);
     finalize_rows(gh->g);
     *out = gh;
     return CAT_OK;

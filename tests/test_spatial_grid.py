@@ -1,6 +1,7 @@
-"""The spatial-hash ray grid built at cat_create must be a SUPERSET of the exact BBTree gate: for any
-origin and ray, every wall whose bb the thin segment enters (cpBBSegmentQuery finite) is listed for
-(cell of the origin, ray index).  Brute-force check on the host copy of the tables (no GPU)."""
+"""The spatial-hash ray grid built at cat_create must list, for (cell of the origin, ray index), every wall that can matter to
+cpSpaceSegmentQueryFirst: a wall whose bb the thin segment enters (cpBBSegmentQuery finite: it is visited) AND whose rounded hull
+the ray can touch (segment within wall radius + ray radius of the hull: only then can the visit return a hit).  With
+CAT_GRID_HULLS=0 the table keeps every wall of the first kind.  Brute-force check on the host copy of the tables (no GPU)."""
 import ctypes as C
 
 import numpy as np
@@ -45,11 +46,44 @@ def _exact_gate(bb, ax, ay, bx, by):
     return okx & oky & (tmin <= tmax) & (0.0 <= tmax) & (tmin <= 1.0)
 
 
-@pytest.mark.parametrize("name,rays,cell", [("labyrinth", 64, 32), ("agh-map", 90, 32), ("squarinth", 64, 16), ("lbirinth", 90, 48)])
-def test_ray_grid_is_superset_of_exact_gate(name, rays, cell):
+def _seg_hull_distance(hull, ax, ay, bx, by):
+    """Exact distance between the segment a-b and the convex polygon `hull` ([n, 2], any orientation): 0 if they intersect."""
+    a, b = np.array([ax, ay]), np.array([bx, by])
+
+    def inside(q):
+        e = np.roll(hull, -1, 0) - hull
+        c = e[:, 0] * (q[1] - hull[:, 1]) - e[:, 1] * (q[0] - hull[:, 0])
+        return bool(np.all(c >= 0) or np.all(c <= 0))
+
+    def seg_seg(p1, p2, q1, q2):
+        def pt_seg(q, s1, s2):
+            d = s2 - s1
+            t = 0.0 if not d.any() else min(1.0, max(0.0, float(np.dot(q - s1, d) / np.dot(d, d))))
+            return float(np.hypot(*(q - (s1 + t * d))))
+
+        def cross(u, v):
+            return u[0] * v[1] - u[1] * v[0]
+        d1, d2 = p2 - p1, q2 - q1
+        den = cross(d1, d2)
+        if den != 0.0:
+            t, u = cross(q1 - p1, d2) / den, cross(q1 - p1, d1) / den
+            if 0.0 <= t <= 1.0 and 0.0 <= u <= 1.0:
+                return 0.0
+        return min(pt_seg(p1, q1, q2), pt_seg(p2, q1, q2), pt_seg(q1, p1, p2), pt_seg(q2, p1, p2))
+    if inside(a) or inside(b):
+        return 0.0
+    return min(seg_seg(a, b, hull[i], hull[(i + 1) % len(hull)]) for i in range(len(hull)))
+
+
+@pytest.mark.parametrize("name,rays,cell,hulls", [("labyrinth", 64, 32, 1), ("agh-map", 90, 32, 1), ("agh-map", 64, 8, 1), ("squarinth", 64, 16, 1),
+                                                  ("lbirinth", 90, 48, 1), ("agh-map", 64, 16, 0)])
+def test_ray_grid_lists_every_wall_that_can_be_visited_and_hit(name, rays, cell, hulls, monkeypatch):
+    monkeypatch.setenv("CAT_GRID_HULLS", str(hulls))
     cmap = load_preset(name).compile()
     cfg = SimConfig(n_rays=rays)
     L, h, rdx, rdy = _grid(cmap, cfg, cell)
+    hull_of = [cmap.planes[f:f + n, 2:4] for f, n in zip(cmap.shape_first, cmap.shape_count)]
+    rsum = cfg.wall_radius + cfg.ray_radius
     rng = np.random.default_rng(0)
     lo = cmap.shape_bb[:, :2].min(0) - 450; hi = cmap.shape_bb[:, 2:].max(0) + 450
     out = (C.c_int * 256)()
@@ -68,6 +102,10 @@ def test_ray_grid_is_superset_of_exact_gate(name, rays, cell):
             n = L.cat_grid_lookup_host(h, float(ax), float(ay), k, out, 256)
             got = list(out[:n])
             assert got == sorted(got), "ids ascending (index order of the sequential visit)"
+            if hulls:
+                if trial % 16 not in (0, 1, 2, 3, 5):      # the exact hull distance is slow in Python: a third of the origins
+                    continue
+                want = [s_ for s_ in want if s_ in got or _seg_hull_distance(hull_of[s_], ax, ay, bx, by) <= rsum + 1e-9]
             assert set(want) <= set(got), (name, ax, ay, k, sorted(set(want) - set(got)))
             listed += n; exact += len(want)
     assert listed <= 3.0 * max(exact, 1) + 400 * rays * 0.5      # and it is reasonably tight
