@@ -28,6 +28,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "cat_sim.h"
@@ -2173,21 +2175,61 @@ struct GridHost {
     std::vector<unsigned char> ent, cent;
 };
 
-// One map.  bb: [S][4] wall bbs (already inflated by the wall radius).  A wall is a ray-grid candidate
-// of (cell, ray k) iff its bb, grown by `m_ray`, intersects the region swept by the thin segment
-// origin -> origin + d_k over all origins in the cell: conv(cell, cell + d_k), a hexagon whose edge
-// normals are x, y and perp(d_k) -- so a separating-axis test on those three axes is exact.
-// hull_first / hull_count / rsum: the walls' plane records follow the bbs (bb + 4 S: n.x n.y v0.x v0.y dot(v0, n) ...); a wall is
-// listed for (cell, ray) only if, beside the bb rule, some ray of the cell can come within rsum = wall radius + ray radius of its HULL:
-// a wall whose shape query cannot return a hit leaves no trace in [CP cpSpaceSegmentQueryFirst] whether it is visited or not
-// (agh-map: 21 % fewer entries than by the bbs alone -- triangles, slanted and merged blocks).  CAT_GRID_HULLS=0: the bb rule only.
+// One map.  bb: [S][4] wall bbs (already inflated by the wall radius); the walls' plane records follow them (bb + 4 S:
+// n.x n.y v0.x v0.y dot(v0, n) ...; hull_first / hull_count index them).  Three rules decide whether a wall is listed for
+// (cell, ray k); all three keep [CP cpSpaceSegmentQueryFirst]'s result for every origin in the cell exactly as the full wall list gives it.
+//  1. The visit (always): the wall's bb, grown by `m_ray`, meets the region swept by the thin segment origin -> origin + d_k over
+//     all origins of the cell: conv(cell, cell + d_k), a hexagon whose edge normals are x, y and perp(d_k) -- a separating-axis
+//     test on those three axes is exact.
+//  2. The hit (CAT_GRID_HULLS=0 turns it off): some ray of the cell can come within rsum = wall radius + ray radius of the HULL
+//     (separating axes: perp(d_k) with the hull's own vertices, every face normal).  A wall whose shape query cannot return a hit
+//     leaves no trace whether it is visited or not (agh-map: 21 % fewer entries -- triangles, slanted and merged blocks).
+//  3. Occlusion (CAT_GRID_OCCLUSION=0 turns it off): if every ray of the cell is certain to cross the hull of some listed wall W
+//     no later than T (in units of the ray), then after W's turn the best alpha is <= T whatever came before; a wall whose bb,
+//     grown by the ray radius, is entered later than T by every ray of the cell (so t_bb > T and alpha > T) can then be taken out
+//     of the sequence: while the best alpha is above T such a wall can only replace it by another value above T, and every wall
+//     that stays is visited or not regardless of such values PROVIDED its own t_bb never exceeds T -- so T is first raised past
+//     the latest thin-bb entry of every remaining wall whose range of entries straddles it.  (Agents come after the walls in
+//     the visiting order: by then the best alpha is the same with and without the walls taken out.)
+struct RotPoly {   // a convex polygon seen from one ray direction: per vertex its depth along the ray in units of the ray, and its offset across it
+    int n;
+    double al[CAT_MAX_HULL_EDGES + 1], si[CAT_MAX_HULL_EDGES + 1], smin, smax;
+    void close() { smin = 1e300; smax = -1e300; for (int i = 0; i < n; i++) { smin = std::fmin(smin, si[i]); smax = std::fmax(smax, si[i]); } }
+    // smallest depth among the polygon's points at offset s (s within [smin, smax])
+    double entry(double s) const
+    {
+        double best = 1e300;
+        for (int i = 0; i < n; i++) {
+            const int j = i + 1 < n ? i + 1 : 0;
+            const double s0 = si[i], s1 = si[j];
+            if ((s0 <= s && s <= s1) || (s1 <= s && s <= s0))
+                best = std::fmin(best, s0 == s1 ? std::fmin(al[i], al[j]) : al[i] + (al[j] - al[i]) * ((s - s0) / (s1 - s0)));
+        }
+        return best;
+    }
+    // bounds of entry() over the offsets [a, b] clipped to the polygon: false if they do not meet
+    bool entry_range(double a, double b, double &emin, double &emax) const
+    {
+        const double lo = std::fmax(a, smin), hi = std::fmin(b, smax);
+        if (lo > hi) return false;
+        const double e0 = entry(lo), e1 = entry(hi);
+        emax = std::fmax(e0, e1);            // entry() is convex in s: its maximum over an interval is at an end
+        emin = std::fmin(e0, e1);            // its minimum is at an end or at a vertex in between (any vertex there bounds it from below)
+        for (int i = 0; i < n; i++) if (lo <= si[i] && si[i] <= hi) emin = std::fmin(emin, al[i]);
+        return true;
+    }
+};
+
+struct GridRowOut { std::vector<int> off, coff; std::vector<unsigned char> ent, cent; int max_row = 0; };
+
 static void build_grids(const double *bb, int S, int R, const double *rdx, const double *rdy, double reach,
                         double m_ray, double m_contact, double cell, GridHost &g, const int *hull_first, const int *hull_count,
-                        double rsum)
+                        double rsum, double ray_radius)
 {
     const double *planes = bb + 4 * (size_t)S;
-    bool by_hull = hull_first != nullptr;
+    bool by_hull = hull_first != nullptr, occlusion = hull_first != nullptr;
     if (const char *e = getenv("CAT_GRID_HULLS")) { if (atoi(e) == 0) by_hull = false; }
+    if (const char *e = getenv("CAT_GRID_OCCLUSION")) { if (atoi(e) == 0) occlusion = false; }
     double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
     for (int s = 0; s < S; s++) {
         lo[0] = std::fmin(lo[0], bb[4 * s]); lo[1] = std::fmin(lo[1], bb[4 * s + 1]);
@@ -2201,21 +2243,25 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
     d.coff_base = (int)g.coff.size(); d.cent_base = (int)g.cent.size();
     d.row_base = 0;   // set by finalize_rows
     const double eps = 1e-6;   // cell membership is decided in floating point on the device
-    std::vector<int> near;     // walls within reach of the cell (prefilter)
-    for (int cy = 0; cy < d.ny; cy++) {
+    const double mt = 1e-7;    // occlusion: slack on every bound, in units of the ray (4e-5 px of a 400-px ray)
+
+    // one row of cells: its part of the CSR arrays, offsets relative to the row
+    auto do_row = [&](int cy, GridRowOut &o) {
+        std::vector<int> near, list;     // walls within reach of the cell (prefilter); the walls listed for (cell, ray)
+        std::vector<double> t_sure, f_lo, b_hi;
         for (int cx = 0; cx < d.nx; cx++) {
             const double X0 = d.x0 + cx * cell - eps, X1 = d.x0 + (cx + 1) * cell + eps;
             const double Y0 = d.y0 + cy * cell - eps, Y1 = d.y0 + (cy + 1) * cell + eps;
             near.clear();
-            g.coff.push_back((int)g.cent.size() - d.cent_base);
+            o.coff.push_back((int)o.cent.size());
             for (int s = 0; s < S; s++) {
                 const double l = bb[4 * s], b = bb[4 * s + 1], r = bb[4 * s + 2], t = bb[4 * s + 3];
                 if (l - m_contact <= X1 && X0 <= r + m_contact && b - m_contact <= Y1 && Y0 <= t + m_contact)
-                    g.cent.push_back((unsigned char)s);
+                    o.cent.push_back((unsigned char)s);
                 if (l - reach <= X1 && X0 <= r + reach && b - reach <= Y1 && Y0 <= t + reach) near.push_back(s);
             }
             for (int k = 0; k < R; k++) {
-                g.off.push_back((int)g.ent.size() - d.ent_base);
+                o.off.push_back((int)o.ent.size());
                 const double dx = rdx[k], dy = rdy[k];
                 const double hx0 = X0 + std::fmin(0.0, dx) - eps, hx1 = X1 + std::fmax(0.0, dx) + eps;
                 const double hy0 = Y0 + std::fmin(0.0, dy) - eps, hy1 = Y1 + std::fmax(0.0, dy) + eps;
@@ -2224,6 +2270,7 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                 const double nscale = std::fabs(dx) + std::fabs(dy);
                 const double pmin = std::fmin(std::fmin(c0, c1), std::fmin(c2, c3)) - eps * nscale;
                 const double pmax = std::fmax(std::fmax(c0, c1), std::fmax(c2, c3)) + eps * nscale;
+                list.clear();
                 for (int s : near) {
                     const double l = bb[4 * s] - m_ray, b = bb[4 * s + 1] - m_ray, r = bb[4 * s + 2] + m_ray, t = bb[4 * s + 3] + m_ray;
                     if (!(l <= hx1 && hx0 <= r && b <= hy1 && hy0 <= t)) continue;
@@ -2231,8 +2278,6 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                     const double qmin = std::fmin(std::fmin(q0, q1), std::fmin(q2, q3)), qmax = std::fmax(std::fmax(q0, q1), std::fmax(q2, q3));
                     if (!(qmin <= pmax && pmin <= qmax)) continue;
                     if (by_hull) {
-                        // separating axes between the rounded hull and the cell swept along the ray (a hexagon): the ray's normal
-                        // with the hull's own vertices, then every face normal of the hull
                         const double *pl = planes + 8 * (size_t)hull_first[s];
                         const int ne = hull_count[s];
                         const double grow = (rsum + eps) * std::sqrt(dx * dx + dy * dy);
@@ -2249,13 +2294,85 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                         }
                         if (apart) continue;
                     }
-                    g.ent.push_back((unsigned char)s);
+                    list.push_back(s);
                 }
-                const int n = (int)g.ent.size() - d.ent_base - g.off.back();
-                if (n > g.max_row) g.max_row = n;
+                if (occlusion && list.size() > 1) {
+                    const double dd = dx * dx + dy * dy;
+                    const double a0 = (X0 * dx + Y0 * dy) / dd, a1 = (X1 * dx + Y0 * dy) / dd, a2 = (X0 * dx + Y1 * dy) / dd, a3 = (X1 * dx + Y1 * dy) / dd;
+                    const double amin = std::fmin(std::fmin(a0, a1), std::fmin(a2, a3)), amax = std::fmax(std::fmax(a0, a1), std::fmax(a2, a3));
+                    const double ms = eps * nscale;   // a margin across the ray, in the units of pmin / pmax
+                    const size_t n = list.size();
+                    t_sure.assign(n, 1e300); f_lo.assign(n, 1e300); b_hi.assign(n, -1e300);
+                    double T = 1e300;
+                    for (size_t q = 0; q < n; q++) {
+                        const int s = list[q];
+                        RotPoly H, B, F;
+                        const double *pl = planes + 8 * (size_t)hull_first[s];
+                        H.n = hull_count[s];
+                        for (int e = 0; e < H.n; e++) {
+                            const double vx = pl[8 * e + 2], vy = pl[8 * e + 3];
+                            H.al[e] = (vx * dx + vy * dy) / dd; H.si[e] = -dy * vx + dx * vy;
+                        }
+                        H.close();
+                        const double l = bb[4 * s], b = bb[4 * s + 1], r = bb[4 * s + 2], t = bb[4 * s + 3];
+                        const double gw = m_ray > 0.5 * ray_radius ? ray_radius : 0.0;   // gate off: every listed wall counts as entered at once
+                        const double cxs[4] = {l, r, r, l}, cys[4] = {b, b, t, t};
+                        B.n = F.n = 4;
+                        for (int e = 0; e < 4; e++) {
+                            B.al[e] = (cxs[e] * dx + cys[e] * dy) / dd; B.si[e] = -dy * cxs[e] + dx * cys[e];
+                            const double fx = cxs[e] + ((e == 1 || e == 2) ? ray_radius : -ray_radius), fy = cys[e] + (e >= 2 ? ray_radius : -ray_radius);
+                            F.al[e] = (fx * dx + fy * dy) / dd; F.si[e] = -dy * fx + dx * fy;
+                        }
+                        B.close(); F.close();
+                        double emin, emax;
+                        // every ray of the cell crosses the hull: offsets inside the hull's, origins before it, the crossing within the ray
+                        if (H.n >= 3 && pmin >= H.smin + ms && pmax <= H.smax - ms && H.entry_range(pmin, pmax, emin, emax) &&
+                            amax <= emin - mt && emax - amin <= 1.0 - mt)
+                            t_sure[q] = emax - amin + mt;
+                        if (F.entry_range(pmin, pmax, emin, emax)) f_lo[q] = std::fmax(0.0, emin - amax) - mt;
+                        if (gw > 0.0) b_hi[q] = 0.0;
+                        else if (B.entry_range(pmin, pmax, emin, emax)) b_hi[q] = std::fmax(0.0, emax - amin) + mt;
+                        T = std::fmin(T, t_sure[q]);
+                    }
+                    if (T < 1e299) {
+                        for (bool again = true; again;) {
+                            again = false;
+                            for (size_t q = 0; q < n; q++)
+                                if (f_lo[q] <= T && T < b_hi[q]) { T = b_hi[q]; again = true; }
+                        }
+                        size_t w = 0;
+                        for (size_t q = 0; q < n; q++) if (f_lo[q] <= T) list[w++] = list[q];
+                        list.resize(w);
+                    }
+                }
+                for (int s : list) o.ent.push_back((unsigned char)s);
+                if ((int)list.size() > o.max_row) o.max_row = (int)list.size();
             }
         }
+    };
+    std::vector<GridRowOut> rows((size_t)d.ny);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt > 16) nt = 16;
+        if (nt < 1) nt = 1;
+        if ((int)nt > d.ny) nt = (unsigned)d.ny;
+        std::atomic<int> next{0};
+        auto worker = [&]() { for (int cy = next.fetch_add(1); cy < d.ny; cy = next.fetch_add(1)) do_row(cy, rows[(size_t)cy]); };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
     }
+    for (int cy = 0; cy < d.ny; cy++) {
+        const GridRowOut &o = rows[(size_t)cy];
+        const int e0 = (int)g.ent.size() - d.ent_base, c0 = (int)g.cent.size() - d.cent_base;
+        for (int v : o.off) g.off.push_back(e0 + v);
+        for (int v : o.coff) g.coff.push_back(c0 + v);
+        g.ent.insert(g.ent.end(), o.ent.begin(), o.ent.end());
+        g.cent.insert(g.cent.end(), o.cent.begin(), o.cent.end());
+        if (o.max_row > g.max_row) g.max_row = o.max_row;
+    }
+    rows.clear();
     g.off.push_back((int)g.ent.size() - d.ent_base);
     g.coff.push_back((int)g.cent.size() - d.cent_base);
     d.crow_base = (int)g.crows.size();
@@ -2543,7 +2660,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         for (int m = 0; m < n_maps; m++)
             build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, cfg->n_rays, tab->ray_dx, tab->ray_dy, reach, m_ray,
                         cfg->agent_radius + 1e-6, cell, grid_host, geo_i.data() + descs[m].i32_off, geo_i.data() + descs[m].i32_off + descs[m].S,
-                        cfg->wall_radius + cfg->ray_radius);
+                        cfg->wall_radius + cfg->ray_radius, cfg->ray_radius);
         finalize_rows(grid_host);
     }
     // Rays that meet few walls (every list fits one packed row word, ids and agents fit 6 bits, an agent's rays fit four chunks):
@@ -2928,7 +3045,7 @@ extern "C" int cat_grid_build_host(const cat_config *cfg, const cat_tables *tab,
     gh->R = cfg->n_rays;
     build_grids(f.data() + 2, S, cfg->n_rays, tab->ray_dx, tab->ray_dy, cfg->ray_length + cfg->ray_radius + 1e-3,
                 cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6, cfg->agent_radius + 1e-6, cell > 0 ? cell : 8.0, gh->g,
-                iv.data(), iv.data() + S, cfg->wall_radius + cfg->ray_radius);
+                iv.data(), iv.data() + S, cfg->wall_radius + cfg->ray_radius, cfg->ray_radius);
     finalize_rows(gh->g);
     *out = gh;
     return CAT_OK;

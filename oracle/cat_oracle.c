@@ -295,6 +295,11 @@ static void sort_cands(seg_cand *c, int n)
    ascending t_bb; cato_set_index_order(0) switches to that order (ascending t_bb, index on equal values) so that
    tools/query_order_diff.py can count the observations that depend on it (0.003 - 0.2 % of the rays, by map: two walls
    whose hits lie less than the ray radius apart, DESIGN D2). */
+/* Diagnostic (tests of the product's candidate tables): when set, cato_segment_query visits only the walls whose byte is non-zero,
+   in index order as always.  Never set by a stepping sim; single-threaded use. */
+static const uint8_t *g_wall_subset = NULL;
+void cato_set_wall_subset(const uint8_t *mask) { g_wall_subset = mask; }
+
 static int segment_query_first(const cato_sim *s, int env, int self, double ax, double ay,
                                double bx, double by, double r2, int los, seg_info *out)
 {
@@ -308,6 +313,7 @@ static int segment_query_first(const cato_sim *s, int env, int self, double ax, 
     seg_cand cand[256 + CATO_MAX_AGENTS];
     int n = 0;
     for (int sh = 0; sh < m->S; sh++) {
+        if (g_wall_subset && !g_wall_subset[sh]) continue;   /* diagnostic: the walls a caller's candidate table lists */
         double tbb = c->bbtree_gate ? bb_segment_query(m->bb + 4 * (size_t)sh, ax, ay, dx, dy, idx, idy) : 0.0;
         if (tbb < 1.0 || !c->bbtree_gate) { cand[n].tbb = tbb; cand[n].id = sh; n++; }
     }

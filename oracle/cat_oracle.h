@@ -123,6 +123,8 @@ void cato_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[
    returns hit shape (-1 none), writes alpha and point. */
 int cato_segment_query(cato_sim *s, int env, int self, double ax, double ay, double bx, double by,
                        double r2, int los, double *alpha, double *point_xy);
+/* diagnostic: cato_segment_query visits only the walls whose byte in mask[S] is non-zero (NULL: all walls, the default) */
+void cato_set_wall_subset(const uint8_t *mask);
 /* point_query_nearest(p, maxd) != None, as agent `self` */
 int cato_point_query_any(cato_sim *s, int env, int self, double px, double py, double maxd);
 

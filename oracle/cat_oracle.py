@@ -67,6 +67,8 @@ def lib():
         _lib.cato_obs_distance_f16.restype = C.c_uint16
         _lib.cato_obs_distance_f16.argtypes = [C.c_double] * 4
         _lib.cato_segment_query.restype = C.c_int
+        _lib.cato_set_wall_subset.restype = None
+        _lib.cato_set_wall_subset.argtypes = [C.c_void_p]
         _lib.cato_segment_query.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_double] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
         _lib.cato_point_query_any.restype = C.c_int
         _lib.cato_point_query_any.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
@@ -164,11 +166,21 @@ class OracleSim:
         keep = {k: np.ascontiguousarray(v, dtype=alloc_state(1, self.A)[k].dtype) for k, v in arrays.items()}
         lib().cato_set_state(self._h, C.byref(_State(*[_ptr(keep.get(n)) for n in _STATE_FIELDS])))
 
-    def segment_query(self, env, self_agent, a, b, r2, los=False):
+    def segment_query(self, env, self_agent, a, b, r2, los=False, walls=None):
+        """``walls``: visit only these wall ids (diagnostic: the list a candidate table holds for the ray); None = every wall."""
         alpha = C.c_double()
         pt = (C.c_double * 2)()
-        sh = lib().cato_segment_query(self._h, env, self_agent, a[0], a[1], b[0], b[1], r2, int(los),
-                                      C.byref(alpha), pt)
+        mask = None
+        if walls is not None:
+            mask = np.zeros(1024, np.uint8)        # one byte per wall id (maps hold at most 256 shapes)
+            mask[list(walls)] = 1
+            lib().cato_set_wall_subset(mask.ctypes.data_as(C.c_void_p))
+        try:
+            sh = lib().cato_segment_query(self._h, env, self_agent, a[0], a[1], b[0], b[1], r2, int(los),
+                                          C.byref(alpha), pt)
+        finally:
+            if mask is not None:
+                lib().cato_set_wall_subset(None)
         return sh, alpha.value, (pt[0], pt[1])
 
     def point_query_any(self, env, self_agent, p, maxd):

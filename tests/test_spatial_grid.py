@@ -1,7 +1,9 @@
 """The spatial-hash ray grid built at cat_create must list, for (cell of the origin, ray index), every wall that can matter to
 cpSpaceSegmentQueryFirst: a wall whose bb the thin segment enters (cpBBSegmentQuery finite: it is visited) AND whose rounded hull
 the ray can touch (segment within wall radius + ray radius of the hull: only then can the visit return a hit).  With
-CAT_GRID_HULLS=0 the table keeps every wall of the first kind.  Brute-force check on the host copy of the tables (no GPU)."""
+CAT_GRID_HULLS=0 the table keeps every wall of the first kind.  The third rule, occlusion, takes out walls that ARE visitable and
+hittable for some origins but can never change the result: that is checked on the results (last test).  Brute-force checks on the
+host copy of the tables (no GPU)."""
 import ctypes as C
 
 import numpy as np
@@ -79,6 +81,7 @@ def _seg_hull_distance(hull, ax, ay, bx, by):
                                                   ("lbirinth", 90, 48, 1), ("agh-map", 64, 16, 0)])
 def test_ray_grid_lists_every_wall_that_can_be_visited_and_hit(name, rays, cell, hulls, monkeypatch):
     monkeypatch.setenv("CAT_GRID_HULLS", str(hulls))
+    monkeypatch.setenv("CAT_GRID_OCCLUSION", "0")      # rules 1 and 2 of build_grids; rule 3 (occlusion) is checked through the query results below
     cmap = load_preset(name).compile()
     cfg = SimConfig(n_rays=rays)
     L, h, rdx, rdy = _grid(cmap, cfg, cell)
@@ -127,4 +130,38 @@ def test_contact_grid_lists_every_wall_within_agent_radius():
         r = cfg.agent_radius
         want = np.nonzero((bb[:, 0] <= x + r) & (x - r <= bb[:, 2]) & (bb[:, 1] <= y + r) & (y - r <= bb[:, 3]))[0]
         assert set(want) <= got
+    L.cat_grid_free_host(h)
+
+
+@pytest.mark.parametrize("name,rays,cell,gate", [("agh-map", 64, 8, 1), ("agh-map", 90, 16, 1), ("labyrinth", 64, 8, 1), ("lbirinth", 64, 8, 1),
+                                                 ("agh-map", 64, 8, 0), ("grandbyrinth", 64, 8, 1)])
+def test_segment_query_over_the_listed_walls_equals_the_query_over_all_walls(name, rays, cell, gate):
+    """The table's three rules (visit, hit, occlusion -- build_grids) may drop walls, never change a result: for any origin and ray
+    the oracle's sequential wall query gives the same (wall, alpha bits, point) over the listed walls as over every wall."""
+    from oracle.cat_oracle import OracleSim
+    cmap = load_preset(name).compile()
+    cfg = SimConfig(n_envs=1, n_rays=rays, bbtree_gate=gate)
+    L, h, rdx, rdy = _grid(cmap, cfg, cell)
+    orc = OracleSim(cfg, [cmap])
+    rng = np.random.default_rng(7)
+    lo = cmap.shape_bb[:, :2].min(0) - 60; hi = cmap.shape_bb[:, 2:].max(0) + 60
+    out = (C.c_int * 256)()
+    dropped = listed = 0
+    for trial in range(1500):
+        if trial % 5 == 0:      # origins right at walls (their bb edges, a hair inside / outside) and on cell borders
+            s_ = rng.integers(cmap.n_shapes)
+            ax = cmap.shape_bb[s_, rng.choice([0, 2])] + rng.choice([-2.0, -1e-9, 0.0, 1e-9, 2.0])
+            ay = rng.uniform(cmap.shape_bb[s_, 1] - 3, cmap.shape_bb[s_, 3] + 3)
+            if trial % 10 == 0:
+                ax, ay = np.floor(ax / cell) * cell, np.floor(ay / cell) * cell
+        else:
+            ax, ay = rng.uniform(lo, hi)
+        for k in rng.choice(rays, 16, replace=False):
+            b = (ax + rdx[k], ay + rdy[k])
+            n = L.cat_grid_lookup_host(h, float(ax), float(ay), int(k), out, 256)
+            full = orc.segment_query(0, -1, (ax, ay), b, cfg.ray_radius, los=True)
+            part = orc.segment_query(0, -1, (ax, ay), b, cfg.ray_radius, los=True, walls=list(out[:n]))
+            assert (full[0], np.float64(full[1]).tobytes(), full[2]) == (part[0], np.float64(part[1]).tobytes(), part[2]), \
+                (name, ax, ay, int(k), full, part, list(out[:n]))
+            listed += n
     L.cat_grid_free_host(h)
