@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -2248,7 +2249,8 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
     // one row of cells: its part of the CSR arrays, offsets relative to the row
     auto do_row = [&](int cy, GridRowOut &o) {
         std::vector<int> near, list;     // walls within reach of the cell (prefilter); the walls listed for (cell, ray)
-        std::vector<double> t_sure, f_lo, b_hi;
+        std::vector<double> f_lo, b_hi, cuts;
+        std::vector<RotPoly> hulls;
         for (int cx = 0; cx < d.nx; cx++) {
             const double X0 = d.x0 + cx * cell - eps, X1 = d.x0 + (cx + 1) * cell + eps;
             const double Y0 = d.y0 + cy * cell - eps, Y1 = d.y0 + (cy + 1) * cell + eps;
@@ -2260,8 +2262,8 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                     o.cent.push_back((unsigned char)s);
                 if (l - reach <= X1 && X0 <= r + reach && b - reach <= Y1 && Y0 <= t + reach) near.push_back(s);
             }
-            for (int k = 0; k < R; k++) {
-                o.off.push_back((int)o.ent.size());
+            // the walls listed for ray k and the origins of the rectangle [X0, X1] x [Y0, Y1] (rules 1 - 3), ascending, into `list`
+            auto list_for = [&](int k, double X0, double X1, double Y0, double Y1) {
                 const double dx = rdx[k], dy = rdy[k];
                 const double hx0 = X0 + std::fmin(0.0, dx) - eps, hx1 = X1 + std::fmax(0.0, dx) + eps;
                 const double hy0 = Y0 + std::fmin(0.0, dy) - eps, hy1 = Y1 + std::fmax(0.0, dy) + eps;
@@ -2302,20 +2304,24 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                     const double amin = std::fmin(std::fmin(a0, a1), std::fmin(a2, a3)), amax = std::fmax(std::fmax(a0, a1), std::fmax(a2, a3));
                     const double ms = eps * nscale;   // a margin across the ray, in the units of pmin / pmax
                     const size_t n = list.size();
-                    t_sure.assign(n, 1e300); f_lo.assign(n, 1e300); b_hi.assign(n, -1e300);
-                    double T = 1e300;
+                    f_lo.assign(n, 1e300); b_hi.assign(n, -1e300);
+                    hulls.resize(n);
+                    cuts.clear();
+                    cuts.push_back(pmin); cuts.push_back(pmax);
                     for (size_t q = 0; q < n; q++) {
                         const int s = list[q];
-                        RotPoly H, B, F;
+                        RotPoly &H = hulls[q];
+                        RotPoly B, F;
                         const double *pl = planes + 8 * (size_t)hull_first[s];
                         H.n = hull_count[s];
                         for (int e = 0; e < H.n; e++) {
                             const double vx = pl[8 * e + 2], vy = pl[8 * e + 3];
                             H.al[e] = (vx * dx + vy * dy) / dd; H.si[e] = -dy * vx + dx * vy;
+                            if (pmin < H.si[e] && H.si[e] < pmax) cuts.push_back(H.si[e]);
                         }
                         H.close();
                         const double l = bb[4 * s], b = bb[4 * s + 1], r = bb[4 * s + 2], t = bb[4 * s + 3];
-                        const double gw = m_ray > 0.5 * ray_radius ? ray_radius : 0.0;   // gate off: every listed wall counts as entered at once
+                        const bool gate_off = m_ray > 0.5 * ray_radius && ray_radius > 0.0;   // every listed wall counts as entered at once
                         const double cxs[4] = {l, r, r, l}, cys[4] = {b, b, t, t};
                         B.n = F.n = 4;
                         for (int e = 0; e < 4; e++) {
@@ -2325,15 +2331,31 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                         }
                         B.close(); F.close();
                         double emin, emax;
-                        // every ray of the cell crosses the hull: offsets inside the hull's, origins before it, the crossing within the ray
-                        if (H.n >= 3 && pmin >= H.smin + ms && pmax <= H.smax - ms && H.entry_range(pmin, pmax, emin, emax) &&
-                            amax <= emin - mt && emax - amin <= 1.0 - mt)
-                            t_sure[q] = emax - amin + mt;
                         if (F.entry_range(pmin, pmax, emin, emax)) f_lo[q] = std::fmax(0.0, emin - amax) - mt;
-                        if (gw > 0.0) b_hi[q] = 0.0;
+                        if (gate_off) b_hi[q] = 0.0;
                         else if (B.entry_range(pmin, pmax, emin, emax)) b_hi[q] = std::fmax(0.0, emax - amin) + mt;
-                        T = std::fmin(T, t_sure[q]);
                     }
+                    // T: by when every ray of the cell has certainly crossed the hull of SOME listed wall.  Between two neighbouring
+                    // cuts (the cell's span across the ray, cut at the hull vertices inside it) every hull's entry depth is linear; a
+                    // hull counts there if it spans the piece (a ray passing a hair -- ms -- outside its end vertex still meets the
+                    // rounded shape before that vertex's depth) and every origin of the cell lies before it; the piece's bound is the
+                    // smallest of the hulls' larger end values (max-min <= min-max), T the largest bound of any piece.
+                    std::sort(cuts.begin(), cuts.end());
+                    double T = -1e300;
+                    for (size_t c = 0; c + 1 < cuts.size() && T < 1e299; c++) {
+                        const double lft = cuts[c], rgt = cuts[c + 1];
+                        if (!(lft < rgt)) continue;
+                        double best = 1e300;
+                        for (size_t q = 0; q < n; q++) {
+                            const RotPoly &H = hulls[q];
+                            if (H.n < 3 || !(H.smin - ms <= lft && rgt <= H.smax + ms)) continue;
+                            const double e0 = H.entry(std::fmin(std::fmax(lft, H.smin), H.smax)), e1 = H.entry(std::fmin(std::fmax(rgt, H.smin), H.smax));
+                            if (!(amax <= std::fmin(e0, e1) - mt)) continue;
+                            best = std::fmin(best, std::fmax(e0, e1));
+                        }
+                        T = std::fmax(T, best);
+                    }
+                    T = (T > -1e299 && T < 1e299 && T - amin <= 1.0 - 2.0 * mt) ? T - amin + mt : 1e300;
                     if (T < 1e299) {
                         for (bool again = true; again;) {
                             again = false;
@@ -2345,6 +2367,10 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                         list.resize(w);
                     }
                 }
+            };
+            for (int k = 0; k < R; k++) {
+                o.off.push_back((int)o.ent.size());
+                list_for(k, X0, X1, Y0, Y1);
                 for (int s : list) o.ent.push_back((unsigned char)s);
                 if ((int)list.size() > o.max_row) o.max_row = (int)list.size();
             }
@@ -2653,14 +2679,31 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     // ---- spatial-hash grids per map (cell size: CAT_GRID_CELL px, default 8); their longest candidate list picks the ray fan
     GridHost grid_host;
     {
-        double cell = 8.0;   // 16 -> 8 px: lists 15 % shorter, tables 2 - 4 x larger (labyrinth 39 MB, agh-map 66 MB), kernel 2 - 3 % faster
-        if (const char *e = getenv("CAT_GRID_CELL")) { double v = atof(e); if (v >= 4.0 && v <= 512.0) cell = v; }
+        // Cell size: the smaller the cell, the tighter the three listing rules (agh-map, entries per ray: 16 px 2.1, 8 px 1.56, 4 px 1.35;
+        // kernel 70.0 -> 64.6 us from 8 to 4 px) and the larger the table (rows of 8 - 16 B per cell and ray: labyrinth 38 -> 151 MB,
+        // agh-map 64 -> 251 MB).  4 px while a map's table stays under 384 MB, else 8, 16 ...; CAT_GRID_CELL fixes it.
+        double forced_cell = 0.0;
+        if (const char *e = getenv("CAT_GRID_CELL")) { double v = atof(e); if (v >= 2.0 && v <= 512.0) forced_cell = v; }
         const double reach = cfg->ray_length + cfg->ray_radius + 1e-3;
         const double m_ray = cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6;
-        for (int m = 0; m < n_maps; m++)
+        for (int m = 0; m < n_maps; m++) {
+            double cell = forced_cell;
+            if (cell == 0.0) {
+                const double *bbm = geo_f.data() + descs[m].f64_off;
+                double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+                for (int sidx = 0; sidx < descs[m].S; sidx++) {
+                    lo[0] = std::fmin(lo[0], bbm[4 * sidx]); lo[1] = std::fmin(lo[1], bbm[4 * sidx + 1]);
+                    hi[0] = std::fmax(hi[0], bbm[4 * sidx + 2]); hi[1] = std::fmax(hi[1], bbm[4 * sidx + 3]);
+                }
+                for (cell = 4.0; cell < 256.0; cell *= 2.0) {
+                    const double rows = std::ceil((hi[0] - lo[0] + 2.0 * reach) / cell + 2.0) * std::ceil((hi[1] - lo[1] + 2.0 * reach) / cell + 2.0) * cfg->n_rays;
+                    if (rows * 16.0 <= 384e6) break;
+                }
+            }
             build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, cfg->n_rays, tab->ray_dx, tab->ray_dy, reach, m_ray,
                         cfg->agent_radius + 1e-6, cell, grid_host, geo_i.data() + descs[m].i32_off, geo_i.data() + descs[m].i32_off + descs[m].S,
                         cfg->wall_radius + cfg->ray_radius, cfg->ray_radius);
+        }
         finalize_rows(grid_host);
     }
     // Rays that meet few walls (every list fits one packed row word, ids and agents fit 6 bits, an agent's rays fit four chunks):

@@ -256,10 +256,14 @@ def _picket_map(tmp_path, n_posts):
     return Map(f).compile()
 
 
-def test_more_than_31_candidate_walls_on_one_ray(tmp_path):
-    """Packed ray-grid rows hold 31 ids; 40 posts in a row force the CSR continuation of the candidate list."""
+@pytest.mark.parametrize("occlusion", [0, 1])
+def test_more_than_31_candidate_walls_on_one_ray(tmp_path, monkeypatch, occlusion):
+    """Packed ray-grid rows hold 31 ids; 40 posts in a row force the CSR continuation of the candidate list -- with the table's
+    occlusion rule switched off (CAT_GRID_OCCLUSION=0: every post behind the first is listed); with it on the same map runs with
+    short lists, and both must agree with the oracle, which visits all 44 walls."""
     import ctypes as C
     from as_cops_and_thieves_amd.config import SimConfig
+    monkeypatch.setenv("CAT_GRID_OCCLUSION", str(occlusion))
     m = _picket_map(tmp_path, 40)
     cfg = SimConfig(n_envs=16, n_cops=2, n_thieves=1, n_rays=64, max_step_count=60, seed=5)
     gpu, cpu = _pair(cfg, [m], np.zeros(16, np.int32))
@@ -267,7 +271,7 @@ def test_more_than_31_candidate_walls_on_one_ray(tmp_path):
     from as_cops_and_thieves_amd import _native as nat
     longest = max(nat.lib().cat_debug_grid_lookup(gpu._h, 0, 30.0, 201.0, k, out, 256) for k in range(64))
     gpu.close()
-    assert longest > 31, longest
+    assert (longest > 31) if occlusion == 0 else (longest <= 31), longest
     _run(cfg, [m], np.zeros(16, np.int32), ticks=70, rng=np.random.default_rng(3), auto_reset=True)
 
 
