@@ -1888,6 +1888,9 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
     PHASE(pc, 16);
     if (fin_mask) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the other waves' units of those slots
     PHASE(pc, 21);
+#ifdef CAT_PHASE_TIMING
+    bool wb_first = true;
+#endif
     while (fin_mask) {
         const int slot = uni(__builtin_ctz(fin_mask));
         fin_mask &= fin_mask - 1;
@@ -1895,6 +1898,11 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         const int e_s = uni(L.ctrl[4 * slot + 3]);
         const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
         PHASE(pc, 22);
+#ifdef CAT_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic: what the wave still has in flight when it starts a write-back
+        if (wb_first) PHASE(pc, 23); else PHASE(pc, 3);       // its first one / a further one (the stores of the one before)
+        wb_first = false;
+#endif
         LateOut late;
         rewards_and_positions<D>(Ls, p, la, lane, tick, captured2, timeout2, cop_lut, thief_lut, late);
         PHASE(pc, 17);

@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 L.cat_debug_phase_cycles(buf, 1)
 # a mark closes the span since the previous mark of the same wave, so with shared work units the spans also contain
 # the claim/scan steps that precede them; "tail" = everything after a wave's last unit (scan, waits, write-back)
-names = {21: "write-back: acquire fence", 22: "write-back: slot area + flags", 0: "stage_map", 1: "state -> LDS", 2: "termination+actions", 4: "agent setup (cells, cones)",
+names = {3: "write-back: stores of the wave's previous write-back still in flight", 23: "write-back (first of the wave): older memory operations in flight", 21: "write-back: acquire fence", 22: "write-back: slot area + flags", 0: "stage_map", 1: "state -> LDS", 2: "termination+actions", 4: "agent setup (cells, cones)",
          5: "packing (gate)", 20: "unit claim + chunk prologue (row fetch)", 16: "after last unit: scan / wait for open units", 17: "write-back: rewards (LUT)", 18: "write-back: state record", 19: "write-back: shared obs + output stores", 6: "dense items (hull query)", 7: "per-ray resolve", 8: "hit point + f16",
          9: "before physics unit", 10: "physics (rest)", 11: "kernel end", 12: "phys: integrate",
          13: "phys: wall broadphase+narrow", 14: "phys: pairs", 15: "phys: aging"}
