@@ -165,3 +165,64 @@ def test_segment_query_over_the_listed_walls_equals_the_query_over_all_walls(nam
                 (name, ax, ay, int(k), full, part, list(out[:n]))
             listed += n
     L.cat_grid_free_host(h)
+
+
+def _random_polygon_map(tmp_path, seed, n_blocks):
+    """Convex blocks of every kind the rules have to get right: slivers, slanted boxes, triangles, blocks that touch along an
+    edge, overlap, or sit a hair (less than the ray radius) apart, and a ring of border walls."""
+    import json
+    from as_cops_and_thieves_amd.maps import Map
+    rng = np.random.default_rng(seed)
+    blocks = []
+    for q in range(n_blocks):
+        cx, cy = rng.uniform(60, 580), rng.uniform(60, 420)
+        kind = q % 5
+        if kind == 0:      # axis-aligned box, sometimes a sliver
+            w, h_ = rng.uniform(2, 80), rng.uniform(2, 80)
+            blocks.append({"type": "rect", "x": cx, "y": cy, "w": w, "h": h_})
+            if q % 10 == 0:      # a neighbour sharing its right edge, and one 0.5 px away from its top edge
+                blocks.append({"type": "rect", "x": cx + w, "y": cy, "w": rng.uniform(5, 40), "h": h_})
+                blocks.append({"type": "rect", "x": cx, "y": cy + h_ + 0.5, "w": w, "h": rng.uniform(3, 20)})
+        else:              # convex polygon with 3 - 7 vertices on an ellipse, rotated
+            n = int(rng.integers(3, 8))
+            a, b, rot = rng.uniform(3, 60), rng.uniform(3, 60), rng.uniform(0, np.pi)
+            ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+            vs = [{"x": float(cx + a * np.cos(t) * np.cos(rot) - b * np.sin(t) * np.sin(rot)),
+                   "y": float(cy + a * np.cos(t) * np.sin(rot) + b * np.sin(t) * np.cos(rot))} for t in ang]
+            blocks.append({"type": "poly", "vs": vs})
+    blocks += [{"type": "rect", "x": 10, "y": 10, "w": 5, "h": 460}, {"type": "rect", "x": 10, "y": 470, "w": 620, "h": 5},
+               {"type": "rect", "x": 630, "y": 10, "w": 5, "h": 465}, {"type": "rect", "x": 10, "y": 10, "w": 620, "h": 5}]
+    agents = [{"type": "cop", "x": 30, "y": 30}, {"type": "cop", "x": 60, "y": 30}, {"type": "thief", "x": 30, "y": 450}]
+    f = tmp_path / f"random_{seed}.json"
+    f.write_text(json.dumps({"window": {"w_px": 640, "h_px": 480}, "canvas": {"w": 640, "h": 480},
+                             "objects": {"blocks": blocks}, "agents": agents}))
+    return Map(f).compile()
+
+
+@pytest.mark.parametrize("seed,cell,gate", [(1, 4, 1), (2, 8, 1), (3, 4, 1), (4, 16, 1), (5, 4, 0), (6, 6, 1)])
+def test_listed_walls_give_the_full_query_result_on_random_polygon_maps(tmp_path, seed, cell, gate):
+    from oracle.cat_oracle import OracleSim
+    cmap = _random_polygon_map(tmp_path, seed, 30)
+    cfg = SimConfig(n_envs=1, n_rays=64, bbtree_gate=gate)
+    L, h, rdx, rdy = _grid(cmap, cfg, cell)
+    orc = OracleSim(cfg, [cmap])
+    rng = np.random.default_rng(100 + seed)
+    out = (C.c_int * 256)()
+    shorter = 0
+    for trial in range(2500):
+        if trial % 4 == 0:      # right at a wall's bb, a hair inside / outside, or within the ray radius of it
+            s_ = rng.integers(cmap.n_shapes)
+            ax = cmap.shape_bb[s_, rng.choice([0, 2])] + rng.choice([-2.5, -1.0, -1e-9, 0.0, 1e-9, 1.0, 2.5])
+            ay = rng.uniform(cmap.shape_bb[s_, 1] - 3, cmap.shape_bb[s_, 3] + 3)
+            if trial % 8 == 0:
+                ax, ay = np.floor(ax / cell) * cell, np.floor(ay / cell) * cell
+        else:
+            ax, ay = rng.uniform([0, 0], [640, 480])
+        for k in rng.choice(64, 12, replace=False):
+            b = (ax + rdx[k], ay + rdy[k])
+            n = L.cat_grid_lookup_host(h, float(ax), float(ay), int(k), out, 256)
+            full = orc.segment_query(0, -1, (ax, ay), b, cfg.ray_radius, los=True)
+            part = orc.segment_query(0, -1, (ax, ay), b, cfg.ray_radius, los=True, walls=list(out[:n]))
+            assert (full[0], np.float64(full[1]).tobytes(), full[2]) == (part[0], np.float64(part[1]).tobytes(), part[2]), \
+                (seed, ax, ay, int(k), full, part, list(out[:n]))
+    L.cat_grid_free_host(h)
