@@ -88,6 +88,17 @@ def test_chunk_form_of_the_ray_fan_on_the_light_maps(name, rays, monkeypatch):
     assert stats["done"] >= 32
 
 
+@pytest.mark.parametrize("switch,value", [("CAT_GRID_HULLS", "0"), ("CAT_GRID_OCCLUSION", "0"), ("CAT_GRID_CELL", "16"), ("CAT_GRID_CELL", "5")])
+@pytest.mark.parametrize("name", ["agh-map", "labyrinth"])
+def test_results_do_not_depend_on_the_rules_that_build_the_candidate_table(name, switch, value, monkeypatch):
+    """The spatial hash lists fewer walls with each of its rules on (cat_sim.hip build_grids: the hull rule, the occlusion rule, the
+    smaller cell); the oracle visits every wall.  Bit-exact parity with each of them switched off or coarsened."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    monkeypatch.setenv(switch, value)
+    cfg = SimConfig(n_envs=32, n_rays=64, max_step_count=60, seed=17)
+    _run(cfg, [compiled(name)], None, ticks=80, rng=np.random.default_rng(6), spread=40.0)
+
+
 @pytest.mark.parametrize("rays", [100, 130, 200, 256, 300])
 def test_group_form_of_the_ray_fan_across_ray_counts(rays):
     """fan_group groups two agents while their rays fill at most four 64-ray chunks (R <= 128) and one agent beyond (R <= 256: three
