@@ -99,6 +99,26 @@ def test_results_do_not_depend_on_the_rules_that_build_the_candidate_table(name,
     _run(cfg, [compiled(name)], None, ticks=80, rng=np.random.default_rng(6), spread=40.0)
 
 
+@pytest.mark.parametrize("seed,rays", [(11, 64), (12, 90), (13, 64)])
+def test_parity_on_random_polygon_maps(tmp_path, seed, rays):
+    """Slanted, touching, overlapping and sliver blocks (tests/test_spatial_grid.py builds them): the candidate table's hull and
+    occlusion rules meet every case they reason about, with agents spawned all over the map."""
+    import json
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.maps import Map
+    from tests.test_spatial_grid import _random_polygon_map
+    _random_polygon_map(tmp_path, seed, 14)
+    f = tmp_path / f"random_{seed}.json"
+    data = json.loads(f.read_text())
+    everywhere = {"x": 20, "y": 20, "w": 600, "h": 440}
+    for a in data["agents"]:
+        a["spawn_region"] = everywhere
+    f.write_text(json.dumps(data))
+    m = Map(f).compile()
+    cfg = SimConfig(n_envs=64, n_rays=rays, max_step_count=25, seed=seed)
+    _run(cfg, [m], np.zeros(64, np.int32), ticks=80, rng=np.random.default_rng(seed), auto_reset=True)
+
+
 @pytest.mark.parametrize("rays", [100, 130, 200, 256, 300])
 def test_group_form_of_the_ray_fan_across_ray_counts(rays):
     """fan_group groups two agents while their rays fill at most four 64-ray chunks (R <= 128) and one agent beyond (R <= 256: three
