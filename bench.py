@@ -95,9 +95,13 @@ def cpu_baseline(cfg, cmap, budget_s: float = 12.0):
 
 
 def event_stride(steps: int) -> int:
-    """Which tick_kernel launches of the timed region carry HIP events: every 8th on a long run (each pair costs a
-    little host time), every 2nd when K <= 40 so that the driver's --steps 20 still times 10 launches."""
-    return 2 if steps <= 40 else 8
+    """Which tick_kernel launches of the timed region carry their own pair of HIP events: every 8th on a long run; NONE (0) when
+    K <= 40 -- a dispatch with events attached costs ~4 us of host / command-processor time (K = 20: 37.4 us per step with every
+    launch bracketed, 34.5 with every 2nd, 32.4 with none), which a 20-step region does not absorb.  A short region is
+    timed by ONE pair of events recorded on the kernel's stream around all K launches instead (timed_steps)."""
+    if os.environ.get("CAT_BENCH_EVENT_STRIDE"):      # measurement of the instrumentation's own cost (DESIGN 5)
+        return max(0, int(os.environ["CAT_BENCH_EVENT_STRIDE"]))
+    return 0 if steps <= 40 else 8
 
 
 class HipEvents:
@@ -115,6 +119,7 @@ class HipEvents:
                     break
         self.lib = C.CDLL(path)
         self.lib.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.lib.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
         self.lib.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
 
     def create(self) -> int:
@@ -122,6 +127,10 @@ class HipEvents:
         if self.lib.hipEventCreate(self.C.byref(h)) != 0:
             raise RuntimeError("hipEventCreate failed")
         return h.value
+
+    def record(self, event: int, stream: int) -> None:
+        if self.lib.hipEventRecord(event, stream) != 0:
+            raise RuntimeError("hipEventRecord failed")
 
     def elapsed_ms(self, a: int, b: int) -> float:
         ms = self.C.c_float()
@@ -161,22 +170,31 @@ def build_sim(map_name: str, cops: int, thieves: int, envs: int, rays: int, rank
 
 def timed_steps(sim, steps: int, warmup: int, fence, hip: "HipEvents", first_tick: int = 0):
     """W untimed + K timed rollout steps (cat_step_fused: in-kernel Philox actions + tick + auto-reset, ONE launch per
-    step).  Every event_stride(K)-th tick_kernel launch of the timed region carries a pair of HIP events attached to the
+    step).  Long regions: every event_stride(K)-th tick_kernel launch carries a pair of HIP events attached to the
     dispatch itself (hipExtLaunchKernelGGL start/stop events, on the stream the kernel is launched on), so kernel_ms is
-    the kernel's own duration, as in a rocprofv3 kernel trace; events recorded AROUND the call would add the
-    inter-kernel dispatch gap (~5 us here).  Returns (seconds of the timed region on this rank, mean kernel ms, launches timed)."""
+    the kernel's own duration, as in a rocprofv3 kernel trace.  Short regions (K <= 40, the driver's --steps 20): one pair of
+    HIP events recorded on that stream around ALL K launches, kernel_ms = their span / K -- every launch of the region is timed,
+    the figure includes the gaps between consecutive launches (it is an upper bound of the trace's average), and no launch pays for
+    instrumentation.  Returns (seconds of the timed region on this rank, mean kernel ms, launches timed, method)."""
     for t in range(warmup):
         sim.step_fused(None, tick=first_tick + t, auto_reset=True)
-    ev = {k: (hip.create(), hip.create()) for k in range(0, steps, event_stride(steps))}
+    stride = event_stride(steps)
+    ev = {k: (hip.create(), hip.create()) for k in range(0, steps, stride)} if stride else {}
+    span = (hip.create(), hip.create())
+    stream = sim._stream()
     fence()
     t0 = time.perf_counter()
+    hip.record(span[0], stream)
     for k in range(steps):
         if k in ev:
             sim.arm_kernel_timing(*ev[k])
         sim.step_fused(None, tick=first_tick + warmup + k, auto_reset=True)
+    hip.record(span[1], stream)
     fence()
     elapsed = time.perf_counter() - t0
-    return elapsed, sum(hip.elapsed_ms(a, b) for a, b in ev.values()) / len(ev), len(ev)
+    if ev:
+        return elapsed, sum(hip.elapsed_ms(a, b) for a, b in ev.values()) / len(ev), len(ev), "HIP events attached to the dispatch"
+    return elapsed, hip.elapsed_ms(*span) / steps, steps, "one HIP event pair on the kernel's stream around the K launches, / K"
 
 
 def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16) -> dict:
@@ -303,7 +321,7 @@ def main() -> None:
     sim.reset()
     for t in range(args.burn_in):
         sim.step_fused(None, tick=t, auto_reset=True)
-    elapsed, tick_ms, n_timed = timed_steps(sim, args.steps, args.warmup, fence, hip, first_tick=args.burn_in)
+    elapsed, tick_ms, n_timed, tick_method = timed_steps(sim, args.steps, args.warmup, fence, hip, first_tick=args.burn_in)
     elapsed = max_over_ranks(elapsed, device=None if rehearse else dev)   # the slowest rank bounds the whole-job rate
     episodes = int(sim.get_state()["reset_count"].sum().item())
     sim.close()
@@ -328,7 +346,7 @@ def main() -> None:
         s2, c2, m2 = build_sim(w["map"], w["cops"], w["thieves"], w["envs"], w.get("rays", args.rays), rank, dev)
         s2.reset()
         k_steps = 300                                   # own step counts: the driver's --steps 20 --warmup 5 would only
-        e2, k2, _ = timed_steps(s2, k_steps, 100, fence, hip)   # see the first ticks after the reset
+        e2, k2, _, _ = timed_steps(s2, k_steps, 100, fence, hip)   # see the first ticks after the reset
         e2 = max_over_ranks(e2, device=None if rehearse else dev)
         bytes2 = algorithmic_bytes_per_env_step(c2.n_agents, c2.n_rays) * c2.n_envs
         s2.close()
@@ -382,7 +400,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_regime": traffic_regime,
                          "traffic_from_reset": traffic_from_reset, "traffic_source": traffic_source,
-                         "kernel": "tick_kernel", "kernel_ms": tick_ms, "kernel_launches_timed": n_timed,
+                         "kernel": "tick_kernel", "kernel_ms": tick_ms, "kernel_launches_timed": n_timed, "kernel_ms_method": tick_method,
                          "algorithmic_bytes_per_launch": bytes_launch, "valu": valu, "valu_source": traffic_source,
                          "hbm_stream_copy_GBs": copy_gbs,
                          "frac_of_stream_copy": (achieved / copy_gbs) if copy_gbs else None,

@@ -13,8 +13,8 @@ def test_algorithmic_bytes_follow_survey_8d():
     assert bench.algorithmic_bytes_per_env_step(5, 64) == 108 * 5 + 3 * 5 * 64 + 6 * 64 + 8
 
 
-def test_short_runs_time_every_second_launch():
-    assert bench.event_stride(20) == 2 and len(range(0, 20, bench.event_stride(20))) == 10    # the driver's --steps 20
+def test_short_regions_carry_no_per_dispatch_events():
+    assert bench.event_stride(20) == 0      # the driver's --steps 20: one event pair around all 20 launches (timed_steps), none attached to a dispatch
     assert bench.event_stride(2000) == 8
 
 
