@@ -2187,7 +2187,7 @@ struct GridHost {
 // One map.  bb: [S][4] wall bbs (already inflated by the wall radius); the walls' plane records follow them (bb + 4 S:
 // n.x n.y v0.x v0.y dot(v0, n) ...; hull_first / hull_count index them).  Three rules decide whether a wall is listed for
 // (cell, ray k); all three keep [CP cpSpaceSegmentQueryFirst]'s result for every origin in the cell exactly as the full wall list gives it.
-//  1. The visit (always): the wall's bb, grown by `m_ray`, meets the region swept by the thin segment origin -> origin + d_k over
+//  1. The visit (always): the wall's bb, grown by 1e-6 (gate off: by the ray radius), meets the region swept by the thin segment origin -> origin + d_k over
 //     all origins of the cell: conv(cell, cell + d_k), a hexagon whose edge normals are x, y and perp(d_k) -- a separating-axis
 //     test on those three axes is exact.
 //  2. The hit (CAT_GRID_HULLS=0 turns it off): some ray of the cell can come within rsum = wall radius + ray radius of the HULL
@@ -2232,9 +2232,10 @@ struct RotPoly {   // a convex polygon seen from one ray direction: per vertex i
 struct GridRowOut { std::vector<int> off, coff; std::vector<unsigned char> ent, cent; int max_row = 0; };
 
 static void build_grids(const double *bb, int S, int R, const double *rdx, const double *rdy, double reach,
-                        double m_ray, double m_contact, double cell, GridHost &g, const int *hull_first, const int *hull_count,
+                        bool gate, double m_contact, double cell, GridHost &g, const int *hull_first, const int *hull_count,
                         double rsum, double ray_radius)
 {
+    const double m_ray = gate ? 1e-6 : ray_radius + 1e-6;   // gate off: every wall the fat ray can touch counts as visited
     const double *planes = bb + 4 * (size_t)S;
     bool by_hull = hull_first != nullptr, occlusion = hull_first != nullptr;
     if (const char *e = getenv("CAT_GRID_HULLS")) { if (atoi(e) == 0) by_hull = false; }
@@ -2329,7 +2330,6 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                         }
                         H.close();
                         const double l = bb[4 * s], b = bb[4 * s + 1], r = bb[4 * s + 2], t = bb[4 * s + 3];
-                        const bool gate_off = m_ray > 0.5 * ray_radius && ray_radius > 0.0;   // every listed wall counts as entered at once
                         const double cxs[4] = {l, r, r, l}, cys[4] = {b, b, t, t};
                         B.n = F.n = 4;
                         for (int e = 0; e < 4; e++) {
@@ -2340,7 +2340,7 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                         B.close(); F.close();
                         double emin, emax;
                         if (F.entry_range(pmin, pmax, emin, emax)) f_lo[q] = std::fmax(0.0, emin - amax) - mt;
-                        if (gate_off) b_hi[q] = 0.0;
+                        if (!gate) b_hi[q] = 0.0;   // every listed wall counts as entered at once
                         else if (B.entry_range(pmin, pmax, emin, emax)) b_hi[q] = std::fmax(0.0, emax - amin) + mt;
                     }
                     // T: by when every ray of the cell has certainly crossed the hull of SOME listed wall.  Between two neighbouring
@@ -2693,7 +2693,6 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         double forced_cell = 0.0;
         if (const char *e = getenv("CAT_GRID_CELL")) { double v = atof(e); if (v >= 2.0 && v <= 512.0) forced_cell = v; }
         const double reach = cfg->ray_length + cfg->ray_radius + 1e-3;
-        const double m_ray = cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6;
         for (int m = 0; m < n_maps; m++) {
             double cell = forced_cell;
             if (cell == 0.0) {
@@ -2708,7 +2707,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
                     if (rows * 16.0 <= 384e6) break;
                 }
             }
-            build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, cfg->n_rays, tab->ray_dx, tab->ray_dy, reach, m_ray,
+            build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, cfg->n_rays, tab->ray_dx, tab->ray_dy, reach, cfg->bbtree_gate != 0,
                         cfg->agent_radius + 1e-6, cell, grid_host, geo_i.data() + descs[m].i32_off, geo_i.data() + descs[m].i32_off + descs[m].S,
                         cfg->wall_radius + cfg->ray_radius, cfg->ray_radius);
         }
@@ -3095,7 +3094,7 @@ extern "C" int cat_grid_build_host(const cat_config *cfg, const cat_tables *tab,
     cat_grid_host *gh = new cat_grid_host();
     gh->R = cfg->n_rays;
     build_grids(f.data() + 2, S, cfg->n_rays, tab->ray_dx, tab->ray_dy, cfg->ray_length + cfg->ray_radius + 1e-3,
-                cfg->bbtree_gate ? 1e-6 : cfg->ray_radius + 1e-6, cfg->agent_radius + 1e-6, cell > 0 ? cell : 8.0, gh->g,
+                cfg->bbtree_gate != 0, cfg->agent_radius + 1e-6, cell > 0 ? cell : 8.0, gh->g,
                 iv.data(), iv.data() + S, cfg->wall_radius + cfg->ray_radius, cfg->ray_radius);
     finalize_rows(gh->g);
     *out = gh;
