@@ -2708,7 +2708,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
                 }
             }
             build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, cfg->n_rays, tab->ray_dx, tab->ray_dy, reach, cfg->bbtree_gate != 0,
-                        cfg->agent_radius + 1e-6, cell, grid_host, geo_i.data() + descs[m].i32_off, geo_i.data() + descs[m].i32_off + descs[m].S,
+                        cfg->ray_radius + 2e-6, cell, grid_host, geo_i.data() + descs[m].i32_off, geo_i.data() + descs[m].i32_off + descs[m].S,
                         cfg->wall_radius + cfg->ray_radius, cfg->ray_radius);
         }
         finalize_rows(grid_host);
@@ -3094,7 +3094,7 @@ extern "C" int cat_grid_build_host(const cat_config *cfg, const cat_tables *tab,
     cat_grid_host *gh = new cat_grid_host();
     gh->R = cfg->n_rays;
     build_grids(f.data() + 2, S, cfg->n_rays, tab->ray_dx, tab->ray_dy, cfg->ray_length + cfg->ray_radius + 1e-3,
-                cfg->bbtree_gate != 0, cfg->agent_radius + 1e-6, cell > 0 ? cell : 8.0, gh->g,
+                cfg->bbtree_gate != 0, cfg->ray_radius + 2e-6, cell > 0 ? cell : 8.0, gh->g,
                 iv.data(), iv.data() + S, cfg->wall_radius + cfg->ray_radius, cfg->ray_radius);
     finalize_rows(gh->g);
     *out = gh;

@@ -116,20 +116,30 @@ def test_ray_grid_lists_every_wall_that_can_be_visited_and_hit(name, rays, cell,
     L.cat_grid_free_host(h)
 
 
-def test_contact_grid_lists_every_wall_within_agent_radius():
+def test_contact_grid_lists_every_wall_whose_bb_is_within_the_ray_radius():
+    """The contact rows serve one rule, [CP cpShapeSegmentQuery]'s "start point within the query radius of the shape -> alpha 0"
+    (agent_setup): every wall whose bb comes within the ray radius of the origin must be listed for the origin's cell."""
     cmap = load_preset("agh-map").compile()
     cfg = SimConfig(n_rays=64)
-    L, h, *_ = _grid(cmap, cfg, 32)
+    L, h, *_ = _grid(cmap, cfg, 8)
     rng = np.random.default_rng(1)
     out = (C.c_int * 256)()
     bb = cmap.shape_bb
-    for _ in range(4000):
-        x, y = rng.uniform([-50, -50], [1350, 850])
+    longest = 0
+    for trial in range(6000):
+        if trial % 3 == 0:      # right at a wall's bb
+            s_ = rng.integers(cmap.n_shapes)
+            x = bb[s_, rng.choice([0, 2])] + rng.choice([-1.0, -1.0 + 1e-9, -1e-9, 0.0, 1e-9, 1.0 - 1e-9, 1.0])
+            y = rng.uniform(bb[s_, 1] - 1, bb[s_, 3] + 1)
+        else:
+            x, y = rng.uniform([-50, -50], [1350, 850])
         n = L.cat_grid_lookup_host(h, float(x), float(y), -1, out, 256)
         got = set(out[:n])
-        r = cfg.agent_radius
-        want = np.nonzero((bb[:, 0] <= x + r) & (x - r <= bb[:, 2]) & (bb[:, 1] <= y + r) & (y - r <= bb[:, 3]))[0]
+        r = cfg.ray_radius + 1e-6      # the margin agent_setup tests the origin against
+        want = np.nonzero((bb[:, 0] - r <= x) & (x <= bb[:, 2] + r) & (bb[:, 1] - r <= y) & (y <= bb[:, 3] + r))[0]
         assert set(want) <= got
+        longest = max(longest, n)
+    assert longest <= 7      # one packed row: no cell of the densest map needs the CSR continuation
     L.cat_grid_free_host(h)
 
 
