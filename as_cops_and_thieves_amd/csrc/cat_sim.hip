@@ -152,7 +152,8 @@ template <class D> __device__ __forceinline__ int group_agents(const Params &p)
 {
     // Two agents per unit when their rays fill at most four chunks: compaction across the pair (two cops in the open: ~40 active
     // rays of 128 -> one round) while a slot still has several units for the waves of the workgroup to share.  (All three agents of
-    // a 2v1 roster in ONE unit: 40.3 us against 37.9 on the labyrinth x4096; one agent per unit: 42.0.)
+    // a 2v1 roster in ONE unit: 40.3 us against 37.9 on the labyrinth x4096, 32.4 against 31.6 with the round-3 candidate table -- and
+    // 106.9 against 110.4 at 16384 envs, where the launch is several workgroup rounds long; one agent per unit: 42.0.)
     const int cpa = (D::R(p) + 63) / 64;
     return cpa <= 2 ? 2 : 1;
 }
