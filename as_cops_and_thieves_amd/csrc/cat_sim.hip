@@ -67,11 +67,11 @@ struct MapDesc {
 };
 
 // Spatial-hash grids, built once per (map, ray table) on the host (build_grids):
-//   ray grid     : (origin cell, ray index) -> ascending wall ids whose bb the thin segment of that ray
-//                  can enter from ANY origin inside the cell (a conservative superset; the exact
-//                  [CP cpBBSegmentQuery] gate is still evaluated per visit)
-//   contact grid : cell -> ascending wall ids whose bb comes within the agent radius of the cell
-//                  (broadphase of [CP cpSpaceStep], the "origin within ray radius" rule, spawn queries)
+//   ray grid     : (origin cell, ray index) -> ascending ids of the walls that can matter to that ray's query from ANY origin
+//                  inside the cell: visitable (bb), hittable (hull), not occluded by a certain earlier hit -- see build_grids;
+//                  the exact [CP cpBBSegmentQuery] gate and shape query are still evaluated per listed wall
+//   contact grid : cell -> ascending wall ids whose bb comes within the ray radius of the cell (the "origin within the
+//                  query radius of the shape" rule of the ray fan's setup)
 struct GridDesc {
     double x0, y0, inv_cell;
     int nx, ny;
