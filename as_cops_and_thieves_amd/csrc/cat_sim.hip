@@ -2728,16 +2728,17 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         const int cu = 256;
         int forced = 0;
         if (const char *e = getenv("CAT_WAVES_PER_BLOCK")) forced = atoi(e);
-        int best_score = -1;
-        for (int w = 1; w <= kMaxWaves; w *= 2) {
+        int best_score = -1, best_w = 0;
+        if (forced >= 1 && forced <= kMaxWaves && ls.total(forced) <= 160 * 1024) wpb = forced;   // any size, also not a power of two
+        for (int w = 1; w <= kMaxWaves && wpb == 0; w *= 2) {
             const size_t bytes = ls.total(w);
             if (bytes > 160 * 1024) continue;
-            if (forced == w) { wpb = w; break; }
             int resident = (int)((160 * 1024) / bytes) * w;
             if (resident > 16) resident = 16;
             const bool small_launch = (long long)N <= 2LL * 16 * cu;
-            if (resident > best_score || (resident == best_score && small_launch)) { best_score = resident; wpb = w; }
+            if (resident > best_score || (resident == best_score && small_launch)) { best_score = resident; best_w = w; }
         }
+        if (wpb == 0) wpb = best_w;
         if (wpb == 0) {
             snprintf(g_create_err, sizeof g_create_err, "LDS budget exceeded: %zu bytes for one env slot", ls.total(1));
             return CAT_ERR_BAD_CONFIG;
