@@ -112,7 +112,7 @@ struct Params {
     // in free space has no cached arbiter, and its slot then moves 96 A + 16 bytes per tick instead of the whole record.
     char *state;
     int rec_bytes, hot_bytes;
-    int maxE, ang_ok, row_words;
+    int maxE, ang_ok, row_words, row_id_bits, row_cnt_mul;   // four-byte rows: field width; (bit index * row_cnt_mul) >> 16 = field index
     float ang0, inv_step;
     // LDS carve (bytes)
     int lds_map_bytes, lds_env_bytes, lds_union_bytes;
@@ -345,7 +345,7 @@ struct Lds {
     unsigned short *itm;    // [kItemCap] in: ray lane | id << 6   out: id << 6 | feature
     unsigned short *itemidx;  // [kPassJ][64] item index of (candidate position, ray lane)
     // fan_group only (light maps): the rays of an agent group that have any candidate, compacted
-    unsigned long long *arow; // [rays of a group] the active ray's packed candidate row
+    unsigned *arow;           // [rays of a group] the active ray's packed candidate row (four bytes: finalize_rows)
     unsigned char *alist;     // [rays of a group] the active ray: chunk slot of the group << 6 | lane
     unsigned char *adyn;      // [rays of a group] its cone mask of the other agents
     unsigned short *od;  // [A*R]
@@ -1008,7 +1008,7 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
 // over all 64 lanes.  Here the rays are first sorted out with lane = ray (packed row loaded, candidate count, cone mask of the other
 // agents): a ray without a candidate gets its EMPTY observation at once, the others go into a compact list; then rounds of 64
 // ACTIVE rays run the position-major fan of fan_chunk with the origin, the "inside" walls and the roster side per lane.
-// Requires (cat_create): every candidate list fits one packed row word, shape ids S + A fit 6 bits, R <= kGroupRays.
+// Requires (cat_create): every candidate list fits a four-byte row (fields of wall id + 1), shape ids S + A fit 6 bits, R <= kGroupRays.
 template <class D>
 __device__ void fan_group(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, int env, int lane,
                           int S, float cmax, int rew_mode, int g, PhaseClock &pc)
@@ -1025,14 +1025,16 @@ __device__ void fan_group(const Lds &L, const Params &p, const LaunchArgs &la, c
     const int my_dk0 = lane < A * A ? L.dk0[lane] : 0, my_dcnt = lane < A * A ? L.dcnt[lane] : 0;
     // ---- lane = ray: the packed rows of the group's chunks (all requested before the first is looked at), then the sorting
     const int nslots = (i1 - i0) * cpa;          // <= 4
-    unsigned long long wrow[4] = {0ull, 0ull, 0ull, 0ull};
+    const int idb = launder(uni(p.row_id_bits)), cmul = launder(uni(p.row_cnt_mul));   // four-byte rows: fields of idb bits = id + 1 (finalize_rows)
+    auto row_count = [&](unsigned w) -> int { return w ? (((31 - __builtin_clz(w)) * cmul) >> 16) + 1 : 0; };
+    unsigned wrow[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int sl = 0; sl < 4; sl++) {
         if (sl < nslots) {
             const int i = i0 + sl / cpa, k = (sl % cpa) * kLanes + lane;
             const int cell = __builtin_amdgcn_readlane(my_cell, i);
             const size_t r = (cell < 0 || k >= R) ? 0 : (size_t)cell * R + k;
-            wrow[sl] = G(p.grid_rows)[gd.row_base + r];
+            wrow[sl] = ((GAS const unsigned *)G(p.grid_rows))[gd.row_base + r];
         }
     }
     int n_act = 0;
@@ -1042,7 +1044,7 @@ __device__ void fan_group(const Lds &L, const Params &p, const LaunchArgs &la, c
             const int i = i0 + sl / cpa, k = (sl % cpa) * kLanes + lane;
             const int cell = __builtin_amdgcn_readlane(my_cell, i);
             const bool in = k < R;
-            const int cnt_w = (in && cell >= 0) ? (int)(wrow[sl] & 0xFF) : 0;
+            const unsigned rowv = (in && cell >= 0) ? wrow[sl] : 0u;   // non-zero: the ray has candidate walls
             unsigned dynmask = 0;
             if (in)
                 for (int j = 0; j < A; j++) {
@@ -1051,12 +1053,12 @@ __device__ void fan_group(const Lds &L, const Params &p, const LaunchArgs &la, c
                     int rel = k - dk; if (rel < 0) rel += R;
                     if (rel < dc) dynmask |= 1u << j;
                 }
-            const bool act = cnt_w != 0 || dynmask != 0u;
+            const bool act = rowv != 0u || dynmask != 0u;
             const unsigned long long m = __ballot(act);
             if (act) {
                 const int a = n_act + __popcll(m & lt_mask);
                 L.alist[a] = (unsigned char)((sl << 6) | lane);
-                L.arow[a] = wrow[sl];
+                L.arow[a] = rowv;
                 L.adyn[a] = (unsigned char)dynmask;
             } else if (in) {   // nothing along this ray: its observation is final
                 const int q = i * R + k;
@@ -1081,9 +1083,9 @@ __device__ void fan_group(const Lds &L, const Params &p, const LaunchArgs &la, c
         const double ax = org.x, ay = org.y;
         const int near0 = L.anear[2 * i], near1 = L.anear[2 * i + 1];
         const unsigned dnear_mask = (unsigned)L.adn[i];
-        const unsigned long long w0 = on ? L.arow[r0 + lane] : 0ull;
+        const unsigned w0 = on ? L.arow[r0 + lane] : 0u;
         const unsigned dynmask = on ? (unsigned)L.adyn[r0 + lane] : 0u;
-        const int cnt_w = (int)(w0 & 0xFF);
+        const int cnt_w = row_count(w0);
         const int cnt = cnt_w + __popc(dynmask);
         double rdx, rdy, rix, riy;
         {
@@ -1102,7 +1104,7 @@ __device__ void fan_group(const Lds &L, const Params &p, const LaunchArgs &la, c
                 int id = 0;
                 double tbb = 0.0;
                 if (has) {
-                    if (jj < cnt_w) id = (int)((w0 >> (8 * (jj + 1))) & 0xFF);      // jj < 7: the row word holds the whole list
+                    if (jj < cnt_w) id = (int)((w0 >> (idb * jj)) & ((1u << idb) - 1u)) - 1;      // the row holds the whole list
                     else {
                         unsigned dj = dynmask;
                         for (int q = jj - cnt_w; q > 0; q--) dj &= dj - 1;
@@ -1679,7 +1681,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.ialpha = L.itbb + kItemCap;
     L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
     L.itemidx = L.itm + kItemCap;
-    L.arow = reinterpret_cast<unsigned long long *>(u + kFanBytes);
+    L.arow = reinterpret_cast<unsigned *>(u + kFanBytes);
     const int grays = group_agents<D>(p) * ((D::R(p) + 63) / 64) * 64;   // rays of one agent group: what the arrays are sized for
     L.alist = reinterpret_cast<unsigned char *>(L.arow + grays);
     L.adyn = L.alist + grays;
@@ -2181,6 +2183,7 @@ struct GridHost {
     std::vector<int> rows_of;               // rows per map
     std::vector<unsigned long long> crows;  // per cell: count | first 7 contact candidates
     int max_row = 0, row_words = 1;
+    int id_bits = 0;                        // > 0: four-byte rows (finalize_rows)
     std::vector<int> off, coff;
     std::vector<unsigned char> ent, cent;
 };
@@ -2459,11 +2462,32 @@ extern "C" int cat_map_wall_bb_depth_host(const void *blob, size_t size, double 
 // Packed rows, one per (cell, ray): byte 0 = count (saturating at 255), then the first 8*row_words - 1
 // candidate ids; row_words (1, 2 or 4 eight-byte words) is the smallest that holds the longest list of
 // any map of the sim, lists beyond 31 ids continue in the CSR arrays (slow path on the device).
-static void finalize_rows(GridHost &g)
+// id_bits > 0 (fan_group sims: S <= 2^id_bits - 1 and every list has at most 32 / id_bits walls): FOUR-byte rows, two per word of
+// `rows` -- field q (id_bits bits) = the list's q-th wall id + 1, zero beyond the list, so the count is the highest non-zero field's
+// index + 1; d.row_base counts rows either way.
+static void finalize_rows(GridHost &g, int id_bits = 0)
 {
     g.row_words = g.max_row <= 7 ? 1 : (g.max_row <= 15 ? 2 : 4);
+    g.id_bits = id_bits;
     const int cap = 8 * g.row_words - 1;
     g.rows.clear();
+    if (id_bits > 0) {
+        std::vector<unsigned> r32;
+        for (size_t m = 0; m < g.desc.size(); m++) {
+            GridDesc &d = g.desc[m];
+            d.row_base = (int)r32.size();
+            for (int r = 0; r < g.rows_of[m]; r++) {
+                const int o0 = g.off[d.off_base + r] + d.ent_base, n = g.off[d.off_base + r + 1] + d.ent_base - o0;
+                unsigned w = 0u;                                // n <= max_row <= 32 / id_bits
+                for (int q = 0; q < n; q++) w |= ((unsigned)g.ent[o0 + q] + 1u) << (id_bits * q);
+                r32.push_back(w);
+            }
+        }
+        if (r32.size() & 1) r32.push_back(0u);
+        g.rows.resize(r32.size() / 2);
+        memcpy(g.rows.data(), r32.data(), r32.size() * 4);
+        return;
+    }
     for (size_t m = 0; m < g.desc.size(); m++) {
         GridDesc &d = g.desc[m];
         d.row_base = (int)(g.rows.size() / g.row_words);
@@ -2513,7 +2537,7 @@ static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool grou
     z.map = up((kBB * maxS + rest) * 8 + 2 * maxS * 4, 16) + 16 * R;
     const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
     const int cpa = (R + 63) / 64;
-    const int fan_bytes = kFanBytes + (group_fan ? (cpa <= 2 ? 2 : 1) * cpa * 64 * (8 + 1 + 1) : 0);   // group_agents() x cpa x 64 rays
+    const int fan_bytes = kFanBytes + (group_fan ? (cpa <= 2 ? 2 : 1) * cpa * 64 * (4 + 1 + 1) : 0);   // group_agents() x cpa x 64 rays: arow, alist, adyn
     z.uni = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 16);
     const int rec_bytes = 96 * A + 16 + ((A * kK + NPs) * 8 + (2 * A * kK + NPs) * 4 + 15) / 16 * 16;
     int eb = rec_bytes + 8 * A * 8;                                // record, spawn/snapshot
@@ -2712,12 +2736,17 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
                         cfg->ray_radius + 2e-6, cell, grid_host, geo_i.data() + descs[m].i32_off, geo_i.data() + descs[m].i32_off + descs[m].S,
                         cfg->wall_radius + cfg->ray_radius, cfg->ray_radius);
         }
-        finalize_rows(grid_host);
     }
-    // Rays that meet few walls (every list fits one packed row word, ids and agents fit 6 bits, an agent's rays fit four chunks):
+    // Rays that meet few walls (every list fits a four-byte row -- the labyrinth's six walls of 5 bits --; ids and agents fit 6 bits; an agent's rays fit four chunks):
     // the group form of the ray fan, which compacts the rays that have any candidate across the agents of a group.  Else chunk by chunk.
-    int fan = (grid_host.max_row <= 7 && maxS + A <= 63 && cfg->n_rays <= kGroupRays) ? 1 : 0;
+    int id_bits = 1;   // bits of a wall id + 1
+    while ((1 << id_bits) <= maxS) id_bits++;
+    int fan = (grid_host.max_row <= 7 && grid_host.max_row * id_bits <= 32 && maxS + A <= 63 && cfg->n_rays <= kGroupRays) ? 1 : 0;
     if (const char *e = getenv("CAT_FAN")) { if (!strcmp(e, "chunks")) fan = 0; }
+    finalize_rows(grid_host, fan == 1 ? id_bits : 0);   // the group form reads four-byte rows, the chunk form 8 / 16 / 32-byte ones
+    if (getenv("CAT_VERBOSE"))
+        fprintf(stderr, "[cat_sim] ray fan: %s form; longest candidate list %d, %d-bit wall ids, %d-byte rows, table %.1f MB\n", fan ? "group" : "chunk",
+                grid_host.max_row, id_bits, fan ? 4 : 8 * grid_host.row_words, grid_host.rows.size() * 8 / 1e6);
     // ---- LDS carve sizes (must match carve()) and the workgroup size
     LdsSizes ls = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, fan == 1);
     int wpb = 0;
@@ -2822,10 +2851,18 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     {
         s->grid = std::move(grid_host);
         p.row_words = s->grid.row_words;
+        p.row_id_bits = s->grid.id_bits;
+        if (p.row_id_bits) {
+            p.row_cnt_mul = (65536 + p.row_id_bits - 1) / p.row_id_bits;
+            for (int b = 0; b < 32; b++)
+                if (((b * p.row_cnt_mul) >> 16) != b / p.row_id_bits) { snprintf(g_create_err, sizeof g_create_err, "row field divider"); return CAT_ERR_BAD_CONFIG; }
+        }
         TRY_ALLOC(dev_alloc(s, const_cast<GridDesc **>(&p.grids), s->grid.desc.size(), s->grid.desc.data()));
         TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.grid_rows), s->grid.rows.size(), s->grid.rows.data()));
-        TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.grid_off), s->grid.off.size(), s->grid.off.data()));
-        TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.grid_ent), s->grid.ent.size(), s->grid.ent.data()));
+        // the CSR arrays of the ray grid are only read for lists beyond a row's capacity: not uploaded when no list is that long
+        const bool csr = !s->grid.id_bits && s->grid.max_row > 8 * s->grid.row_words - 1;
+        TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.grid_off), csr ? s->grid.off.size() : 1, csr ? s->grid.off.data() : nullptr));
+        TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.grid_ent), csr ? s->grid.ent.size() : 1, csr ? s->grid.ent.data() : nullptr));
         TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.cgrid_off), s->grid.coff.size(), s->grid.coff.data()));
         TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.cgrid_ent), s->grid.cent.size(), s->grid.cent.data()));
         TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.cgrid_rows), s->grid.crows.size(), s->grid.crows.data()));
