@@ -821,6 +821,7 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int cpa = (R + kLanes - 1) / kLanes;   // chunks per agent
     const int rw = uni(p.row_words), row_cap = 8 * rw - 1;
+    const int idb = launder(uni(p.row_id_bits)), cmul = launder(uni(p.row_cnt_mul));   // != 0: one word of fields (wall id + 1), finalize_rows
     const int gate = launder(uni(p.gate)), n_cops = launder(uni(D::n_cops(p)));
     const double wall_r = launder(p.wall_r), rc = launder(p.rc);
     // the setup of agent_setup, back into registers (lane i / lane i*A+j), broadcast with readlane below
@@ -861,7 +862,8 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
         const double rdx = bx - ax, rdy = by - ay, rix = 1.0 / rdx, riy = 1.0 / rdy;
         // ---- candidates of this ray: walls from the spatial hash (ascending ids), then the other agents
         int cnt_w = (active && cellid >= 0) ? (int)(w0 & 0xFF) : 0;
-        if (__ballot(cnt_w == 255) != 0ull) {   // saturated count byte (a map with >= 255 walls along one ray)
+        if (idb) cnt_w = (active && cellid >= 0 && w0 != 0ull) ? (((63 - __builtin_clzll(w0)) * cmul) >> 16) + 1 : 0;
+        else if (__ballot(cnt_w == 255) != 0ull) {   // saturated count byte (a map with >= 255 walls along one ray)
             if (cnt_w == 255) {
                 const size_t r0 = (size_t)cellid * R + k;
                 cnt_w = G(p.grid_off)[gd.off_base + r0 + 1] - G(p.grid_off)[gd.off_base + r0];
@@ -891,7 +893,8 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
                 double tbb = 0.0;
                 if (has) {
                     if (jj < cnt_w) {
-                        if (jj < row_cap) id = row_byte(jj + 1);
+                        if (idb) id = (int)((w0 >> (idb * jj)) & ((1ull << idb) - 1ull)) - 1;
+                        else if (jj < row_cap) id = row_byte(jj + 1);
                         else {   // more than 31 candidate walls on one ray: the rest of the list, from the CSR arrays
                             const size_t r0 = (size_t)cellid * R + k;
                             id = G(p.grid_ent)[gd.ent_base + G(p.grid_off)[gd.off_base + r0] + jj];
@@ -2465,12 +2468,26 @@ extern "C" int cat_map_wall_bb_depth_host(const void *blob, size_t size, double 
 // id_bits > 0 (fan_group sims: S <= 2^id_bits - 1 and every list has at most 32 / id_bits walls): FOUR-byte rows, two per word of
 // `rows` -- field q (id_bits bits) = the list's q-th wall id + 1, zero beyond the list, so the count is the highest non-zero field's
 // index + 1; d.row_base counts rows either way.
-static void finalize_rows(GridHost &g, int id_bits = 0)
+static void finalize_rows(GridHost &g, int id_bits = 0, bool wide = false)
 {
     g.row_words = g.max_row <= 7 ? 1 : (g.max_row <= 15 ? 2 : 4);
     g.id_bits = id_bits;
     const int cap = 8 * g.row_words - 1;
     g.rows.clear();
+    if (id_bits > 0 && wide) {   // the same fields in ONE eight-byte word per row (fan_chunk sims whose lists fit 64 / id_bits walls)
+        g.row_words = 1;
+        for (size_t m = 0; m < g.desc.size(); m++) {
+            GridDesc &d = g.desc[m];
+            d.row_base = (int)g.rows.size();
+            for (int r = 0; r < g.rows_of[m]; r++) {
+                const int o0 = g.off[d.off_base + r] + d.ent_base, n = g.off[d.off_base + r + 1] + d.ent_base - o0;
+                unsigned long long w = 0ull;
+                for (int q = 0; q < n; q++) w |= ((unsigned long long)g.ent[o0 + q] + 1ull) << (id_bits * q);
+                g.rows.push_back(w);
+            }
+        }
+        return;
+    }
     if (id_bits > 0) {
         std::vector<unsigned> r32;
         for (size_t m = 0; m < g.desc.size(); m++) {
@@ -2743,10 +2760,15 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     while ((1 << id_bits) <= maxS) id_bits++;
     int fan = (grid_host.max_row <= 7 && grid_host.max_row * id_bits <= 32 && maxS + A <= 63 && cfg->n_rays <= kGroupRays) ? 1 : 0;
     if (const char *e = getenv("CAT_FAN")) { if (!strcmp(e, "chunks")) fan = 0; }
-    finalize_rows(grid_host, fan == 1 ? id_bits : 0);   // the group form reads four-byte rows, the chunk form 8 / 16 / 32-byte ones
+    // the group form reads four-byte rows; the chunk form eight-byte rows of the same fields where the longest list fits
+    // (agh-map: 9 walls of 7 bits), else byte rows of 8 / 16 / 32 bytes with the CSR continuation (CAT_GRID_FIELDS=0 forces those)
+    bool wide = fan == 0 && grid_host.max_row * id_bits <= 64;
+    if (const char *e = getenv("CAT_GRID_FIELDS")) { if (atoi(e) == 0) wide = false; }
+    finalize_rows(grid_host, (fan == 1 || wide) ? id_bits : 0, wide);
     if (getenv("CAT_VERBOSE"))
-        fprintf(stderr, "[cat_sim] ray fan: %s form; longest candidate list %d, %d-bit wall ids, %d-byte rows, table %.1f MB\n", fan ? "group" : "chunk",
-                grid_host.max_row, id_bits, fan ? 4 : 8 * grid_host.row_words, grid_host.rows.size() * 8 / 1e6);
+        fprintf(stderr, "[cat_sim] ray fan: %s form; longest candidate list %d; rows of %d bytes (%s); table %.1f MB\n", fan ? "group" : "chunk",
+                grid_host.max_row, fan ? 4 : 8 * grid_host.row_words, (fan || wide) ? "fields of wall id + 1" : "count byte + id bytes, CSR beyond",
+                grid_host.rows.size() * 8 / 1e6);
     // ---- LDS carve sizes (must match carve()) and the workgroup size
     LdsSizes ls = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, fan == 1);
     int wpb = 0;
@@ -2854,7 +2876,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         p.row_id_bits = s->grid.id_bits;
         if (p.row_id_bits) {
             p.row_cnt_mul = (65536 + p.row_id_bits - 1) / p.row_id_bits;
-            for (int b = 0; b < 32; b++)
+            for (int b = 0; b < 64; b++)
                 if (((b * p.row_cnt_mul) >> 16) != b / p.row_id_bits) { snprintf(g_create_err, sizeof g_create_err, "row field divider"); return CAT_ERR_BAD_CONFIG; }
         }
         TRY_ALLOC(dev_alloc(s, const_cast<GridDesc **>(&p.grids), s->grid.desc.size(), s->grid.desc.data()));

@@ -88,11 +88,14 @@ def test_chunk_form_of_the_ray_fan_on_the_light_maps(name, rays, monkeypatch):
     assert stats["done"] >= 32
 
 
-@pytest.mark.parametrize("switch,value", [("CAT_GRID_HULLS", "0"), ("CAT_GRID_OCCLUSION", "0"), ("CAT_GRID_CELL", "16"), ("CAT_GRID_CELL", "5")])
+@pytest.mark.parametrize("switch,value", [("CAT_GRID_HULLS", "0"), ("CAT_GRID_OCCLUSION", "0"), ("CAT_GRID_CELL", "16"), ("CAT_GRID_CELL", "5"),
+                                          ("CAT_GRID_FIELDS", "0"), ("CAT_FAN", "chunks")])
 @pytest.mark.parametrize("name", ["agh-map", "labyrinth"])
 def test_results_do_not_depend_on_the_rules_that_build_the_candidate_table(name, switch, value, monkeypatch):
     """The spatial hash lists fewer walls with each of its rules on (cat_sim.hip build_grids: the hull rule, the occlusion rule, the
-    smaller cell); the oracle visits every wall.  Bit-exact parity with each of them switched off or coarsened."""
+    smaller cell) and stores them in one of three row formats (four-byte fields for the group form, eight-byte fields or count + id
+    bytes for the chunk form: finalize_rows); the oracle visits every wall.  Bit-exact parity with each rule switched off or coarsened
+    and with each format forced."""
     from as_cops_and_thieves_amd.config import SimConfig
     monkeypatch.setenv(switch, value)
     cfg = SimConfig(n_envs=32, n_rays=64, max_step_count=60, seed=17)
