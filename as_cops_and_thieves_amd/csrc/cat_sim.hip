@@ -2729,9 +2729,9 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     // ---- spatial-hash grids per map (cell size: CAT_GRID_CELL px, default 8); their longest candidate list picks the ray fan
     GridHost grid_host;
     {
-        // Cell size: the smaller the cell, the tighter the three listing rules (agh-map, entries per ray: 16 px 2.1, 8 px 1.56, 4 px 1.35;
-        // kernel 70.0 -> 64.6 us from 8 to 4 px) and the larger the table (rows of 8 - 16 B per cell and ray: labyrinth 38 -> 151 MB,
-        // agh-map 64 -> 251 MB).  4 px while a map's table stays under 384 MB, else 8, 16 ...; CAT_GRID_CELL fixes it.
+        // Cell size: the smaller the cell, the tighter the three listing rules (agh-map, entries per ray: 16 px 2.1, 8 px 1.56, 4 px 1.35,
+        // 2 px: kernel 64.6 -> 63.2 us for four times the table) and the larger the table (rows of 4 - 8 B per cell and ray: labyrinth
+        // 48 MB, agh-map 98 MB at 4 px).  4 px while a map's table stays under 384 MB, else 8, 16 ...; CAT_GRID_CELL fixes it.
         double forced_cell = 0.0;
         if (const char *e = getenv("CAT_GRID_CELL")) { double v = atof(e); if (v >= 2.0 && v <= 512.0) forced_cell = v; }
         const double reach = cfg->ray_length + cfg->ray_radius + 1e-3;
@@ -2746,7 +2746,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
                 }
                 for (cell = 4.0; cell < 256.0; cell *= 2.0) {
                     const double rows = std::ceil((hi[0] - lo[0] + 2.0 * reach) / cell + 2.0) * std::ceil((hi[1] - lo[1] + 2.0 * reach) / cell + 2.0) * cfg->n_rays;
-                    if (rows * 16.0 <= 384e6) break;
+                    if (rows * 8.0 <= 384e6) break;   // eight bytes per row unless a map's lists need the wide byte format
                 }
             }
             build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, cfg->n_rays, tab->ray_dx, tab->ray_dy, reach, cfg->bbtree_gate != 0,
