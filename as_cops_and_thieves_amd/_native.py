@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
     L.cat_reset_done.argtypes = [vp, vp, vp]
     L.cat_step.argtypes = [vp, vp, vp, vp]
     L.cat_step_fused.argtypes = [vp, vp, u64, i32, vp, vp]
+    L.cat_rollout_fused.argtypes = [vp, i32, vp, u64, i32, vp, vp]
     L.cat_get_state.argtypes = [vp, vp, vp]
     L.cat_set_state.argtypes = [vp, vp, vp]
     L.cat_random_actions.argtypes = [vp, u64, vp, vp]
@@ -114,7 +115,7 @@ def lib() -> C.CDLL:
     L.cat_grid_free_host.restype = None
     L.cat_map_wall_bb_depth_host.argtypes = [vp, C.c_size_t, C.c_double]
     L.cat_map_wall_bb_depth_host.restype = i32
-    for name in ("cat_create", "cat_destroy", "cat_reset", "cat_reset_done", "cat_step", "cat_step_fused", "cat_get_state",
+    for name in ("cat_create", "cat_destroy", "cat_reset", "cat_reset_done", "cat_step", "cat_step_fused", "cat_rollout_fused", "cat_get_state",
                  "cat_set_state", "cat_random_actions", "cat_set_seed", "cat_device_errors", "cat_arm_kernel_timing", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup"):
         getattr(L, name).restype = i32
     _lib = L
@@ -122,6 +123,6 @@ def lib() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ("cat_abi_version", "cat_last_error", "cat_create", "cat_destroy", "cat_reset",
-                    "cat_reset_done", "cat_step", "cat_step_fused", "cat_get_state", "cat_set_state", "cat_random_actions",
+                    "cat_reset_done", "cat_step", "cat_step_fused", "cat_rollout_fused", "cat_get_state", "cat_set_state", "cat_random_actions",
                     "cat_set_seed", "cat_device_errors", "cat_arm_kernel_timing", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup",
                     "cat_grid_build_host", "cat_grid_lookup_host", "cat_grid_bytes_host", "cat_grid_free_host", "cat_map_wall_bb_depth_host")

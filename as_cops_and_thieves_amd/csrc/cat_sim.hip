@@ -85,6 +85,10 @@ struct GridDesc {
 __host__ __device__ inline int geo_rest_doubles(const MapDesc &md) { return CAT_EDGE_PAIRS ? 8 * md.P + (kPairF / 2) * md.PP : kGeoPerPlane * md.P; }
 
 struct BlockDesc { MapDesc md; GridDesc gd; };   // per workgroup: one load instead of block_map -> maps / grids
+constexpr int kWgConstBytes = 128;   // LDS copy of the workgroup's BlockDesc (resident rollout kernel: descriptors are re-read from LDS
+                                     // by the phase that needs them instead of living in registers across the scheduler loop)
+static_assert(sizeof(BlockDesc) <= kWgConstBytes, "BlockDesc must fit its LDS block");
+__host__ __device__ inline int ctrl_bytes(int W) { return 16 * W + kWgConstBytes; }   // [W][4] control words, then the constant block
 
 struct Params {
     int N, A, n_cops, R, max_step, iterations, persistence, gate, NP, maxc;
@@ -211,6 +215,7 @@ struct LaunchArgs {
     int use_done_mask;
     int auto_reset;                 // tick_kernel: episodes that end this tick are reset inside the same launch
     unsigned long long synth_tick;  // tick_kernel with actions == NULL: Philox actions of this tick
+    int T;                          // rollout_kernel: ticks per launch (outputs and actions carry a leading T)
 };
 
 // ------------------------------------------------------------------ small helpers -----------
@@ -812,7 +817,7 @@ __device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, i
 // One 64-ray chunk c (agent c / cpa, rays (c % cpa) * 64 ...) of the env whose env area is in L; the scratch
 // union of L is the calling wave's.  Writes the chunk's observations to the env's output staging.
 template <class D>
-__device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, int env, int lane,
+__device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, long long env, int lane,
                           int S, float cmax, int rew_mode, int c, PhaseClock &pc)
 {
     const int A = D::A(p), R = D::R(p);
@@ -1013,7 +1018,7 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
 // ACTIVE rays run the position-major fan of fan_chunk with the origin, the "inside" walls and the roster side per lane.
 // Requires (cat_create): every candidate list fits a four-byte row (fields of wall id + 1), shape ids S + A fit 6 bits, R <= kGroupRays.
 template <class D>
-__device__ void fan_group(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, int env, int lane,
+__device__ void fan_group(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, long long env, int lane,
                           int S, float cmax, int rew_mode, int g, PhaseClock &pc)
 {
     const int A = D::A(p), R = D::R(p);
@@ -1254,7 +1259,7 @@ __device__ __forceinline__ void wide_store(void *gdst, const void *lsrc, int n, 
 // All output stores, issued at the very end of the kernel: the compiler's s_waitcnt vmcnt(0) (in-order
 // with stores, and forced by every flat access) would otherwise stall mid-kernel on HBM write latency.
 template <class D>
-__device__ __forceinline__ void emit_observations(const Lds &L, const Params &p, const LaunchArgs &la, int env, int lane,
+__device__ __forceinline__ void emit_observations(const Lds &L, const Params &p, const LaunchArgs &la, long long env, int lane,
                                                   int rew_mode, const LateOut &late)
 {
     const int A = D::A(p), R = D::R(p);
@@ -1649,7 +1654,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.fp = L.fc + S;
     L.rayd = reinterpret_cast<const double *>(smem + p.lds_map_bytes - 16 * D::R(p));
     L.ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
-    char *w = smem + p.lds_map_bytes + 16 * W + slot * p.lds_env_bytes;
+    char *w = smem + p.lds_map_bytes + ctrl_bytes(W) + slot * p.lds_env_bytes;
     const int A = D::A(p), R = D::R(p), NPs = D::NP(p) > 0 ? D::NP(p) : 1;
     L.rec = w;
     double *d = reinterpret_cast<double *>(w);
@@ -1677,7 +1682,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
         L.st = reinterpret_cast<unsigned char *>(o);
     }
     // union: contact arrays (physics) / ray-fan scratch
-    char *u = smem + p.lds_map_bytes + 16 * W + W * p.lds_env_bytes + wave * p.lds_union_bytes;
+    char *u = smem + p.lds_map_bytes + ctrl_bytes(W) + W * p.lds_env_bytes + wave * p.lds_union_bytes;
     L.conf = reinterpret_cast<double *>(u);
     L.coni = reinterpret_cast<int *>(L.conf + 12 * D::maxc(p));
     L.itbb = reinterpret_cast<double *>(u);
@@ -1826,6 +1831,33 @@ __device__ __forceinline__ void publish_slot(const Lds &L, int wave, int lane, i
     if (lane == 0) __hip_atomic_store(&L.ctrl[4 * wave + 2], n_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Write-back of one finished slot tick: rewards (cop.py / thief.py), the counters of the state record, the record itself
+// (store_rec: the one-tick kernels store it every tick, the resident rollout kernel only after its last tick) and every
+// output.  env_out indexes the output buffers: the env slot, or row t * N + env of buffers with a leading T.
+template <class D>
+__device__ __forceinline__ void slot_writeback(const Lds &Ls, const Params &p, const LaunchArgs &la, int e_s, long long env_out, int lane,
+                                               int tick, bool store_rec, int step2, int captured2, int timeout2, int rcount,
+                                               GAS const float *cop_lut, GAS const float *thief_lut, PhaseClock &pc)
+{
+    LateOut late;
+    rewards_and_positions<D>(Ls, p, la, lane, tick, captured2, timeout2, cop_lut, thief_lut, late);
+    PHASE(pc, 17);
+    const unsigned char term = (unsigned char)(captured2 || timeout2);
+    if (lane == 0) {   // a slot that went through a reset (rcount >= 0) starts its new episode: base_env.py:350
+        Ls.cnt[0] = step2; Ls.cnt[2] = rcount >= 0 ? 0 : term;
+        if (rcount >= 0) Ls.cnt[1] = rcount;
+    }
+    if (store_rec) store_state<D>(Ls, p, e_s, lane);
+    PHASE(pc, 18);
+    emit_observations<D>(Ls, p, la, env_out, lane, tick, late);
+    PHASE(pc, 19);
+    if (tick && lane == 0) {
+        if (la.out.terminated) la.out.terminated[env_out] = term;       // entity.py:146
+        if (la.out.truncated) la.out.truncated[env_out] = (unsigned char)timeout2;  // :397
+        if (la.out.winner) la.out.winner[env_out] = (signed char)(captured2 ? 0 : (timeout2 ? 1 : -1));  // :399-406
+    }
+}
+
 // The shared part of both kernels.  Units of a published slot, claimed in order by any wave of the workgroup:
 // ray chunks 0 .. nchunks-1, then (tick only) Space.step.  A wave starts with its own slot.  The wave that completes
 // a slot's last unit writes that slot back: rewards, state record and outputs to HBM.
@@ -1909,29 +1941,67 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
         if (wb_first) PHASE(pc, 23); else PHASE(pc, 3);       // its first one / a further one (the stores of the one before)
         wb_first = false;
 #endif
-        LateOut late;
-        rewards_and_positions<D>(Ls, p, la, lane, tick, captured2, timeout2, cop_lut, thief_lut, late);
-        PHASE(pc, 17);
-        const unsigned char term = (unsigned char)(captured2 || timeout2);
-        if (lane == 0) {   // a slot that went through a reset (rcount >= 0) starts its new episode: base_env.py:350
-            Ls.cnt[0] = step2; Ls.cnt[2] = rcount >= 0 ? 0 : term;
-            if (rcount >= 0) Ls.cnt[1] = rcount;
-        }
-        store_state<D>(Ls, p, e_s, lane);
-        PHASE(pc, 18);
-        emit_observations<D>(Ls, p, la, e_s, lane, tick, late);
-        PHASE(pc, 19);
-        if (tick && lane == 0) {
-            if (la.out.terminated) la.out.terminated[e_s] = term;       // entity.py:146
-            if (la.out.truncated) la.out.truncated[e_s] = (unsigned char)timeout2;  // :397
-            if (la.out.winner) la.out.winner[e_s] = (signed char)(captured2 ? 0 : (timeout2 ? 1 : -1));  // :399-406
-        }
+        slot_writeback<D>(Ls, p, la, e_s, (long long)e_s, lane, tick, true, step2, captured2, timeout2, rcount, cop_lut, thief_lut, pc);
     }
 }
 
 template <class D>
 __device__ __forceinline__ void spawn_and_reset(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
                                                 int env, unsigned rc, int lane);
+
+// The serial front of one slot's tick (BaseEnv.step up to the observations, base_env.py:372-383): step count, termination on
+// last tick's positions, the tick-start snapshot, Entity._perform_action with lane = agent, the in-kernel auto-reset of an
+// episode that ends with this tick, and the per-agent ray-fan setup.  Leaves L.flags for the write-back and returns the
+// number of work units to publish (ray-fan units [+ Space.step]).  act_pref: lane i's action when la.actions is set.
+template <class D>
+__device__ __forceinline__ int slot_front(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md, const GridDesc &gd,
+                                          int env, int lane, int act_pref, unsigned long long synth_tick, PhaseClock &pc)
+{
+    const int S = md.S, A = D::A(p);
+    const int nchunks = fan_units<D>(p);
+    const int step = uni(L.cnt[0]) + 1;                                 // :372
+    const int captured = termination_captured<D>(L, p, S, lane);           // :378
+    const int timeout = (!captured && step >= p.max_step) ? 1 : 0;
+    copy_snapshot(L, A, lane);
+
+    // Entity._perform_action (entity.py:126-134), lane = agent.  (As a wave-uniform loop over the agents -- the
+    // synthetic-action Philox rounds and the sqrt/divide chain of each agent one after the other, on the scalar
+    // unit -- this was 6 us of the tick, in the part of the kernel every wave of the launch executes in step.)
+    if (lane < A) {
+        const int i = lane;
+        const double m_inv = 1.0 / p.mass;
+        int act;
+        if (la.actions) act = act_pref;
+        else { unsigned rnd[4]; philox_env(p, env, (unsigned)synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
+        if ((unsigned)act > 3u) atomicOr(p.err_word, CAT_DEVERR_BAD_ACTION);   // applied as "no impulse", and flagged
+        double jx = 0.0, jy = 0.0;
+        if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
+        else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
+        double vx = L.vel[2 * i] + jx * m_inv, vy = L.vel[2 * i + 1] + jy * m_inv;
+        double len = sqrt(vx * vx + vy * vy);
+        if (len > p.max_speed) { vx = vx / len * p.max_speed; vy = vy / len * p.max_speed; }
+        L.vel[2 * i] = vx; L.vel[2 * i + 1] = vy;
+    }
+    wave_sync();
+    PHASE(pc, 2);
+    int n_units = nchunks + 1, rcount = -1, step_store = step;
+    if (la.auto_reset && (captured || timeout)) {
+        // The episode ends with this tick and the caller wants the slot reset in the same call: the terminal
+        // observations would be overwritten by the reset's (the rewards of a terminal tick are constants), so the
+        // slot's ray chunks are those of the NEW episode.  The reset needs the stepped state (stale circle caches
+        // and leaf bbs, quirk Q1), so the owner runs Space.step here instead of queueing it.
+        physics_env<D>(L, p, S, lane, pc);                        // :392
+        rcount = uni(L.cnt[1]) + 1;
+        spawn_and_reset<D>(L, p, la, md, env, (unsigned)rcount, lane);   // base_env.py:286-352
+        wave_sync();
+        copy_snapshot(L, A, lane);
+        n_units = nchunks; step_store = 0;
+    }
+    agent_setup<D>(L, p, gd, lane);                              // entity.py:143-144, :388-390 (setup part)
+    PHASE(pc, 4);
+    if (lane == 0) { L.flags[0] = step_store; L.flags[1] = captured; L.flags[2] = timeout; L.flags[3] = rcount; }
+    return n_units;
+}
 
 // BaseEnv.step (base_env.py:354-413).  A workgroup of wpb waves advances wpb envs sharing one map.  Wave w OWNS
 // env slot w: it loads the state, decides termination, applies the actions, publishes the ray-fan setup, runs the
@@ -1966,55 +2036,12 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
     fetch_state<D>(sregs, p, env, lane);
     stage_map<D>(p, smem, md);   // ends with the workgroup barrier
     PHASE(pc, 0);
-    const int S = md.S, A = D::A(p);
-    const int nchunks = fan_units<D>(p);
     const bool has = env >= 0;
-    int captured = 0, timeout = 0, step = 0;
     if (has) {
         commit_state<D>(L, sregs, p, lane);
         load_cold<D>(L, p, env, lane);
         PHASE(pc, 1);
-        step = uni(L.cnt[0]) + 1;                                 // :372
-        captured = termination_captured<D>(L, p, S, lane);           // :378
-        timeout = (!captured && step >= p.max_step) ? 1 : 0;
-        copy_snapshot(L, A, lane);
-
-        // Entity._perform_action (entity.py:126-134), lane = agent.  (As a wave-uniform loop over the agents -- the
-        // synthetic-action Philox rounds and the sqrt/divide chain of each agent one after the other, on the scalar
-        // unit -- this was 6 us of the tick, in the part of the kernel every wave of the launch executes in step.)
-        if (lane < A) {
-            const int i = lane;
-            const double m_inv = 1.0 / p.mass;
-            int act;
-            if (la.actions) act = act_pref;
-            else { unsigned rnd[4]; philox_env(p, env, (unsigned)la.synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
-            if ((unsigned)act > 3u) atomicOr(p.err_word, CAT_DEVERR_BAD_ACTION);   // applied as "no impulse", and flagged
-            double jx = 0.0, jy = 0.0;
-            if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
-            else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
-            double vx = L.vel[2 * i] + jx * m_inv, vy = L.vel[2 * i + 1] + jy * m_inv;
-            double len = sqrt(vx * vx + vy * vy);
-            if (len > p.max_speed) { vx = vx / len * p.max_speed; vy = vy / len * p.max_speed; }
-            L.vel[2 * i] = vx; L.vel[2 * i + 1] = vy;
-        }
-        wave_sync();
-        PHASE(pc, 2);
-        int n_units = nchunks + 1, rcount = -1, step_store = step;
-        if (la.auto_reset && (captured || timeout)) {
-            // The episode ends with this tick and the caller wants the slot reset in the same call: the terminal
-            // observations would be overwritten by the reset's (the rewards of a terminal tick are constants), so the
-            // slot's ray chunks are those of the NEW episode.  The reset needs the stepped state (stale circle caches
-            // and leaf bbs, quirk Q1), so the owner runs Space.step here instead of queueing it.
-            physics_env<D>(L, p, S, lane, pc);                        // :392
-            rcount = uni(L.cnt[1]) + 1;
-            spawn_and_reset<D>(L, p, la, md, env, (unsigned)rcount, lane);   // base_env.py:286-352
-            wave_sync();
-            copy_snapshot(L, A, lane);
-            n_units = nchunks; step_store = 0;
-        }
-        agent_setup<D>(L, p, gd, lane);                              // entity.py:143-144, :388-390 (setup part)
-        PHASE(pc, 4);
-        if (lane == 0) { L.flags[0] = step_store; L.flags[1] = captured; L.flags[2] = timeout; L.flags[3] = rcount; }
+        const int n_units = slot_front<D>(L, p, la, md, gd, env, lane, act_pref, la.synth_tick, pc);
         publish_slot(L, wave, lane, n_units);
     }
     run_units<D>(L, p, la, md, gd, smem, wave, lane, 1, pc);
@@ -2023,6 +2050,166 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *_
 #endif
     PHASE(pc, 11);
     pc.flush(lane);
+}
+
+// ------------------------------------------------------------------ resident rollout ----------
+// T consecutive ticks of BaseEnv.step in ONE launch (the random-action phases of the reference's loops: src/driver.py:65-69,
+// random_timesteps of src/configs/mappo_config.py:9; with an action tape: any fixed-policy replay).  The map is staged once, a
+// slot's state record stays in its LDS env area for all T ticks (HBM sees it after the last one), and EVERY tick's outputs go to
+// row t of caller buffers with a leading T.  Per tick the arithmetic is tick_kernel's (slot_front, the same work units, the same
+// write-back), so the results equal T calls of cat_step_fused bit for bit.
+//
+// Scheduling.  The one-tick kernel pays, per launch, the dispatch floor, the map staging, the state record both ways and one slot's
+// front -> fan -> write-back chain during which most waves of the workgroup wait (DESIGN: ~16 of 31 us).  Here the slots of a
+// workgroup advance INDEPENDENTLY -- tick t + 1 of a slot starts as soon as its own tick t is written back, whatever the other
+// slots are doing -- so in steady state every wave always finds a unit and only the last ticks of the launch have a tail.
+// One control word per slot, W = epoch << 14 | units << 7 | next (epoch = tick + 1; 0 = nothing published yet; all ones =
+// the slot has finished its T ticks): a wave claims unit `next` with a compare-and-swap on the whole word, so a claim made
+// on a stale view (another epoch, another unit count) simply fails and the wave rescans.  The wave that completes a slot's
+// last unit writes the tick back and runs the slot's NEXT front itself, then publishes the new epoch.
+constexpr unsigned kRwFinished = 0xFFFFFFFFu;
+__device__ __forceinline__ unsigned rw_make(int epoch, int n_units) { return ((unsigned)epoch << 14) | ((unsigned)n_units << 7); }
+__device__ __forceinline__ int rw_next(unsigned w) { return (int)(w & 127u); }
+__device__ __forceinline__ int rw_units(unsigned w) { return (int)((w >> 7) & 127u); }
+__device__ __forceinline__ int rw_epoch(unsigned w) { return (int)(w >> 14); }
+
+// LDS-only workgroup fences: the units hand LDS data from wave to wave; global stores of an earlier write-back that are still
+// in flight need not be waited for (a fence over every address space would sit on their acknowledgements at every unit).
+__device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
+__device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
+
+// The scheduler loop below holds three large inlined phases (front, work unit, write-back).  Whatever is invariant across the loop
+// -- lane-derived LDS addresses, output pointers plus lane offsets, compare masks, fields of Params and of the launch arguments --
+// the compiler hoists in front of it and then has to keep alive through every phase (first build: 141 spilled VGPRs, 760 B of
+// scratch per lane).  So each phase starts from opaque copies of its roots (lane id, parameter pointer, kernarg pointer) and
+// re-derives what it needs: nothing but the scheduler's own few scalars lives across phases.
+__device__ __forceinline__ int opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
+typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsK;
+typedef const Params __attribute__((address_space(4))) *ParamsK;   // the parameter block is never written while a kernel runs: constant address space -> scalar loads   // the by-value launch arguments, in the kernarg segment
+
+template <class D>
+__global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params *__restrict__ pp0, const LaunchArgs la0)
+{
+    extern __shared__ __align__(16) char smem[];
+    const int lane0 = threadIdx.x % kLanes;
+    const int wave = uni(threadIdx.x / kLanes);
+    // kernarg layout: [const Params *][LaunchArgs] (8-byte aligned)
+    const LaunchArgsK lap0 = (LaunchArgsK)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+    PhaseClock pc;
+    int env, T, W;
+    {   // ---- prologue: descriptors -> LDS, control words, state record -> LDS, map staging
+        const Params &p = *pp0;
+        const int lane = lane0;
+        W = uni((int)(blockDim.x / kLanes));
+        T = la0.T;
+        env = uni(p.work_env[blockIdx.x * W + wave]);
+        int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+        const MapDesc md0 = p.block_desc[blockIdx.x].md;
+        if (wave == 0 && lane < (int)(sizeof(BlockDesc) / 4))
+            reinterpret_cast<int *>(smem + p.lds_map_bytes + 16 * W)[lane] = reinterpret_cast<GAS const int *>(G(p.block_desc) + blockIdx.x)[lane];
+        // control words of slot `wave`: claim word (above), units done in this epoch, -, env id
+        if (lane < 4) ctrl[4 * wave + lane] = lane == 3 ? env : ((lane == 0 && env < 0) ? (int)kRwFinished : 0);
+        StateRegs sregs;
+        fetch_state<D>(sregs, p, env, lane);
+        stage_map<D>(p, smem, md0);   // ends with the workgroup barrier
+        PHASE(pc, 0);
+        if (env >= 0) {
+            const Lds L = carve<D>(p, smem, md0, wave, wave);
+            commit_state<D>(L, sregs, p, lane);
+            load_cold<D>(L, p, env, lane);
+            PHASE(pc, 1);
+        }
+    }
+    int pend = env >= 0 ? wave : -1, pend_t = 0;   // the slot whose next front this wave is to run, and its tick
+    int hint = wave;                                // the slot this wave worked on last: looked at first
+    for (;;) {
+        if (pend >= 0) {   // ---- the serial front of (slot pend, tick pend_t), then its units are published
+            const int lane = opaque_v(lane0);
+            const Params &p = *(const Params *)launder((ParamsK)pp0);
+            const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
+            int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+            const BlockDesc *const K = reinterpret_cast<const BlockDesc *>(smem + p.lds_map_bytes + 16 * W);   // the workgroup's descriptors, in LDS
+            const int slot = pend, t = pend_t;
+            pend = -1;
+            const int e_s = uni(ctrl[4 * slot + 3]);
+            const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
+            int ap = 0;
+            if (la.actions && lane < D::A(p)) ap = la.actions[((size_t)t * p.N + e_s) * D::A(p) + lane];
+            if (lane == 0) ctrl[4 * slot + 1] = 0;
+            const int n2 = slot_front<D>(Ls, p, la, K->md, K->gd, e_s, lane, ap, la.synth_tick + (unsigned long long)t, pc);
+            lds_release();
+            if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], rw_make(t + 1, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            hint = slot;
+        }
+        int slot, unit, n_units, t;
+        {   // ---- look for an open unit and claim it
+            const int lane = opaque_v(lane0);
+            int *const ctrl = reinterpret_cast<int *>(smem + launder((ParamsK)pp0)->lds_map_bytes);
+            unsigned w_l = kRwFinished;
+            if (lane < W) w_l = __hip_atomic_load((unsigned *)&ctrl[4 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned open = (unsigned)__ballot(rw_next(w_l) < rw_units(w_l));
+            if (open == 0u) {
+                if (__ballot(w_l != kRwFinished) == 0ull) break;   // every slot of the workgroup has finished its T ticks
+                __builtin_amdgcn_s_sleep(4);                        // fronts / write-backs under way on other waves
+                continue;
+            }
+            const unsigned rot = hint == 0 ? open : ((open >> hint) | (open << (32 - hint)));
+            slot = uni((hint + __builtin_ctz(rot)) & 31);   // bits >= W are never set (W <= 16)
+            const unsigned wv = (unsigned)__builtin_amdgcn_readlane((int)w_l, slot);
+            unsigned seen = wv;
+            if (lane == 0)
+                __hip_atomic_compare_exchange_strong((unsigned *)&ctrl[4 * slot], &seen, wv + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((unsigned)uni((int)seen) != wv) continue;   // someone else took it (or the epoch moved on): look again
+            lds_acquire();
+            hint = slot;
+            unit = rw_next(wv); n_units = rw_units(wv); t = rw_epoch(wv) - 1;
+        }
+        bool fin;
+        {   // ---- the unit: a part of the slot's ray fan (entity.py:143-144, base_env.py:388-390) or its Space.step (base_env.py:392)
+            const int lane = opaque_v(lane0);
+            const Params &p = *(const Params *)launder((ParamsK)pp0);
+            const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
+            int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+            const BlockDesc *const K = reinterpret_cast<const BlockDesc *>(smem + p.lds_map_bytes + 16 * W);
+            const int e_s = uni(ctrl[4 * slot + 3]);
+            const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
+            const long long eo = (long long)t * p.N + e_s;   // row of the [T, N, ...] output buffers
+            if (unit < fan_units<D>(p)) {
+                if constexpr (D::kFan == 1) fan_group<D>(Ls, p, la, K->gd, eo, lane, uni(K->md.S), K->md.cmax, 1, unit, pc);
+                else fan_chunk<D>(Ls, p, la, K->gd, eo, lane, uni(K->md.S), K->md.cmax, 1, unit, pc);
+            } else {
+                PHASE(pc, 9);
+                physics_env<D>(Ls, p, uni(K->md.S), lane, pc);
+                PHASE(pc, 10);
+            }
+            lds_release();   // the unit's LDS writes, before it counts as done
+            int d = 0;
+            if (lane == 0) d = __hip_atomic_fetch_add(&ctrl[4 * slot + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            fin = uni(d) == n_units - 1;
+        }
+        if (!fin) continue;
+        {   // ---- this wave completed the slot's tick t: write it back; the slot's next front is this wave's next job
+            const int lane = opaque_v(lane0);
+            const Params &p = *(const Params *)launder((ParamsK)pp0);
+            const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
+            int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+            const BlockDesc *const K = reinterpret_cast<const BlockDesc *>(smem + p.lds_map_bytes + 16 * W);
+            lds_acquire();
+            PHASE(pc, 16);
+            const int e_s = uni(ctrl[4 * slot + 3]);
+            const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
+            const long long eo = (long long)t * p.N + e_s;
+            const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
+            const bool last = t + 1 >= T;
+            slot_writeback<D>(Ls, p, la, e_s, eo, lane, 1, last, step2, captured2, timeout2, rcount, G(p.cop_lut), G(p.thief_lut), pc);
+            wave_sync();   // the write-back has read the slot's staging and flags; the next front overwrites them
+            if (!last) { pend = slot; pend_t = t + 1; }
+            else if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], kRwFinished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    PHASE(pc, 11);
+    pc.flush(lane0);
 }
 
 template <class D>
@@ -2523,27 +2710,29 @@ static void finalize_rows(GridHost &g, int id_bits = 0, bool wide = false)
 // Kernel instantiations: fixed dimensions for the rosters / ray counts of the BASELINE configurations and of the
 // reference's defaults, the generic one for everything else (CAT_GENERIC_KERNEL=1 forces it: A/B tests).
 using KernelFn = void (*)(const Params *, const LaunchArgs);
-template <class D> static void kernels_of(int fan, KernelFn &tick, KernelFn &reset)
+template <class D> static void kernels_of(int fan, KernelFn &tick, KernelFn &reset, KernelFn &rollout)
 {
-    if (fan == 1) { tick = tick_kernel<WithFan<D, 1>>; reset = reset_kernel<WithFan<D, 1>>; }
-    else { tick = tick_kernel<WithFan<D, 0>>; reset = reset_kernel<WithFan<D, 0>>; }
+    if (fan == 1) { tick = tick_kernel<WithFan<D, 1>>; reset = reset_kernel<WithFan<D, 1>>; rollout = rollout_kernel<WithFan<D, 1>>; }
+    else { tick = tick_kernel<WithFan<D, 0>>; reset = reset_kernel<WithFan<D, 0>>; rollout = rollout_kernel<WithFan<D, 0>>; }
 }
 // fan: 0 = chunk by chunk, 1 = agent groups with compacted rays (cat_create decides from the maps; CAT_FAN=chunks forces 0)
-static const char *select_kernels(int A, int R, int n_cops, int fan, KernelFn &tick, KernelFn &reset)
+static const char *select_kernels(int A, int R, int n_cops, int fan, KernelFn &tick, KernelFn &reset, KernelFn &rollout)
 {
     const char *e = getenv("CAT_GENERIC_KERNEL");
     const bool generic = e && atoi(e) != 0;
-    if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(fan, tick, reset); return "3 agents (2 cops), 64 rays"; }
-    if (!generic && A == 3 && n_cops == 2 && R == 90) { kernels_of<FixDims<3, 90, 2>>(fan, tick, reset); return "3 agents (2 cops), 90 rays"; }
-    if (!generic && A == 5 && n_cops == 3 && R == 64) { kernels_of<FixDims<5, 64, 3>>(fan, tick, reset); return "5 agents (3 cops), 64 rays"; }
-    kernels_of<DynDims>(fan, tick, reset);
+    if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(fan, tick, reset, rollout); return "3 agents (2 cops), 64 rays"; }
+#ifndef CAT_QUICK_BUILD   // diagnostic builds (tools/build_variant.sh -DCAT_QUICK_BUILD): the headline instantiation + the generic one only
+    if (!generic && A == 3 && n_cops == 2 && R == 90) { kernels_of<FixDims<3, 90, 2>>(fan, tick, reset, rollout); return "3 agents (2 cops), 90 rays"; }
+    if (!generic && A == 5 && n_cops == 3 && R == 64) { kernels_of<FixDims<5, 64, 3>>(fan, tick, reset, rollout); return "5 agents (3 cops), 64 rays"; }
+#endif
+    kernels_of<DynDims>(fan, tick, reset, rollout);
     return "generic";
 }
 
 // LDS carve sizes (must match carve())
 struct LdsSizes {
     int map, env, uni;
-    size_t total(int wpb) const { return (size_t)map + 16 * (size_t)wpb + (size_t)wpb * ((size_t)env + (size_t)uni); }
+    size_t total(int wpb) const { return (size_t)map + (size_t)ctrl_bytes(wpb) + (size_t)wpb * ((size_t)env + (size_t)uni); }
 };
 static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool group_fan)
 {
@@ -2570,7 +2759,7 @@ struct cat_sim {
     Params *dev_p;
     int device;
     int n_blocks, wpb;
-    KernelFn tick_fn = nullptr, reset_fn = nullptr;   // the instantiation matching (agents, rays, cops)
+    KernelFn tick_fn = nullptr, reset_fn = nullptr, rollout_fn = nullptr;   // the instantiation matching (agents, rays, cops)
     const char *kernel_variant = "";
     hipEvent_t t_start = nullptr, t_stop = nullptr;   // cat_arm_kernel_timing
     size_t lds_bytes;
@@ -2921,11 +3110,12 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     p.lds_map_bytes = ls.map; p.lds_env_bytes = ls.env; p.lds_union_bytes = ls.uni; p.wpb = wpb;
     s->wpb = wpb;
     s->lds_bytes = ls.total(wpb);
-    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, s->tick_fn, s->reset_fn);
+    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, s->tick_fn, s->reset_fn, s->rollout_fn);
     if (s->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->tick_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
+        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->rollout_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
             snprintf(s->err, sizeof s->err, "cannot raise dynamic LDS limit to %zu", s->lds_bytes);
             return fail(CAT_ERR_HIP);
         }
@@ -2976,15 +3166,16 @@ extern "C" int cat_reset_done(cat_sim *s, const cat_outputs *out, void *stream)
 
 // tick_kernel launch; when cat_arm_kernel_timing armed a pair of HIP events they are attached to THIS dispatch
 // (recorded at the kernel's own begin and end, not at the surrounding stream positions), one shot.
-static void launch_tick(cat_sim *s, const LaunchArgs &la, void *stream)
+static void launch_tick(cat_sim *s, const LaunchArgs &la, void *stream, KernelFn fn = nullptr)
 {
     const dim3 grid(s->n_blocks), block(s->wpb * kLanes);
+    if (!fn) fn = s->tick_fn;
     if (s->t_start && s->t_stop) {
-        hipExtLaunchKernelGGL(s->tick_fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->t_start, s->t_stop, 0,
+        hipExtLaunchKernelGGL(fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->t_start, s->t_stop, 0,
                               s->dev_p, la);
         s->t_start = s->t_stop = nullptr;
     } else {
-        hipLaunchKernelGGL(s->tick_fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->dev_p, la);
+        hipLaunchKernelGGL(fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->dev_p, la);
     }
 }
 
@@ -3019,6 +3210,22 @@ extern "C" int cat_step_fused(cat_sim *s, const int32_t *actions, uint64_t synth
     la.actions = actions; la.synth_tick = synth_tick;
     la.auto_reset = auto_reset ? 1 : 0;   // finished episodes are reset inside the same launch (no second kernel)
     launch_tick(s, la, stream);
+    HIP_TRY(s, hipGetLastError());
+    return CAT_OK;
+}
+
+extern "C" int cat_rollout_fused(cat_sim *s, int T, const int32_t *actions, uint64_t synth_tick0, int auto_reset,
+                                 const cat_outputs *out, void *stream)
+{
+    if (!s) return CAT_ERR_BAD_ARG;
+    if (T < 1 || T > CAT_MAX_ROLLOUT_TICKS) { snprintf(s->err, sizeof s->err, "cat_rollout_fused: T = %d outside 1..%d", T, CAT_MAX_ROLLOUT_TICKS); return CAT_ERR_BAD_ARG; }
+    HIP_TRY(s, hipSetDevice(s->device));
+    LaunchArgs la;
+    memset(&la, 0, sizeof la);
+    if (out) la.out = *out;
+    la.actions = actions; la.synth_tick = synth_tick0; la.T = T;
+    la.auto_reset = auto_reset ? 1 : 0;
+    launch_tick(s, la, stream, s->rollout_fn);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }

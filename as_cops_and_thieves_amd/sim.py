@@ -137,6 +137,38 @@ class CatSim:
                                            self._stream()), "cat_step_fused")
         return self.out
 
+    def rollout_buffers(self, T: int) -> Dict[str, torch.Tensor]:
+        """Caller-owned output buffers with a leading T for ``rollout_fused`` (cached per T)."""
+        cache = self.__dict__.setdefault("_rollout_bufs", {})
+        if T not in cache:
+            with torch.cuda.device(self.device):
+                cache[T] = {k: torch.zeros((T,) + tuple(fn(self.N, self.A, self.R)), dtype=dt, device=self.device)
+                            for k, (fn, dt) in _OUT_SPEC.items() if k in self.out}
+        return cache[T]
+
+    def rollout_fused(self, T: int, actions: Optional[torch.Tensor] = None, tick: int = 0, auto_reset: bool = True,
+                      out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """ONE launch for T consecutive ticks (cat_rollout_fused): the map stays in LDS, every env's state record stays in LDS
+        for the T ticks, and row t of every ``[T, N, ...]`` buffer holds what ``step_fused(actions[t], tick + t, auto_reset)``
+        leaves in ``self.out``.  ``actions``: ``[T, N, A]`` int32 or None (synthetic Philox actions of ticks tick .. tick+T-1)."""
+        T = int(T)
+        bufs = self.rollout_buffers(T) if out is None else out
+        for k, v in bufs.items():
+            fn, dt = _OUT_SPEC[k]
+            if tuple(v.shape) != (T,) + tuple(fn(self.N, self.A, self.R)) or v.dtype != dt or not v.is_contiguous() or v.device != self.device:
+                raise ValueError(f"rollout buffer {k!r} must be a contiguous {dt} tensor of shape {(T,) + tuple(fn(self.N, self.A, self.R))} on {self.device}")
+        ptr = None
+        if actions is not None:
+            if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
+                actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+            if actions.shape != (T, self.N, self.A):
+                raise ValueError(f"actions must have shape {(T, self.N, self.A)}, got {tuple(actions.shape)}")
+            ptr = actions.data_ptr()
+        view = nat.CatOutputs(*[bufs[k].data_ptr() if k in bufs else None for k in nat.OUT_FIELDS])
+        self._check(self._L.cat_rollout_fused(self._h, T, ptr, int(tick), int(auto_reset), C.byref(view), self._stream()),
+                    "cat_rollout_fused")
+        return bufs
+
     def random_actions(self, tick: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty((self.N, self.A), dtype=torch.int32, device=self.device)

@@ -25,6 +25,7 @@ extern "C" {
 #define CAT_MAX_RAYS 512
 #define CAT_MAX_SHAPES 256
 #define CAT_MAX_HULL_EDGES 31   /* edges of one convex wall */
+#define CAT_MAX_ROLLOUT_TICKS 65536   /* ticks of one cat_rollout_fused launch */
 #define CAT_WALL_CACHE 8        /* cached wall arbiters per agent; cat_create refuses a map on which an agent could need more */
 
 enum {
@@ -155,6 +156,18 @@ int cat_device_errors(cat_sim *sim, uint32_t *flags, int clear, void *stream);
    and then overwrite, are not computed). */
 int cat_step_fused(cat_sim *sim, const int32_t *actions, uint64_t synth_tick, int auto_reset,
                    const cat_outputs *out, void *stream);
+
+/* RESIDENT ROLLOUT: T consecutive ticks of cat_step_fused in ONE launch -- the random-action phases of the reference's loops
+   (src/driver.py:65-69 steps the env with sampled actions tick after tick; skrl's trainer does so for random_timesteps = 10000
+   ticks, src/configs/mappo_config.py:9) and, with an action tape, any replay of fixed actions.  The map geometry is staged into
+   LDS once, every env slot's state record stays in LDS for the T ticks and reaches HBM after the last one, and EVERY tick's
+   outputs are written: each non-NULL pointer of `out` addresses a buffer with a leading T -- obs_distance [T,N,A,R], reward
+   [T,N,A], terminated [T,N] ... -- whose row t holds exactly what cat_step_fused(actions_t, synth_tick0 + t, auto_reset)
+   leaves in its [N,...] buffers after tick t.  actions: DEVICE [T,N,A] int32, or NULL = the synthetic Philox actions of
+   cat_random_actions for ticks synth_tick0 .. synth_tick0 + T - 1.  1 <= T <= CAT_MAX_ROLLOUT_TICKS.  Bit-identical to T calls
+   of cat_step_fused (outputs of every tick and the state afterwards). */
+int cat_rollout_fused(cat_sim *sim, int T, const int32_t *actions, uint64_t synth_tick0, int auto_reset,
+                      const cat_outputs *out, void *stream);
 
 /* Env-state access (the reference cannot checkpoint env state). D2D copies. */
 int cat_get_state(cat_sim *sim, const cat_state *dst, void *stream);
