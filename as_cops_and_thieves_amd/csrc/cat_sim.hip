@@ -2140,6 +2140,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             lds_release();
             if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], rw_make(t + 1, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             hint = slot;
+            PHASE(pc, 3);
         }
         int slot, unit, n_units, t;
         {   // ---- look for an open unit and claim it
@@ -2151,10 +2152,19 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             if (open == 0u) {
                 if (__ballot(w_l != kRwFinished) == 0ull) break;   // every slot of the workgroup has finished its T ticks
                 __builtin_amdgcn_s_sleep(4);                        // fronts / write-backs under way on other waves
+                PHASE(pc, 21);
                 continue;
             }
-            const unsigned rot = hint == 0 ? open : ((open >> hint) | (open << (32 - hint)));
-            slot = uni((hint + __builtin_ctz(rot)) & 31);   // bits >= W are never set (W <= 16)
+            // Which open slot: the one FURTHEST BEHIND (lowest epoch), ties going to the slot this wave worked on last and then round
+            // the ring from it.  With "own slot first" every slot advances at its own pace -- envs differ in work per tick -- and
+            // over T ticks the slots of a workgroup drift apart: the launch then ends on its slowest slots, three units wide, while
+            // the other waves idle (10 % of all wave time at T = 64).  Helping the hindmost keeps the slots together.
+            unsigned key = 0xFFFFFFFFu;
+            if (rw_next(w_l) < rw_units(w_l)) key = ((unsigned)rw_epoch(w_l) << 5) | (unsigned)((lane - hint) & 31);
+#define CAT_ROW_MIN(SH) { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x120 + SH, 0xF, 0xF, false); key = o_ < key ? o_ : key; }
+            CAT_ROW_MIN(8) CAT_ROW_MIN(4) CAT_ROW_MIN(2) CAT_ROW_MIN(1)   // minimum over the 16 lanes of the row: row_ror by 8, 4, 2, 1
+#undef CAT_ROW_MIN
+            slot = uni((hint + (int)(key & 31u)) & 31);   // lane 0's row holds slots 0 .. 15
             const unsigned wv = (unsigned)__builtin_amdgcn_readlane((int)w_l, slot);
             unsigned seen = wv;
             if (lane == 0)
@@ -2164,6 +2174,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             lds_acquire();
             hint = slot;
             unit = rw_next(wv); n_units = rw_units(wv); t = rw_epoch(wv) - 1;
+            PHASE(pc, 22);
         }
         bool fin;
         {   // ---- the unit: a part of the slot's ray fan (entity.py:143-144, base_env.py:388-390) or its Space.step (base_env.py:392)
@@ -2187,6 +2198,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             int d = 0;
             if (lane == 0) d = __hip_atomic_fetch_add(&ctrl[4 * slot + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             fin = uni(d) == n_units - 1;
+            PHASE(pc, 23);
         }
         if (!fin) continue;
         {   // ---- this wave completed the slot's tick t: write it back; the slot's next front is this wave's next job
