@@ -62,3 +62,127 @@ def test_every_slot_matches_the_oracle(label, names, cops, thieves, N, ticks, ma
         gpu.close()
     finally:
         cat_oracle.lib().cato_set_threads(1)
+
+
+def _full_pair(names, cops, thieves, N, rays, max_steps, seed=0):
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.sim import CatSim
+    from oracle.cat_oracle import OracleSim
+    maps = [compiled(n, cops, thieves) for n in names]
+    slot = (np.arange(N) % len(maps)).astype(np.int32) if len(maps) > 1 else None
+    cfg = SimConfig(n_envs=N, n_cops=cops, n_thieves=thieves, n_rays=rays, max_step_count=max_steps, seed=seed)
+    return CatSim(cfg, maps, slot, device="cuda:0", debug_hit_shape=True), OracleSim(cfg, maps, slot)
+
+
+def _lockstep(gpu, cpu, ticks, checks, label, resident_from=None):
+    """cat_step_fused tick by tick on the GPU (from tick `resident_from` on: ONE resident launch for the remaining ticks, compared
+    at the same ticks), random actions + step + masked reset on the oracle; every slot compared at the ticks in `checks`."""
+    import torch
+    flag_keys = ("reward", "terminated", "truncated", "winner")
+    rows = None
+    for t in range(ticks):
+        if resident_from is not None and t == resident_from:
+            rows = to_np(gpu.rollout_fused(ticks - t, None, tick=t, auto_reset=True))
+        elif rows is None:
+            gpu.step_fused(None, tick=t, auto_reset=True)
+        c = cpu.step(cpu.random_actions(t))
+        flags = {k: c[k].copy() for k in flag_keys}
+        cpu.reset(mask=c["terminated"].copy())
+        if t in checks:
+            torch.cuda.synchronize()
+            got = to_np(gpu.out) if rows is None else {k: v[t - resident_from] for k, v in rows.items()}
+            assert_outputs_equal(got, cpu.out, keys=OBS_KEYS, ctx=f"{label}: tick {t}")
+            assert_outputs_equal(got, flags, keys=flag_keys, ctx=f"{label}: tick {t}")
+            if rows is None:
+                assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"{label}: tick {t}")
+    torch.cuda.synchronize()
+    assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"{label}: after tick {ticks - 1}")
+    assert gpu.device_errors() == 0
+
+
+@pytest.mark.parametrize("name", ["labyrinth", "agh-map"])
+def test_the_regime_the_bench_times(name):
+    """bench.py's own sequence on its own batch: reset, 600 ticks of cat_step_fused with 400-tick episodes (every slot times out
+    together at tick 400 and restarts), then the 25 ticks the driver's command times (--warmup 5 --steps 20) -- every slot, outputs
+    and the whole state against the oracle at the episode end (ticks 399 - 401), mid-episode (599 - 600) and through the timed ticks.
+    Agents have spread over the map by then (table rows that miss L2, contacts, long candidate lists), which the 25-tick
+    episodes of the tests above never reach."""
+    import torch
+    from oracle import cat_oracle
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    cat_oracle.lib().cato_set_threads(threads)
+    try:
+        gpu, cpu = _full_pair([name], 2, 1, 4096, 64, 400, seed=0)
+        g, c = gpu.reset(), cpu.reset()
+        torch.cuda.synchronize()
+        assert_outputs_equal(to_np(g), c, keys=OBS_KEYS, ctx=f"{name}: reset")
+        _lockstep(gpu, cpu, 625, {0, 200, 398, 399, 400, 401, 599, 600, 605, 612, 619, 624}, f"bench regime, {name} x4096")
+        assert int(cpu.get_state()["reset_count"].min()) >= 2
+        gpu.close()
+    finally:
+        cat_oracle.lib().cato_set_threads(1)
+
+
+@pytest.mark.parametrize("name,rays,ticks,max_steps", [
+    ("labyrinth", 90, 60, 25),          # the reference's own sensor (entity.py:86) at the BASELINE batch size
+    ("agh-map", 90, 60, 25),
+    ("labyrinth-inside", 64, 60, 25),   # every agent spawned inside the maze
+])
+def test_reference_sensor_and_inside_spawns_at_full_batch(name, rays, ticks, max_steps):
+    import torch
+    from oracle import cat_oracle
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    cat_oracle.lib().cato_set_threads(threads)
+    try:
+        gpu, cpu = _full_pair([name], 2, 1, 4096, rays, max_steps, seed=20261004)
+        g, c = gpu.reset(), cpu.reset()
+        torch.cuda.synchronize()
+        assert_outputs_equal(to_np(g), c, keys=OBS_KEYS, ctx=f"{name}: reset")
+        # the second half of the ticks in ONE resident launch (cat_rollout_fused), compared row by row
+        _lockstep(gpu, cpu, ticks, set(range(0, ticks, 5)) | {ticks - 1}, f"{name} x4096, {rays} rays", resident_from=ticks // 2)
+        assert int(cpu.get_state()["reset_count"].min()) >= 2
+        gpu.close()
+    finally:
+        cat_oracle.lib().cato_set_threads(1)
+
+
+@pytest.mark.parametrize("name,rays", [("labyrinth", 64), ("agh-map", 64), ("agh-map", 90)])
+def test_soak_128_envs_3000_ticks(name, rays):
+    """tools/soak_parity.py's rows as a test: 128 envs x 3000 ticks with 90-tick episodes (respawns all over the map, ~4 000
+    episodes), outputs and state compared every 10 ticks; the last 1000 ticks run as resident launches of 50 ticks."""
+    import torch
+    from oracle import cat_oracle
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    cat_oracle.lib().cato_set_threads(threads)
+    try:
+        gpu, cpu = _full_pair([name], 2, 1, 128, rays, 90, seed=41)
+        gpu.reset(); cpu.reset()
+        flag_keys = ("reward", "terminated", "truncated", "winner")
+        done = 0
+        t = 0
+        while t < 3000:
+            span = 1 if t < 2000 else 50
+            rows = to_np(gpu.rollout_fused(span, None, tick=t, auto_reset=True)) if span > 1 else None
+            if rows is None:
+                gpu.step_fused(None, tick=t, auto_reset=True)
+            for q in range(span):
+                c = cpu.step(cpu.random_actions(t + q))
+                flags = {k: c[k].copy() for k in flag_keys}
+                done += int(c["terminated"].sum())
+                cpu.reset(mask=c["terminated"].copy())
+                if (t + q) % 10 == 0:
+                    torch.cuda.synchronize()
+                    got = to_np(gpu.out) if rows is None else {k: v[q] for k, v in rows.items()}
+                    assert_outputs_equal(got, cpu.out, keys=OBS_KEYS, ctx=f"soak {name}: tick {t + q}")
+                    assert_outputs_equal(got, flags, keys=flag_keys, ctx=f"soak {name}: tick {t + q}")
+                    if rows is None:
+                        assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"soak {name}: tick {t + q}")
+            t += span
+            if rows is not None:
+                torch.cuda.synchronize()
+                assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"soak {name}: after tick {t - 1}")
+        assert done >= 128 * 25
+        assert gpu.device_errors() == 0
+        gpu.close()
+    finally:
+        cat_oracle.lib().cato_set_threads(1)

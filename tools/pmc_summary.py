@@ -21,7 +21,7 @@ for path in args:
             v.sort()
             acc[k][c] += [x for _, x in (v[-last:] if last else v)]
 for k, cs in acc.items():
-    if not any(n in k for n in ("tick", "reset", "random_actions")):
+    if not any(n in k for n in ("tick", "reset", "random_actions", "rollout")):
         continue
     print(k)
     for c, v in sorted(cs.items()):
