@@ -197,6 +197,48 @@ def timed_steps(sim, steps: int, warmup: int, fence, hip: "HipEvents", first_tic
     return elapsed, hip.elapsed_ms(*span) / steps, steps, "one HIP event pair on the kernel's stream around the K launches, / K"
 
 
+def timed_rollout(sim, T: int, fence, hip: "HipEvents", first_tick: int, reps: int = 4):
+    """The resident rollout launch (cat_rollout_fused: T ticks per launch, map staged once, state records kept in LDS, every tick's
+    outputs written to [T, N, ...] buffers) on the batch as it stands: one untimed launch, then `reps` timed ones, each with a pair
+    of HIP events attached to its dispatch.  Returns (seconds of the timed region on this rank, kernel ms per TICK, launches timed)."""
+    sim.rollout_fused(T, None, tick=first_tick, auto_reset=True)
+    ev = [(hip.create(), hip.create()) for _ in range(reps)]
+    fence()
+    t0 = time.perf_counter()
+    for r, (a, b) in enumerate(ev):
+        sim.arm_kernel_timing(a, b)
+        sim.rollout_fused(T, None, tick=first_tick + (r + 1) * T, auto_reset=True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    return elapsed, sum(hip.elapsed_ms(a, b) for a, b in ev) / (reps * T), reps
+
+
+def find_profile(wl: dict, kernel: str):
+    """The newest committed PMC profile (profiles/r*_traffic*.json) of this workload and kernel, or None.  PMC counters need
+    rocprofv3 passes of their own, so the bench line REPLAYS them and says so."""
+    default_key = {"map": "labyrinth", "envs": 4096, "rays": 64, "cops": 2, "thieves": 1}
+    for tfile in sorted((ROOT / "profiles").glob("r*_traffic*.json"), reverse=True):
+        prof = json.loads(tfile.read_text())
+        if prof.get("workload_key", default_key) == wl and prof.get("kernel", "tick_kernel") == kernel:
+            prof["_file"] = tfile.name
+            return prof
+    return None
+
+
+def replay_profile(entry: dict, wl: dict, kernel: str, ticks_per_launch: int = 1) -> None:
+    """Adds the replayed HBM traffic (bytes per env batch TICK) and VALU figures of a committed profile to an `extra` entry."""
+    prof = find_profile(wl, kernel)
+    if prof is None:
+        entry.update({"traffic": None, "traffic_source": None})
+        return
+    entry["traffic"] = prof["hbm_bytes_per_launch"] / prof.get("ticks_per_launch", 1)
+    entry["traffic_source"] = f"profiles/{prof['_file']} (committed rocprofv3 --pmc passes; replayed, not measured in this run)"
+    entry["traffic_over_algorithmic"] = entry["traffic"] / (algorithmic_bytes_per_env_step(wl["cops"] + wl["thieves"], wl["rays"]) * wl["envs"])
+    if prof.get("valu"):
+        entry["lane_utilisation"] = prof["valu"].get("lane_utilisation")
+        entry["valu"] = prof["valu"]
+
+
 def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16) -> dict:
     """SURVEY 8(f) rank 2 beside the headline: env-steps/s of the MAPPO trainer on the same env workload -- rollout
     collection (env tick + the six stacked LSTM networks per tick) plus the PPO update of ``CFG_AGENT`` (4 epochs x 4
@@ -261,6 +303,9 @@ def main() -> None:
                     "tick 400 together: 400 would land on the next reset); kernel time there = the whole-episode average (DESIGN 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE shapes (the `extra` object)")
+    ap.add_argument("--rollout-ticks", type=int, default=64, help="T of the resident-rollout legs in `extra` (cat_rollout_fused)")
+    ap.add_argument("--shape-only", action="store_true", help="profiling runs of one shape (tools/collect_profiles.sh): this workload's one-launch-per-tick "
+                    "region and its resident-rollout leg only -- no other shapes, no learner legs, no CPU baseline")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -323,6 +368,12 @@ def main() -> None:
         sim.step_fused(None, tick=t, auto_reset=True)
     elapsed, tick_ms, n_timed, tick_method = timed_steps(sim, args.steps, args.warmup, fence, hip, first_tick=args.burn_in)
     elapsed = max_over_ranks(elapsed, device=None if rehearse else dev)   # the slowest rank bounds the whole-job rate
+    TR = args.rollout_ticks
+    roll = None
+    if not args.no_extras or args.shape_only:   # the resident rollout launch on the same running batch (value stays one launch per tick)
+        r_el, r_kms, r_n = timed_rollout(sim, TR, fence, hip, first_tick=args.burn_in + args.warmup + args.steps)
+        r_el = max_over_ranks(r_el, device=None if rehearse else dev)
+        roll = (r_el, r_kms, r_n)
     episodes = int(sim.get_state()["reset_count"].sum().item())
     sim.close()
     offsets = [cfg.env_id_offset]
@@ -349,16 +400,26 @@ def main() -> None:
         e2, k2, _, _ = timed_steps(s2, k_steps, 100, fence, hip)   # see the first ticks after the reset
         e2 = max_over_ranks(e2, device=None if rehearse else dev)
         bytes2 = algorithmic_bytes_per_env_step(c2.n_agents, c2.n_rays) * c2.n_envs
+        r_el, r_kms, r_n = timed_rollout(s2, TR, fence, hip, first_tick=100 + k_steps)
+        r_el = max_over_ranks(r_el, device=None if rehearse else dev)
         s2.close()
-        return {"value": world * c2.n_envs * k_steps / e2, "unit": "env-steps/s", "steps": k_steps,
-                "ms_per_step": 1e3 * e2 / k_steps, "kernel_ms": k2, "envs_per_gpu": c2.n_envs,
-                "roofline_frac": bytes2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        key = {"map": w["map"], "envs": w["envs"], "rays": w.get("rays", args.rays), "cops": w["cops"], "thieves": w["thieves"]}
+        ent = {"value": world * c2.n_envs * k_steps / e2, "unit": "env-steps/s", "steps": k_steps,
+               "ms_per_step": 1e3 * e2 / k_steps, "kernel_ms": k2, "envs_per_gpu": c2.n_envs,
+               "roofline_frac": bytes2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        replay_profile(ent, key, "tick_kernel")
+        res = {"T": TR, "launches_timed": r_n, "value": world * c2.n_envs * TR * r_n / r_el, "unit": "env-steps/s",
+               "kernel_ms_per_tick": r_kms, "roofline_frac": bytes2 / (r_kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "what": "cat_rollout_fused: T ticks per launch, map staged once, state records resident in LDS, every tick's outputs written"}
+        replay_profile(res, key, "rollout_kernel")
+        ent["resident_rollout"] = res
+        return ent
 
     extra = None
-    if world > 1 and not args.no_extras:    # BASELINE configs[2]: agh-map, 32768 envs over 8 GPUs = 4096 per GPU, all ranks
+    if world > 1 and not args.no_extras and not args.shape_only:    # BASELINE configs[2]: agh-map, 32768 envs over 8 GPUs = 4096 per GPU, all ranks
         label, w = EXTRA_WORKLOADS[0]
         extra = {f"agh-map 2v1 x4096 per GPU (configs[2]), {world} GPUs": measure_extra(w)}
-    if rank == 0 and world == 1 and not args.no_extras:   # the other BASELINE shapes, same process, same box
+    if rank == 0 and world == 1 and not args.no_extras and not args.shape_only:   # the other BASELINE shapes, same process, same box
         extra = {label: measure_extra(w) for label, w in EXTRA_WORKLOADS}
         extra["learner_collect_plus_update"] = learner_throughput(args.map, cfg.n_envs, args.rays)
         extra["learner_collect_plus_update, 90 rays"] = learner_throughput(args.map, cfg.n_envs, 90)
@@ -373,16 +434,23 @@ def main() -> None:
         # replayed from the committed PMC summary of this exact workload and labelled as such
         traffic = valu = traffic_source = traffic_regime = traffic_from_reset = None
         wl = {"map": args.map, "envs": cfg.n_envs, "rays": R, "cops": args.cops, "thieves": args.thieves}
-        for tfile in sorted((ROOT / "profiles").glob("r*_traffic.json"), reverse=True):   # newest round whose workload matches
-            prof = json.loads(tfile.read_text())
-            if prof.get("workload_key", {"map": "labyrinth", "envs": 4096, "rays": 64, "cops": 2, "thieves": 1}) != wl:
-                continue
+        prof = find_profile(wl, "tick_kernel")   # newest round whose workload matches
+        if prof is not None:
             traffic, valu = prof["hbm_bytes_per_launch"], prof.get("valu")
             traffic_regime = prof.get("regime", "from reset (--burn-in 0: 25 launches straight after the reset)")
             traffic_from_reset = prof.get("hbm_bytes_per_launch_from_reset")
-            traffic_source = (f"profiles/{tfile.name} (committed rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 5 "
+            traffic_source = (f"profiles/{prof['_file']} (committed rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 5 "
                               f"--burn-in {prof.get('burn_in', 0)}`; replayed, not measured in this run)")
-            break
+        if roll is not None:
+            r_el, r_kms, r_n = roll
+            res = {"T": TR, "launches_timed": r_n, "value": world * cfg.n_envs * TR * r_n / r_el, "unit": "env-steps/s",
+                   "kernel": "rollout_kernel", "kernel_ms_per_tick": r_kms, "kernel_ms_method": "HIP events attached to each dispatch, / T",
+                   "roofline_frac": bytes_launch / (r_kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "envs_per_gpu": cfg.n_envs,
+                   "what": "cat_rollout_fused: T ticks per launch on the same running batch -- map staged once, state records resident in "
+                           "LDS for the T ticks, EVERY tick's outputs written to [T, N, ...] buffers; the headline `value` stays one launch per tick"}
+            replay_profile(res, wl, "rollout_kernel")
+            extra = dict(extra or {})
+            extra[f"{args.map} {args.cops}v{args.thieves} x{cfg.n_envs}, T={TR} resident rollout"] = res
         line = {
             "metric": "env-steps/sec (whole node) at 4096 parallel envs, 2v1 agents, 64-ray sensors",
             "value": world * cfg.n_envs * args.steps / elapsed,

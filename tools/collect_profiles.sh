@@ -1,35 +1,54 @@
 #!/bin/bash
-# GPU box: rocprofv3 kernel trace of the default bench command + PMC passes (one counter group per pass, with --kernel-trace only),
-# summarised into profiles/<tag>_*.  The PMC passes run the command the driver runs (bench.py --steps 20 --warmup 5: 600 burn-in
-# ticks first) and the summary averages the LAST 25 launches -- the running batch the bench line times; the HBM counters are
-# collected a second time straight from the reset (--burn-in 0, the regime of rounds 1-2) for the from-reset figure.
-# usage: tools/collect_profiles.sh r03
+# GPU box: per BASELINE shape, a rocprofv3 kernel trace + PMC passes (one counter group per pass, with --kernel-trace only) of the
+# bench command the driver runs (--steps 20 --warmup 5 after the burn-in ticks) restricted to that shape (--shape-only: the
+# one-launch-per-tick region + the resident-rollout leg of the SAME workload), summarised into profiles/<tag>_*:
+#   <tag>_<shape>_kernel_stats.csv   trace: tick_kernel / rollout_kernel rows      <tag>_<shape>_pmc_summary.txt   counters
+#   <tag>_traffic_<shape>.json       tick_kernel, last 25 launches                  <tag>_traffic_<shape>_rollout.json   rollout_kernel, last 4
+# The headline shape (labyrinth 2v1 x4096) also keeps the names of the earlier rounds (<tag>_final_*, <tag>_traffic.json) and gets
+# the HBM counters a second time straight from the reset (--burn-in 0).  rocprofv3 is given `python3 bench.py ...` directly.
+# usage: tools/collect_profiles.sh r04 [shape ...]      shapes: lab agh 3v2 mixed r90 (default: all)
 set -e
-tag=${1:-r03}
+tag=${1:-r04}; shift || true
+shapes=${@:-lab agh 3v2 mixed r90}
 out=gpurun_out/prof_$tag
-rm -rf $out; mkdir -p $out
+mkdir -p $out profiles
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --no-cpu-baseline --no-extras > $out/bench_under_rocprof.json 2> $out/trace.err
-i=0
-for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
-         "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
-         "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" \
-         "GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
-  i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc$i -o p -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc$i.err
-  echo "pmc pass $i done" >> $out/progress.txt
+declare -A ARGS KEY
+ARGS[lab]="--map labyrinth --envs 4096";                 KEY[lab]='{"map": "labyrinth", "envs": 4096, "rays": 64, "cops": 2, "thieves": 1}'
+ARGS[agh]="--map agh-map --envs 4096";                   KEY[agh]='{"map": "agh-map", "envs": 4096, "rays": 64, "cops": 2, "thieves": 1}'
+ARGS[3v2]="--map grandbyrinth --cops 3 --thieves 2 --envs 8192"; KEY[3v2]='{"map": "grandbyrinth", "envs": 8192, "rays": 64, "cops": 3, "thieves": 2}'
+ARGS[mixed]="--map mixed --envs 16384";                  KEY[mixed]='{"map": "mixed", "envs": 16384, "rays": 64, "cops": 2, "thieves": 1}'
+ARGS[r90]="--map labyrinth --envs 4096 --rays 90";       KEY[r90]='{"map": "labyrinth", "envs": 4096, "rays": 90, "cops": 2, "thieves": 1}'
+for sh in $shapes; do
+  a="${ARGS[$sh]} --steps 20 --warmup 5 --shape-only"
+  d=$out/$sh; rm -rf $d; mkdir -p $d
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -o t -- python3 bench.py $a > $d/bench_under_rocprof.json 2> $d/trace.err
+  echo "$sh trace done" >> $out/progress.txt
+  i=0
+  for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
+           "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
+    i=$((i+1))
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d/pmc$i -o p -- python3 bench.py $a > /dev/null 2> $d/pmc$i.err
+    echo "$sh pmc pass $i done" >> $out/progress.txt
+  done
+  grep -E '"Name"|tick_kernel|rollout_kernel|reset_kernel' $d/trace/t_kernel_stats.csv > profiles/${tag}_${sh}_kernel_stats.csv
+  { echo "# tick_kernel / reset_kernel: the last 25 launches; rollout_kernel: the last 4 (64 ticks each)"; python3 tools/pmc_summary.py --last 25 --only tick,reset $d/pmc*/p_counter_collection.csv; python3 tools/pmc_summary.py --last 4 --only rollout $d/pmc*/p_counter_collection.csv; } > profiles/${tag}_${sh}_pmc_summary.txt
+  python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel tick_kernel > /dev/null
+  python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel rollout_kernel --ticks-per-launch 64 > /dev/null
+  grep -v amdgpu.ids $d/bench_under_rocprof.json | tail -1 > profiles/${tag}_${sh}_bench_under_rocprof.json
+  if [ $sh = lab ]; then
+    for c in "FETCH_SIZE" "WRITE_SIZE"; do
+      i=$((i+1))
+      timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d/reset$i -o p -- python3 bench.py $a --burn-in 0 > /dev/null 2> $d/reset$i.err
+    done
+    python3 tools/pmc_summary.py --only tick $d/reset*/p_counter_collection.csv > profiles/${tag}_pmc_from_reset.txt
+    cp profiles/${tag}_lab_kernel_stats.csv profiles/${tag}_final_kernel_stats.csv
+    cp profiles/${tag}_lab_pmc_summary.txt profiles/${tag}_final_pmc_summary.txt
+    python3 tools/make_traffic_json.py $tag > /dev/null
+    cp profiles/${tag}_lab_bench_under_rocprof.json profiles/${tag}_final_bench_under_rocprof.json
+  fi
+  echo "$sh done" >> $out/progress.txt
 done
-for c in "FETCH_SIZE" "WRITE_SIZE"; do
-  i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/reset$i -o p -- python3 bench.py --steps 20 --warmup 5 --burn-in 0 --no-cpu-baseline --no-extras > /dev/null 2> $out/reset$i.err
-done
-mkdir -p profiles
-head -4 $out/trace/t_kernel_stats.csv > profiles/${tag}_final_kernel_stats.csv
-python3 tools/pmc_summary.py --last 25 $out/pmc*/p_counter_collection.csv > profiles/${tag}_final_pmc_summary.txt
-python3 tools/pmc_summary.py $out/reset*/p_counter_collection.csv > profiles/${tag}_pmc_from_reset.txt
-python3 tools/make_traffic_json.py $tag > /dev/null
-python3 bench.py > $out/bench.json 2> $out/bench.err     # after the passes: the line replays the traffic figure just collected
-grep -v amdgpu.ids $out/bench.json | tail -1 > profiles/${tag}_final_bench.json
-grep -v amdgpu.ids $out/bench_under_rocprof.json | tail -1 > profiles/${tag}_final_bench_under_rocprof.json
-cp profiles/${tag}_* $out/
-cat profiles/${tag}_final_kernel_stats.csv
+mkdir -p $out/profiles; cp profiles/${tag}_* $out/profiles/     # gpurun merges gpurun_out/ back: copy these into profiles/ and commit
+cat profiles/${tag}_*_kernel_stats.csv

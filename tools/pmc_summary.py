@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection.csv files: mean of each counter per kernel.  --last N: only the last N dispatches of a
-kernel in each file (the RUNNING batch of a bench.py run that starts with a burn-in), default: all.  usage: pmc_summary.py [--last N] FILE..."""
+kernel in each file (the RUNNING batch of a bench.py run that starts with a burn-in), default: all.  usage: pmc_summary.py [--last N] [--only tick,rollout] FILE..."""
 import csv, sys
 from collections import defaultdict
 args = sys.argv[1:]
 last = 0
-if args and args[0] == "--last":
-    last = int(args[1]); args = args[2:]
+only = ("tick", "reset", "random_actions", "rollout")
+while args and args[0] in ("--last", "--only"):
+    if args[0] == "--last":
+        last = int(args[1])
+    else:
+        only = tuple(args[1].split(","))
+    args = args[2:]
 acc = defaultdict(lambda: defaultdict(list))
 for path in args:
     per = defaultdict(lambda: defaultdict(list))
@@ -21,7 +26,7 @@ for path in args:
             v.sort()
             acc[k][c] += [x for _, x in (v[-last:] if last else v)]
 for k, cs in acc.items():
-    if not any(n in k for n in ("tick", "reset", "random_actions", "rollout")):
+    if not any(n in k for n in only):
         continue
     print(k)
     for c, v in sorted(cs.items()):
