@@ -674,6 +674,16 @@ class MAPPOTrainer:
         if optimizer and roles is None:
             self.timestep = int(sd.get(self.META_KEY, {}).get("timestep", 0))
 
+    def param_digest(self) -> str:
+        """SHA-256 over every learner's fp32 master parameters and optimiser step counts: data-parallel replicas must agree on it."""
+        import hashlib
+        h = hashlib.sha256()
+        for k in sorted(self.roles):
+            rl = self.roles[k]
+            h.update(rl.fp.master.detach().float().cpu().numpy().tobytes())
+            h.update(rl.steps.detach().cpu().numpy().tobytes())
+        return h.hexdigest()
+
     def reset_optimizers(self) -> None:
         """A fresh Adam, as every self-play iteration of the reference constructs a new ``MAPPO`` (orchestration.py:135-144)."""
         for rl in self.roles.values():

@@ -22,12 +22,25 @@ checkpoint saved in step 4 holds the last sampled ARCHIVED policies of both role
 the opponents are loaded into a separate evaluation copy and the trained weights are what gets saved.
 
     python -m as_cops_and_thieves_amd.selfplay.self_play --map squarinth --envs 1024 --iterations 3 --timesteps 2000
+
+**N GPUs of one node** (BASELINE configs[2]: 32768 envs sharded 8x, gradient all-reduce over xGMI):
+
+    python -m as_cops_and_thieves_amd.selfplay.self_play --gpus 8 --map agh-map --envs 32768 ...
+
+The command starts N fresh rank processes through ``torch.distributed.run`` as a CHILD process (never an exec; the parent has not
+touched the GPU).  Rank r simulates the global env ids ``shard_envs(envs, r, N)`` (no data-path collective: SURVEY 8e), the ranks
+open one RCCL group, and every optimiser step all-reduces ONE buffer -- the flat gradients | the KL statistics of all stacked
+networks (``mappo.RoleLearner.minibatch_step``) -- so the replicas stay bit-identical and take the same early-stop decisions.
+Rank 0 alone evaluates, writes checkpoints, archives and ``win_rates.json``; the others wait at a barrier and read the files.
 """
 from __future__ import annotations
 
 import argparse
 import dataclasses
+import inspect
+import os
 import random
+import sys
 from pathlib import Path
 from typing import Dict, Optional, Tuple
 
@@ -167,10 +180,25 @@ def evaluate_agent(eval_env, evaluator: MAPPOTrainer, learned: MAPPOTrainer, lea
 def run_self_play(map_name: str, num_envs: int, out_dir: Path, iterations: Optional[int] = None,
                   training: Optional[TrainingConfig] = None, trainer_cfg: Optional[TrainerConfig] = None,
                   role_cfg: Optional[Dict[str, RoleConfig]] = None, num_rays: int = 64, n_cops: Optional[int] = None,
-                  n_thieves: Optional[int] = None, max_step_count: int = 400, eval_envs: Optional[int] = None,
+                  n_thieves: Optional[int] = None, max_step_count: int = 2000, eval_envs: Optional[int] = None,
                   seed: int = 0, device=None, resume: bool = True, log=print, env_factory=None) -> Dict[str, object]:
     """The self-play loop.  ``resume``: continue after the highest iteration found in the archives ("latest").
-    ``env_factory(num_envs, seed)``: build the envs some other way (the CPU tests pass a stand-in env with the same surface)."""
+    ``max_step_count``: 2000, what the reference's driver passes (``self_play_driver.py:34``).
+    ``env_factory(num_envs, seed[, env_id_offset])``: build the envs some other way (the CPU tests pass a stand-in env with the
+    same surface).
+
+    With an initialised ``torch.distributed`` group of W > 1 ranks this is ONE data-parallel job: ``num_envs`` is the TOTAL,
+    rank r simulates ``shard_envs(num_envs, r, W)``; the trainer all-reduces its gradient | KL buffer every optimiser step (all
+    ranks hold identical parameters at all times); rank 0 alone evaluates and writes files, the others wait and read them."""
+    import torch.distributed as dist
+    from ..sharding import shard_envs
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+    chief = rank == 0
+
+    def sync():   # file hand-over between rank 0 and the others
+        if multi:
+            dist.barrier()
     tc = training or TrainingConfig()
     iterations = tc.num_self_play_iterations if iterations is None else iterations
     # TrainerConfig's 128-tick rollouts: with 16-tick rollouts the cops' win rate against random thieves stays at its untrained
@@ -178,13 +206,21 @@ def run_self_play(map_name: str, num_envs: int, out_dir: Path, iterations: Optio
     trainer_cfg = trainer_cfg or TrainerConfig(timesteps=tc.training_timesteps_per_role_training)
     out_dir = Path(out_dir)
     arch = {tc.cop_role_prefix: out_dir / "cops", tc.thief_role_prefix: out_dir / "thieves"}
-    for p in arch.values():
-        p.mkdir(parents=True, exist_ok=True)
+    if chief:
+        for p in arch.values():
+            p.mkdir(parents=True, exist_ok=True)
+    sync()
     n_eval = eval_envs or tc.n_trial_episodes
     if env_factory is None:
         preset = load_preset(map_name, n_cops, n_thieves)
-        env_factory = lambda n, s: VecCopsEnv(preset, n, num_rays=num_rays, max_step_count=max_step_count, seed=s, device=device)
-    env, eval_env = env_factory(num_envs, seed), env_factory(n_eval, seed + 7919)
+        env_factory = lambda n, s, off=0: VecCopsEnv(preset, n, num_rays=num_rays, max_step_count=max_step_count, seed=s, device=device,
+                                                     env_id_offset=off)
+    n_local, offset = shard_envs(num_envs, rank, world)
+    takes_offset = len(inspect.signature(env_factory).parameters) >= 3
+    if multi and not takes_offset:
+        raise TypeError("a data-parallel run needs env_factory(num_envs, seed, env_id_offset): the ranks must simulate different envs")
+    env = env_factory(n_local, seed, offset) if takes_offset else env_factory(n_local, seed)
+    eval_env = env_factory(n_eval, seed + 7919)          # every rank builds one (the evaluator's shapes); only rank 0 plays on it
     role_cfg = role_cfg or {"cop": CFG_AGENT, "thief": CFG_AGENT}        # self_play_driver.py passes CFG_AGENT
     trainer = MAPPOTrainer(env, role_cfg, trainer_cfg, seed=seed)
     evaluator = MAPPOTrainer(eval_env, role_cfg, dataclasses.replace(trainer_cfg, graph_rollout=False, graph_update=False),
@@ -206,21 +242,66 @@ def run_self_play(map_name: str, num_envs: int, out_dir: Path, iterations: Optio
         trainer.reset_episodes()
         # ---- 2. simultaneous training (agent_learning_utils.py:172-197)
         stats = trainer.train(trainer_cfg.timesteps)
-        # ---- 3. evaluation against archived opponents (:199-228)
         cop, thief = tc.cop_role_prefix, tc.thief_role_prefix
-        ev = {cop: evaluate_agent(eval_env, evaluator, trainer, cop, thief, arch[thief], tc, rng, log),
-              thief: evaluate_agent(eval_env, evaluator, trainer, thief, cop, arch[cop], tc, rng, log)}
-        # ---- 4. joint checkpoint into both archives (orchestration.py:225-245)
-        ck = out_dir / f"joint_iter_{it}_full_agent.pt"
-        torch.save(trainer.state_dict(), ck)
-        if it % tc.archive_save_interval == 0 or it == start + iterations - 1:
-            for role in arch:
-                archive.add_policy_to_archive(str(ck), arch[role], it, role)
+        ev = {cop: {}, thief: {}}
+        if chief:
+            # ---- 3. evaluation against archived opponents (:199-228)
+            ev = {cop: evaluate_agent(eval_env, evaluator, trainer, cop, thief, arch[thief], tc, rng, log),
+                  thief: evaluate_agent(eval_env, evaluator, trainer, thief, cop, arch[cop], tc, rng, log)}
+            # ---- 4. joint checkpoint into both archives (orchestration.py:225-245)
+            ck = out_dir / f"joint_iter_{it}_full_agent.pt"
+            torch.save(trainer.state_dict(), ck)
+            if it % tc.archive_save_interval == 0 or it == start + iterations - 1:
+                for role in arch:
+                    archive.add_policy_to_archive(str(ck), arch[role], it, role)
+            log(f"[self-play] iteration {it}: saved {ck.name}; evaluated {len(ev[cop])} thief and {len(ev[thief])} cop opponents"
+                + (f"; {world} ranks x {n_local} envs" if multi else ""))
+        sync()                                     # the other ranks read this iteration's archive entries in step 1 of the next
         history.append({"iteration": it, "evaluations": ev, "stats": stats})
-        log(f"[self-play] iteration {it}: saved {ck.name}; evaluated {len(ev[cop])} thief and {len(ev[thief])} cop opponents")
+    digest = trainer.param_digest()
     env.close()
     eval_env.close()
-    return {"iterations": history, "archives": {r: str(p) for r, p in arch.items()}}
+    return {"iterations": history, "param_digest": digest, "archives": {r: str(p) for r, p in arch.items()}, "rank": rank, "world": world,
+            "envs_local": n_local, "env_id_offset": offset}
+
+
+def launch_ranks(n: int, argv) -> int:
+    """``--gpus N`` typed as a plain command: start N fresh rank processes of this module, one per GPU, through
+    ``torch.distributed.run`` as a CHILD process (the bench.py pattern: never an exec, and this parent has not initialised the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "as_cops_and_thieves_amd.selfplay.self_play", *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_ranks(gpus: int) -> str:
+    """Inside a rank process (WORLD_SIZE set by the launcher): one GPU per rank and the RCCL group (``nccl`` IS RCCL on ROCm).
+    ``CAT_SELFPLAY_REHEARSE=1``: the flow on a box with fewer GPUs than ranks -- ranks share devices, gloo carries the all-reduce
+    (RCCL refuses two ranks on one device).  Returns the backend in use."""
+    import torch.distributed as dist
+    world, local = int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if gpus != world:
+        raise SystemExit(f"--gpus {gpus} inside a {world}-rank group: run the plain command, it starts its own ranks")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("CAT_SELFPLAY_REHEARSE") == "1":
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        dist.init_process_group("gloo")
+        return "gloo (CAT_SELFPLAY_REHEARSE=1: ranks share devices)"
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    probe = torch.ones(1, device=torch.device("cuda", local))
+    dist.all_reduce(probe)
+    if int(probe.item()) != world:
+        raise RuntimeError(f"RCCL all-reduce of ones over {world} ranks returned {probe.item()}")
+    return "nccl (RCCL)"
 
 
 def main() -> None:
@@ -233,9 +314,41 @@ def main() -> None:
     ap.add_argument("--out", type=Path, default=Path("lstm_policy_archive_self_play_new"))
     ap.add_argument("--strategy", default="pfsp", choices=["latest", "random", "pfsp"])
     ap.add_argument("--eval-envs", type=int, default=None)
+    ap.add_argument("--max-step-count", type=int, default=2000, help="episode cap (self_play_driver.py:34 passes 2000)")
+    ap.add_argument("--horizon", type=int, default=None, help="rollout ticks per update (TrainerConfig default: 128)")
+    ap.add_argument("--cops", type=int, default=None)
+    ap.add_argument("--thieves", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--per-role-configs", action="store_true", help="CFG_AGENT_COP / CFG_AGENT_THIEF (mappo_config.py:19-39) instead of CFG_AGENT for both")
+    ap.add_argument("--random-timesteps", type=int, default=None, help="override of the role configs' random_timesteps (mappo_config.py:9: 10000)")
+    ap.add_argument("--learning-starts", type=int, default=None, help="override of learning_starts (mappo_config.py:10: 15000)")
+    ap.add_argument("--freeze-duration", type=int, default=None, help="override of CFG_TRAINER's policy / opponent freeze durations (15000)")
+    ap.add_argument("--gpus", type=int, default=1, help="data-parallel ranks, one per GPU: --envs is the TOTAL, sharded across them")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # plain command: start the ranks ourselves
+    backend = None
+    if args.gpus > 1:
+        backend = init_ranks(args.gpus)
     tc = TrainingConfig(policy_sample_strategy=args.strategy, training_timesteps_per_role_training=args.timesteps)
-    run_self_play(args.map, args.envs, args.out, iterations=args.iterations, training=tc, num_rays=args.rays, eval_envs=args.eval_envs)
+    over = {"horizon": args.horizon} if args.horizon else {}
+    if args.freeze_duration is not None:
+        over.update(policy_freeze_duration=args.freeze_duration, opponent_freeze_duration=args.freeze_duration)
+    tcfg = TrainerConfig(timesteps=args.timesteps, **over)
+    from .mappo import CFG_AGENT_COP, CFG_AGENT_THIEF
+    role_cfg = {"cop": CFG_AGENT_COP, "thief": CFG_AGENT_THIEF} if args.per_role_configs else {"cop": CFG_AGENT, "thief": CFG_AGENT}
+    sched = {k: v for k, v in (("random_timesteps", args.random_timesteps), ("learning_starts", args.learning_starts)) if v is not None}
+    role_cfg = {r: dataclasses.replace(c, **sched) for r, c in role_cfg.items()}
+    rank = int(os.environ.get("RANK", "0"))
+    res = run_self_play(args.map, args.envs, args.out, iterations=args.iterations, training=tc, trainer_cfg=tcfg, role_cfg=role_cfg,
+                        num_rays=args.rays, n_cops=args.cops, n_thieves=args.thieves, max_step_count=args.max_step_count,
+                        eval_envs=args.eval_envs, seed=args.seed, log=print if rank == 0 else (lambda *a, **k: None))
+    if backend:
+        import torch.distributed as dist
+        print(f"[self-play] rank {res['rank']}/{res['world']}: {res['envs_local']} envs from global id {res['env_id_offset']}, all-reduce over "
+              f"{backend}, parameters {res['param_digest'][:16]}", flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -239,7 +239,7 @@ def replay_profile(entry: dict, wl: dict, kernel: str, ticks_per_launch: int = 1
         entry["valu"] = prof["valu"]
 
 
-def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16) -> dict:
+def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16, rank: int = 0, world: int = 1, reduce_device=None) -> dict:
     """SURVEY 8(f) rank 2 beside the headline: env-steps/s of the MAPPO trainer on the same env workload -- rollout
     collection (env tick + the six stacked LSTM networks per tick) plus the PPO update of ``CFG_AGENT`` (4 epochs x 4
     minibatches), both as replayed HIP graphs over libcat_learn.so.  3 untimed rollout+update rounds (the graphs are
@@ -249,7 +249,9 @@ def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16)
     try:
         from as_cops_and_thieves_amd import VecCopsEnv, load_preset
         from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, TrainerConfig
-        env = VecCopsEnv(load_preset(map_name), num_envs=n_envs, num_rays=rays, max_step_count=400)
+        # world > 1: every rank trains on its own env shard inside the job's process group -- the trainer all-reduces its
+        # [G, P + 1] gradient | KL buffer every optimiser step (RCCL over xGMI when the group is nccl)
+        env = VecCopsEnv(load_preset(map_name), num_envs=n_envs, num_rays=rays, max_step_count=400, env_id_offset=rank * n_envs)
         tr = MAPPOTrainer(env, None, TrainerConfig(horizon=horizon), seed=0)
         for _ in range(3):
             tr.collect(); tr.update()
@@ -259,10 +261,17 @@ def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16)
             t0 = time.perf_counter(); tr.collect(); torch.cuda.synchronize(); t1 = time.perf_counter()
             tr.update(); torch.cuda.synchronize(); t2 = time.perf_counter()
             tc += t1 - t0; tu += t2 - t1
-        steps = rounds * tr.tcfg.horizon * n_envs
+        steps = world * rounds * tr.tcfg.horizon * n_envs
+        if world > 1:
+            from as_cops_and_thieves_amd.sharding import max_over_ranks
+            tc, tu = max_over_ranks(tc, device=reduce_device), max_over_ranks(tu, device=reduce_device)
         out = {"value": steps / (tc + tu), "unit": "env-steps/s", "rounds": rounds, "horizon": tr.tcfg.horizon,
                "collect_ms": 1e3 * tc / rounds, "update_ms": 1e3 * tu / rounds, "dtype": "bf16",
                "graphs": bool(tr._graph is not None and all(rl._graphs for rl in tr.roles.values()))}
+        if world > 1:
+            import torch.distributed as dist
+            out.update({"ranks": world, "envs_per_gpu": n_envs, "allreduce_backend": dist.get_backend(),
+                        "allreduces_per_update": 16, "param_digest": tr.param_digest()[:16]})
         env.close()
         return out
     except Exception as exc:   # noqa: BLE001
@@ -419,6 +428,10 @@ def main() -> None:
     if world > 1 and not args.no_extras and not args.shape_only:    # BASELINE configs[2]: agh-map, 32768 envs over 8 GPUs = 4096 per GPU, all ranks
         label, w = EXTRA_WORKLOADS[0]
         extra = {f"agh-map 2v1 x4096 per GPU (configs[2]), {world} GPUs": measure_extra(w)}
+        # configs[2]'s other half: MAPPO on the sharded envs, gradients all-reduced under the SAME process group the timing uses
+        lt = learner_throughput("agh-map", w["envs"], args.rays, rank=rank, world=world, reduce_device=None if rehearse else dev)
+        lt["rccl_ranks"] = rccl_ranks
+        extra[f"learner_collect_plus_update, {world} GPUs (agh-map 2v1 x4096 per GPU, CFG_AGENT)"] = lt
     if rank == 0 and world == 1 and not args.no_extras and not args.shape_only:   # the other BASELINE shapes, same process, same box
         extra = {label: measure_extra(w) for label, w in EXTRA_WORKLOADS}
         extra["learner_collect_plus_update"] = learner_throughput(args.map, cfg.n_envs, args.rays)

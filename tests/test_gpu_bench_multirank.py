@@ -34,8 +34,14 @@ def test_two_rank_bench_prints_one_aggregate_line():
     assert d["config"]["env_id_offsets"] == [0, envs]               # disjoint contiguous shards of the global env ids
     assert "gloo" in d["config"]["timing_reductions"]
     assert "cpu_baseline" not in d                                  # N = 1 only
-    (label, agh), = d["extra"].items()                              # configs[2]'s per-GPU shard, measured on every rank
-    assert label.startswith("agh-map 2v1 x4096 per GPU") and agh["value"] > 1e6 and agh["envs_per_gpu"] == 4096
+    (label, agh), = [(k, v) for k, v in d["extra"].items() if k.startswith("agh-map 2v1 x4096 per GPU")]   # configs[2]'s per-GPU shard, on every rank
+    assert agh["value"] > 1e6 and agh["envs_per_gpu"] == 4096 and agh["resident_rollout"]["value"] > agh["value"]
+    # configs[2]'s other half: the MAPPO learner on the sharded envs, its gradient | KL buffer all-reduced under the job's group
+    (_, lt), = [(k, v) for k, v in d["extra"].items() if k.startswith("learner_collect_plus_update, 2 GPUs")]
+    assert lt.get("value") and lt["ranks"] == 2 and lt["allreduce_backend"] == "gloo" and lt["rccl_ranks"] is None, lt
+    # the resident rollout launch on the headline workload, both ranks
+    (_, rr), = [(k, v) for k, v in d["extra"].items() if "resident rollout" in k]
+    assert rr["T"] == 64 and rr["value"] > d["value"] and rr["kernel_ms_per_tick"] > 0
     # whole-job aggregate: both ranks' env-steps over the slowest rank's time
     assert d["value"] == pytest.approx(2 * envs * steps / (d["ms_per_step"] * 1e-3 * steps), rel=1e-9)
     assert d["roofline"]["kernel_ms"] > 0 and d["value"] > 1e6

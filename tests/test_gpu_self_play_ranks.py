@@ -1,0 +1,32 @@
+"""GPU: the data-parallel self-play COMMAND, `python -m as_cops_and_thieves_amd.selfplay.self_play --gpus 2 ...`, typed as a plain
+command on the one-GPU box (CAT_SELFPLAY_REHEARSE=1: the two ranks share the GPU and gloo carries the all-reduce of the GPU
+gradient | KL buffer; on a multi-GPU node the same command opens an RCCL group).  The parent starts its own ranks; both end
+with identical parameters, rank 0 alone wrote the archives."""
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_self_play_command_with_two_ranks(tmp_path):
+    env = dict(os.environ, CAT_SELFPLAY_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=str(ROOT))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "as_cops_and_thieves_amd.selfplay.self_play", "--gpus", "2", "--map", "squarinth", "--envs", "512",
+           "--iterations", "2", "--timesteps", "96", "--horizon", "16", "--max-step-count", "60", "--random-timesteps", "16",
+           "--learning-starts", "32", "--freeze-duration", "48", "--out", str(tmp_path / "arch")]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
+    rows = re.findall(r"rank (\d)/2: (\d+) envs from global id (\d+), all-reduce over (.*?), parameters ([0-9a-f]{16})", res.stdout)
+    assert sorted((int(r), int(n), int(o)) for r, n, o, _, _ in rows) == [(0, 256, 0), (1, 256, 256)], res.stdout[-2000:]
+    assert rows[0][4] == rows[1][4]                                   # bit-identical replicas
+    assert "gloo" in rows[0][3]
+    for role, d in (("cop", "cops"), ("thief", "thieves")):
+        assert sorted(p.name for p in (tmp_path / "arch" / d).glob("*.pt")) == [f"{role}_iter_{i}.pt" for i in range(2)]
+    assert "2 ranks x 256 envs" in res.stdout
