@@ -389,6 +389,23 @@ class VecCopsEnv:
     def random_actions(self, tick: int) -> torch.Tensor:
         return self._sim.random_actions(tick, out=self._actions)
 
+    def rollout_random(self, ticks: int, tick0: int = 0) -> Dict[str, torch.Tensor]:
+        """``ticks`` env ticks under uniformly random actions -- what ``driver.py:65-69`` does tick by tick with
+        ``action_space(agent).sample()`` and skrl's trainer for ``random_timesteps`` (``mappo_config.py:9``) -- as ONE resident
+        launch (``cat_rollout_fused``: the map stays in LDS, the state records stay in LDS) for the first ``ticks - 1`` ticks, whose
+        outputs nobody reads (NULL output pointers: nothing is stored), and one ordinary step for the last, which leaves the
+        ``[N, ...]`` output buffers as ``step`` does.  The actions are the synthetic Philox draws of ticks ``tick0 .. tick0 + ticks - 1``
+        (``cat_random_actions``).  Returns the raw output buffers (``raw_outputs()``)."""
+        ticks = int(ticks)
+        if ticks < 1:
+            raise ValueError("ticks must be >= 1")
+        done, cap = 0, 65536
+        while ticks - 1 - done > 0:
+            n = min(cap, ticks - 1 - done)
+            self._sim.rollout_fused(n, None, tick=tick0 + done, auto_reset=self.auto_reset, out={})
+            done += n
+        return self._sim.step_fused(None, tick=tick0 + ticks - 1, auto_reset=self.auto_reset)
+
     def check_errors(self) -> None:
         """The step launches are asynchronous and cannot raise; this synchronises and raises ``ValueError`` if any
         action since the last check was outside ``Discrete(4)`` (the reference raises at once), ``CatSimError`` if a

@@ -84,6 +84,11 @@ class TrainerConfig:
     random_action_roles: Tuple[str, ...] = ()   # roles that act uniformly at random throughout (a fixed random opponent)
     deferred_values: bool = True           # kernel path: the critics do not run tick by tick (nothing in a rollout reads
                                            # their output) but once per BPTT window after the last tick, on all its ticks
+    resident_random_phase: bool = True     # while EVERY learner is inside its random_timesteps and none is due an update, the env is
+                                           # advanced by the resident rollout launch (VecCopsEnv.rollout_random: cat_rollout_fused,
+                                           # uniformly random Philox actions) instead of tick by tick -- skrl neither evaluates a
+                                           # network nor keeps a transition of that phase (no update before learning_starts, and the
+                                           # rollout memory is overwritten by then), so only the env's state after it matters
     normalize_inputs: bool = False         # False = the reference: raw distances (0..400) and type codes (0..4) go into the
                                            # convolutions (skrl's state_preprocessor is None).  True (build-side option):
                                            # distances / ray length, types / 4 -- see tools/learn_curve.py
@@ -620,18 +625,53 @@ class MAPPOTrainer:
             self.set_frozen(policy=tc.policy_freeze_duration > 0, value=False)
         while self.timestep < timesteps:
             t0, t1 = self.timestep, self.timestep + tc.horizon
+            span = self._random_phase_span(t0, timesteps)
+            if span:
+                t1 = t0 + span
             if tc.opponent_freeze_duration > 0 and t0 <= tc.opponent_freeze_duration < t1:
                 self.set_frozen(value=False)                     # "Unfreezing opponent agent" (README.md:104-108)
             if tc.policy_freeze_duration > 0 and t0 <= tc.policy_freeze_duration < t1:
                 self.set_frozen(policy=False)                    # "Unfreezing policy network" (:109-113)
             # skrl keeps these two thresholds per agent (each agent's own cfg): a learner still inside its random_timesteps
             # acts uniformly at random while another already samples its policy, and each starts updating on its own
+            if span:            # every learner acts at random and nothing of these ticks is kept: one resident launch
+                self._fast_forward_random(span)
+                continue
             in_random = frozenset(k for k, rl in self.roles.items() if t0 < rl.cfg.random_timesteps)
             self.collect(random_actions=in_random)
             ready = [k for k, rl in self.roles.items() if k not in in_random and self.timestep >= rl.cfg.learning_starts]
             if ready:
                 self.update(only=None if len(ready) == len(self.roles) else ready)
         return self.read_stats()
+
+    def _random_phase_span(self, t0: int, timesteps: int) -> int:
+        """How many ticks from ``t0`` can run as ONE resident random-action launch: whole rollouts (thresholds act at rollout
+        granularity, as in the tick-by-tick path) during which every learner is inside its ``random_timesteps`` and after which none
+        is due an update.  0: take the ordinary path."""
+        tc = self.tcfg
+        if not (tc.resident_random_phase and hasattr(self.env, "rollout_random")) or tc.random_action_roles:
+            return 0
+        H = tc.horizon
+        end = min(rl.cfg.random_timesteps for rl in self.roles.values())
+        n = 0
+        # rollout n starts at t0 + n H inside EVERY learner's random phase: train() then has every learner in `in_random`, none in
+        # `ready` -- no network is consulted for an action and no update follows the rollout
+        while t0 + (n + 1) * H <= timesteps and t0 + n * H < end:
+            n += 1
+        return n * H
+
+    def _fast_forward_random(self, ticks: int) -> None:
+        self._synth_tick = getattr(self, "_synth_tick", 1 << 20)
+        out = self.env.rollout_random(ticks, tick0=self._synth_tick)
+        self._synth_tick += ticks
+        self._obs = self.env.observations()
+        done = out["terminated"].bool()
+        self._starts.copy_(done)                      # the env auto-resets: the next tick starts a new episode there
+        self._keep32.copy_((~done).view(1, self.N))
+        for rl in self.roles.values():                # no network ran during the phase: the recurrent states start from zero
+            for st in rl.p_state + rl.v_state:
+                st.zero_()
+        self.timestep += ticks
 
     # ------------------------------------------------------------------ checkpoints
     def agent_models(self, agent: str) -> Dict[str, Dict[str, torch.Tensor]]:

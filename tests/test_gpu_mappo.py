@@ -326,3 +326,35 @@ def test_the_reference_rollout_length_of_4096_ticks_is_reachable():
     assert all(not torch.equal(before[a], tr.agent_models(a)["policy"]["policy_head.4.weight"]) for a in tr.agents)
     assert env._sim.device_errors() == 0
     env.close()
+
+
+def test_random_phase_runs_as_one_resident_launch():
+    """While every learner is inside its random_timesteps (mappo_config.py:9) the trainer advances the env with the resident
+    rollout launch: the env ends in exactly the state a tick-by-tick run of the same synthetic random actions reaches, and training
+    carries on from there."""
+    import torch
+    from as_cops_and_thieves_amd import VecCopsEnv, load_preset
+    from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, RoleConfig, TrainerConfig
+    env = VecCopsEnv(load_preset("squarinth"), 64, num_rays=64, max_step_count=40, seed=5)
+    ref = VecCopsEnv(load_preset("squarinth"), 64, num_rays=64, max_step_count=40, seed=5)
+    rc = RoleConfig(learning_epochs=1, mini_batches=2, random_timesteps=96, learning_starts=112, kl_threshold=0.0)
+    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(horizon=16, timesteps=96, policy_freeze_duration=0, opponent_freeze_duration=0), seed=0)
+    assert tr._random_phase_span(0, 96) == 96 and tr._random_phase_span(0, 100) == 96 and tr._random_phase_span(96, 200) == 0
+    tr.train(96)                                           # all of it inside the random phase: ONE resident launch + one step
+    ref.reset()
+    for t in range(96):
+        ref._sim.step_fused(None, tick=(1 << 20) + t, auto_reset=True)
+    torch.cuda.synchronize()
+    a, b = env.get_env_state(), ref.get_env_state()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert all(torch.equal(env.raw_outputs()[k], ref.raw_outputs()[k]) for k in env.raw_outputs())
+    assert tr.timestep == 96 and torch.equal(tr._starts, ref.raw_outputs()["terminated"].bool())
+    before = tr.param_digest()
+    tr2 = dataclass_replace_timesteps(tr, 160)            # the same trainer carries on past learning_starts and updates
+    assert tr2.param_digest() != before
+    env.close(); ref.close()
+
+
+def dataclass_replace_timesteps(tr, timesteps):
+    tr.train(timesteps)
+    return tr
