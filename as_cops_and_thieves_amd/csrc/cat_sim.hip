@@ -2136,7 +2136,13 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             int ap = 0;
             if (la.actions && lane < D::A(p)) ap = la.actions[((size_t)t * p.N + e_s) * D::A(p) + lane];
             if (lane == 0) ctrl[4 * slot + 1] = 0;
+#ifndef CAT_ABL_NOFRONT
             const int n2 = slot_front<D>(Ls, p, la, K->md, K->gd, e_s, lane, ap, la.synth_tick + (unsigned long long)t, pc);
+#else
+            const int n2 = fan_units<D>(p) + 1;
+            if (lane == 0) { Ls.flags[0] = 1; Ls.flags[1] = 0; Ls.flags[2] = 0; Ls.flags[3] = -1; }
+            (void)ap;
+#endif
             lds_release();
             if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], rw_make(t + 1, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             hint = slot;
@@ -2187,11 +2193,15 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
             const long long eo = (long long)t * p.N + e_s;   // row of the [T, N, ...] output buffers
             if (unit < fan_units<D>(p)) {
+#ifndef CAT_ABL_NOFAN      // diagnostic builds: a phase compiled out, for instruction counts by difference (tools/ablate_rollout.sh)
                 if constexpr (D::kFan == 1) fan_group<D>(Ls, p, la, K->gd, eo, lane, uni(K->md.S), K->md.cmax, 1, unit, pc);
                 else fan_chunk<D>(Ls, p, la, K->gd, eo, lane, uni(K->md.S), K->md.cmax, 1, unit, pc);
+#endif
             } else {
                 PHASE(pc, 9);
+#ifndef CAT_ABL_NOPHYS
                 physics_env<D>(Ls, p, uni(K->md.S), lane, pc);
+#endif
                 PHASE(pc, 10);
             }
             lds_release();   // the unit's LDS writes, before it counts as done
@@ -2214,7 +2224,11 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             const long long eo = (long long)t * p.N + e_s;
             const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
             const bool last = t + 1 >= T;
+#ifndef CAT_ABL_NOWB
             slot_writeback<D>(Ls, p, la, e_s, eo, lane, 1, last, step2, captured2, timeout2, rcount, G(p.cop_lut), G(p.thief_lut), pc);
+#else
+            (void)eo; (void)step2; (void)captured2; (void)timeout2; (void)rcount; (void)la;
+#endif
             wave_sync();   // the write-back has read the slot's staging and flags; the next front overwrites them
             if (!last) { pend = slot; pend_t = t + 1; }
             else if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], kRwFinished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

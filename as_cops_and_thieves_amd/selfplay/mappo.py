@@ -33,6 +33,7 @@ import torch
 
 from .. import packing
 from .. import _learn_native
+from .models import state_width
 from .stacked import (FlatParams, StackedNet, adam_state_dict, agent_state_dict, init_from_modules, load_adam_state_dict,
                       load_agent_state_dict,
                       role_param_shapes)
@@ -84,6 +85,11 @@ class TrainerConfig:
     random_action_roles: Tuple[str, ...] = ()   # roles that act uniformly at random throughout (a fixed random opponent)
     deferred_values: bool = True           # kernel path: the critics do not run tick by tick (nothing in a rollout reads
                                            # their output) but once per BPTT window after the last tick, on all its ticks
+    recurrent: bool = True                 # True: the LSTM pair the reference's drivers use (orchestration.py:52,121:
+                                           # initialize_lstm_models_for_mappo).  False: its non-recurrent pair (policy_net.py:9-45,
+                                           # value_net.py:8-34, model_utils.py:45-77 initialize_models_for_mappo): Policy = conv trunk +
+                                           # MLP on the agent's own rays, Value = an MLP over the WHOLE flattened shared state of all
+                                           # agents; stacked and trained by the same learner (torch packing path, the dense kernels)
     resident_random_phase: bool = True     # while EVERY learner is inside its random_timesteps and none is due an update, the env is
                                            # advanced by the resident rollout launch (VecCopsEnv.rollout_random: cat_rollout_fused,
                                            # uniformly random Philox actions) instead of tick by tick -- skrl neither evaluates a
@@ -192,7 +198,8 @@ class RoleLearner:
     BETA1, BETA2, EPS = 0.9, 0.999, 1e-8    # torch.optim.Adam defaults (what skrl constructs)
 
     def __init__(self, role: str, agents: List[str], indices: List[int], R: int, N: int, T: int, cfg: RoleConfig,
-                 device: torch.device, compute_dtype: torch.dtype, seeds: List[int], bptt: Optional[int] = None):
+                 device: torch.device, compute_dtype: torch.dtype, seeds: List[int], bptt: Optional[int] = None,
+                 arch: str = "lstm", vwidth: Optional[int] = None):
         self.role, self.agents, self.indices, self.cfg = role, agents, indices, cfg
         self.agent_roles = [a.split("_")[0] for a in agents]
         self.G, self.R, self.N, self.T, self.device = len(agents), R, N, T, device
@@ -200,9 +207,10 @@ class RoleLearner:
         assert T % self.bptt == 0, "horizon must be a multiple of the BPTT window"
         self.W = T // self.bptt                                # windows per rollout; training sequences = W * N
         self.index_t = torch.tensor(indices, dtype=torch.long, device=device)     # columns of the [N, A] action tensor
-        self.fp = FlatParams(role_param_shapes(R), self.G, device, compute_dtype)
-        init_from_modules(self.fp, R, seeds)
-        self.policy, self.value = StackedNet("policy", R, self.fp), StackedNet("value", R, self.fp)
+        self.arch = arch
+        self.fp = FlatParams(role_param_shapes(R, arch, vwidth), self.G, device, compute_dtype)
+        init_from_modules(self.fp, R, seeds, arch, vwidth)
+        self.policy, self.value = StackedNet("policy", R, self.fp, arch, vwidth), StackedNet("value", R, self.fp, arch, vwidth)
         G, P = self.G, self.fp.P
         f32 = dict(dtype=torch.float32, device=device)
         self.m, self.v, self.steps = torch.zeros(G, P, **f32), torch.zeros(G, P, **f32), torch.zeros(G, P, **f32)
@@ -219,7 +227,7 @@ class RoleLearner:
         self.B = B
         self.idx = torch.zeros(B, dtype=torch.long, device=device)
         in_dt = dict(dtype=compute_dtype if self.native else torch.float32, device=device)   # the networks cast to it anyway
-        self.buf = {"pin": torch.zeros(G, T, N, 2 * R, **in_dt), "vin": torch.zeros(G, T, N, 4 * R, **in_dt),
+        self.buf = {"pin": torch.zeros(G, T, N, 2 * R, **in_dt), "vin": torch.zeros(G, T, N, self.value.in_width, **in_dt),
                     "act": torch.zeros(G, T, N, dtype=torch.long, device=device), "logp": torch.zeros(G, T, N, **f32),
                     "val": torch.zeros(G, T, N, **f32), "rew": torch.zeros(G, T, N, **f32),
                     "adv": torch.zeros(G, T, N, **f32), "ret": torch.zeros(G, T, N, **f32)}
@@ -412,6 +420,8 @@ class MAPPOTrainer:
         self.N = env.num_envs
         self.R = env.observation_spaces[self.agents[0]]["distance"].shape[0]
         role_cfg = role_cfg or {}
+        n_cops = sum(a.startswith("cop") for a in self.agents)
+        self.state_width = state_width(len(self.agents), n_cops, self.R)    # flattened shared state: the non-recurrent critic's input
         on_gpu = self.device.type == "cuda"
         dt = torch.bfloat16 if (self.tcfg.compute_bf16 and on_gpu) else torch.float32
         # roles configured alike are stacked into ONE learner (key "cop+thief"); otherwise one learner per role
@@ -431,13 +441,17 @@ class MAPPOTrainer:
             idx = [self.agents.index(a) for a in names]
             self.roles["+".join(grp)] = RoleLearner("+".join(grp), names, idx, self.R, self.N, self.tcfg.horizon, cfgs[grp[0]],
                                                     self.device, dt, seeds=[seed * 1000 + i for i in idx],
-                                                    bptt=min(self.tcfg.bptt, self.tcfg.horizon))
+                                                    bptt=min(self.tcfg.bptt, self.tcfg.horizon),
+                                                    arch="lstm" if self.tcfg.recurrent else "mlp", vwidth=self.state_width)
         for rl in self.roles.values():
             mask = [r in self.tcfg.random_action_roles for r in rl.agent_roles]
             rl.random_rows = torch.tensor(mask, device=self.device).view(rl.G, 1) if any(mask) else None
         R, d, t = self.R, 1.0 / 400.0, 0.25          # ray length (entity.py:176 default sensor), number of type codes - 1
         self._pin_scale = torch.tensor([d] * R + [t] * R, device=self.device)
         self._vin_scale = torch.tensor(([d] * R + [t] * R) * 2, device=self.device)
+        nt = len(self.agents) - n_cops      # per agent (sorted ids: cops first): four ray channels, then its team's f16 positions (px)
+        self._state_scale = torch.tensor(sum((([d] * R + [t] * R) * 2 + [1e-3] * (2 * (n_cops if i < n_cops else nt))
+                                              for i in range(len(self.agents))), []), device=self.device)
         self._gen = torch.Generator(device="cpu").manual_seed(seed)
         torch.manual_seed(seed)
         self.timestep = 0
@@ -448,7 +462,7 @@ class MAPPOTrainer:
         self._done_buf = torch.zeros(T, self.N, dtype=torch.bool, device=self.device)
         self._start_buf = torch.zeros(T, self.N, dtype=torch.bool, device=self.device)
         self._actions = torch.zeros(self.N, len(self.agents), dtype=torch.int32, device=self.device)
-        self._native_io = on_gpu and hasattr(env, "raw_outputs")
+        self._native_io = on_gpu and hasattr(env, "raw_outputs") and self.tcfg.recurrent   # cat_rollout.h packs the LSTM pair's rows
         self._native_post = self._native_io and hasattr(env, "step_raw")   # cat_rollout_post: rewards and flags of the raw step   # cat_rollout.h: packing and sampling in one launch each
         self._graph = None
         self._eager_rollouts = 0
@@ -469,6 +483,11 @@ class MAPPOTrainer:
             self._pack_native(rl, pin, vin)
             return pin, vin
         pin = torch.stack([packing.pack_policy_input(obs[a]) for a in rl.agents])                       # [G, N, 2R]
+        if not self.tcfg.recurrent:      # value_net.py: every agent's critic reads the whole flattened shared state
+            vin = packing.pack_value_input(state).unsqueeze(0).expand(rl.G, -1, -1)
+            if self.tcfg.normalize_inputs:
+                pin, vin = pin * self._pin_scale, vin * self._state_scale
+            return pin, vin
         first = sorted(state)[0]
         vin = torch.stack([packing.pack_agent_state(state[first if self.tcfg.reference_q11 else a])[:, :4 * self.R]
                            for a in rl.agents])                                                         # [G, N, 4R]
@@ -691,7 +710,7 @@ class MAPPOTrainer:
             rl, g = self.learner_of(a)
             out[a] = dict(self.agent_models(a), optimizer=adam_state_dict(rl.fp, g, rl.m, rl.v, rl.steps, rl.cfg.learning_rate,
                                                                          (rl.BETA1, rl.BETA2), rl.EPS))
-        out[self.META_KEY] = {"format": "cat-mappo-3", "timestep": self.timestep, "num_rays": self.R}
+        out[self.META_KEY] = {"format": "cat-mappo-3", "timestep": self.timestep, "num_rays": self.R, "recurrent": bool(self.tcfg.recurrent)}
         return out
 
     def load_state_dict(self, sd: dict, roles: Optional[List[str]] = None, optimizer: bool = True) -> None:

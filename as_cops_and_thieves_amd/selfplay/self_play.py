@@ -323,6 +323,8 @@ def main() -> None:
     ap.add_argument("--random-timesteps", type=int, default=None, help="override of the role configs' random_timesteps (mappo_config.py:9: 10000)")
     ap.add_argument("--learning-starts", type=int, default=None, help="override of learning_starts (mappo_config.py:10: 15000)")
     ap.add_argument("--freeze-duration", type=int, default=None, help="override of CFG_TRAINER's policy / opponent freeze durations (15000)")
+    ap.add_argument("--non-recurrent", action="store_true", help="the reference's non-recurrent Policy / Value pair (policy_net.py, value_net.py; "
+                    "model_utils.py:45-77) instead of the LSTM pair its drivers use")
     ap.add_argument("--gpus", type=int, default=1, help="data-parallel ranks, one per GPU: --envs is the TOTAL, sharded across them")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -332,6 +334,8 @@ def main() -> None:
         backend = init_ranks(args.gpus)
     tc = TrainingConfig(policy_sample_strategy=args.strategy, training_timesteps_per_role_training=args.timesteps)
     over = {"horizon": args.horizon} if args.horizon else {}
+    if args.non_recurrent:
+        over["recurrent"] = False
     if args.freeze_duration is not None:
         over.update(policy_freeze_duration=args.freeze_duration, opponent_freeze_duration=args.freeze_duration)
     tcfg = TrainerConfig(timesteps=args.timesteps, **over)

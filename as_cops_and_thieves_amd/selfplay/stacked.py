@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from .. import _learn_native
-from .models import LSTMPolicy, LSTMValue, conv_out_len
+from .models import LSTMPolicy, LSTMValue, Policy, Value, conv_out_len
 
 HIDDEN = 128
 # the stacked parameters are rows of one flat buffer (row stride = all parameters of an agent), and their gradients are
@@ -222,9 +222,26 @@ class FlatParams:
 
 
 # ---------------------------------------------------------------------------------------------- the stacked net
-def _net_shapes(kind: str, R: int) -> Dict[str, Tuple[int, ...]]:
-    C, layers = (2, 1) if kind == "policy" else (4, 2)
+def _net_shapes(kind: str, R: int, arch: str = "lstm", vwidth: Optional[int] = None) -> Dict[str, Tuple[int, ...]]:
+    """Parameter names / shapes of one network.  ``arch`` "lstm": the reference's recurrent pair (lstm_policy_net.py:28-53,
+    lstm_value_net.py:46-75); "mlp": its non-recurrent pair -- ``Policy`` = the conv trunk + ``net`` 256-128-64-4
+    (policy_net.py:17-33), ``Value`` = ``net`` over the whole flattened shared state of ``vwidth`` entries, 512-256-128-64-1
+    (value_net.py:18-28)."""
     L2 = conv_out_len(R)
+    if arch == "mlp":
+        if kind == "policy":
+            s = {"features_extractor.0.weight": (64, 2, 5), "features_extractor.0.bias": (64,),
+                 "features_extractor.2.weight": (32, 64, 5), "features_extractor.2.bias": (32,),
+                 "features_extractor.5.weight": (256, 32 * L2), "features_extractor.5.bias": (256,)}
+            dims = [256, 128, 64, 4]
+        else:
+            assert vwidth, "the non-recurrent critic needs the width of the flattened shared state"
+            s, dims = {}, [vwidth, 512, 256, 128, 64, 1]
+        for j in range(len(dims) - 1):
+            s[f"net.{2 * j}.weight"] = (dims[j + 1], dims[j])
+            s[f"net.{2 * j}.bias"] = (dims[j + 1],)
+        return s
+    C, layers = (2, 1) if kind == "policy" else (4, 2)
     s = {"features_extractor.0.weight": (64, C, 5), "features_extractor.0.bias": (64,),
          "features_extractor.2.weight": (32, 64, 5), "features_extractor.2.bias": (32,),
          "features_extractor.5.weight": (256, 32 * L2), "features_extractor.5.bias": (256,)}
@@ -240,11 +257,11 @@ def _net_shapes(kind: str, R: int) -> Dict[str, Tuple[int, ...]]:
     return s
 
 
-def role_param_shapes(R: int) -> Dict[str, Tuple[int, ...]]:
+def role_param_shapes(R: int, arch: str = "lstm", vwidth: Optional[int] = None) -> Dict[str, Tuple[int, ...]]:
     """Names/shapes of one agent's parameters: ``policy.*`` then ``value.*`` (names below the prefix as in models.py)."""
     out = {}
     for kind in ("policy", "value"):
-        for n, shp in _net_shapes(kind, R).items():
+        for n, shp in _net_shapes(kind, R, arch, vwidth).items():
             out[f"{kind}.{n}"] = shp
     return out
 
@@ -426,12 +443,17 @@ def _conv_as_dense_indices(c_out: int, c_in: int, k: int, stride: int, l_in: int
 class StackedNet:
     """Functional forward of the G stacked policy or value networks of a role over a FlatParams."""
 
-    def __init__(self, kind: str, R: int, fp: FlatParams):
-        assert kind in ("policy", "value")
-        self.kind, self.R, self.fp = kind, R, fp
+    def __init__(self, kind: str, R: int, fp: FlatParams, arch: str = "lstm", vwidth: Optional[int] = None):
+        assert kind in ("policy", "value") and arch in ("lstm", "mlp")
+        self.kind, self.R, self.fp, self.arch, self.vwidth = kind, R, fp, arch, vwidth
         self.C, self.layers = (2, 1) if kind == "policy" else (4, 2)
         self.L1, self.L2 = (R - 5) // 2 + 1, conv_out_len(R)
         self.n_head = 3 if kind == "policy" else 4
+        self.head = f"{kind}_head"
+        if arch == "mlp":   # the reference's non-recurrent pair: no LSTM; the critic has no trunk either (an MLP over the whole state)
+            self.layers, self.head = 0, "net"
+            self.n_head = 3 if kind == "policy" else 5
+        self.in_width = self.C * R if (arch == "lstm" or kind == "policy") else int(vwidth)
         dev = fp.master.device
         # Both convolutions run as ONE dense GEMM each, on the Toeplitz expansion of their (tiny) weights.  It multiplies
         # the flops by ~10 -- irrelevant on the matrix cores -- and removes what the update was actually spending its
@@ -468,6 +490,13 @@ class StackedNet:
         B = B_all if select is None else select.shape[0]
         dt = self.fp.compute_dtype
         N = T * B
+        if self.arch == "mlp" and self.kind == "value":   # value_net.py:18-28: no trunk, no recurrence
+            if select is not None:
+                x = x.index_select(2, select)
+            y = x.reshape(G, N, self.in_width).to(dt)
+            for j in range(self.n_head):
+                y = _lin_act(y, self.w(f"net.{2 * j}.weight"), self.w(f"net.{2 * j}.bias"), 1 if j < self.n_head - 1 else 0)
+            return y.view(G, T, B, -1), state
         fused = (self.fused_trunk and x.is_cuda and dt == torch.bfloat16 and _learn_native.trunk_supported(G, N, self.C, self.R))
         if select is not None and not (fused and x.dtype == dt and x.is_contiguous()):
             x, select = x.index_select(2, select), None
@@ -514,26 +543,28 @@ class StackedNet:
             inp = out.reshape(G, N, HIDDEN)
         y = inp
         for j in range(self.n_head):
-            y = _lin_act(y, self.w(f"{self.kind}_head.{2 * j}.weight"), self.w(f"{self.kind}_head.{2 * j}.bias"), 1 if j < self.n_head - 1 else 0)
-        if update_state and native and not torch.is_grad_enabled() and h0.dtype == dt:
+            y = _lin_act(y, self.w(f"{self.head}.{2 * j}.weight"), self.w(f"{self.head}.{2 * j}.bias"), 1 if j < self.n_head - 1 else 0)
+        if self.layers == 0 or (update_state and native and not torch.is_grad_enabled() and h0.dtype == dt):
             return y.view(G, T, B, -1), state
         return y.view(G, T, B, -1), (torch.stack(hs, 0), torch.stack(cs, 0))
 
 
 # ---------------------------------------------------------------------------------------------- per-agent checkpoints
-def _module_for(kind: str, R: int) -> nn.Module:
+def _module_for(kind: str, R: int, arch: str = "lstm", vwidth: Optional[int] = None) -> nn.Module:
+    if arch == "mlp":
+        return Policy(R) if kind == "policy" else Value(int(vwidth))
     return LSTMPolicy(R) if kind == "policy" else LSTMValue(R)
 
 
 @torch.no_grad()
-def init_from_modules(fp: FlatParams, R: int, seeds: Sequence[int]) -> None:
+def init_from_modules(fp: FlatParams, R: int, seeds: Sequence[int], arch: str = "lstm", vwidth: Optional[int] = None) -> None:
     """Initialise row g of the flat buffer exactly as freshly constructed per-agent modules would be (PyTorch's
     default initialisers, seeded per agent), so a stacked run and a per-module run start from the same weights."""
     for g, seed in enumerate(seeds):
         gen_state = torch.random.get_rng_state()
         torch.manual_seed(seed)
         for kind in ("policy", "value"):
-            sd = _module_for(kind, R).state_dict()
+            sd = _module_for(kind, R, arch, vwidth).state_dict()
             for n, v in sd.items():
                 fp.master_view(f"{kind}.{n}")[g].copy_(v)
         torch.random.set_rng_state(gen_state)

@@ -358,3 +358,24 @@ def test_random_phase_runs_as_one_resident_launch():
 def dataclass_replace_timesteps(tr, timesteps):
     tr.train(timesteps)
     return tr
+
+
+def test_non_recurrent_pair_trains_on_the_gpu():
+    """TrainerConfig.recurrent = False (the reference's Policy / Value, policy_net.py:9-45 / value_net.py:8-34) through the bf16
+    stacked path on the GPU: graph-captured update, finite statistics, parameters move, checkpoint names are the reference's."""
+    import torch
+    from as_cops_and_thieves_amd import VecCopsEnv, load_preset
+    from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, RoleConfig, TrainerConfig
+    env = VecCopsEnv(load_preset("squarinth"), 256, num_rays=64, max_step_count=60, seed=2)
+    rc = RoleConfig(learning_epochs=2, mini_batches=2, random_timesteps=0, learning_starts=0)
+    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(horizon=16, policy_freeze_duration=0, opponent_freeze_duration=0,
+                                                                  recurrent=False), seed=0)
+    before = tr.param_digest()
+    stats = tr.train(96)
+    torch.cuda.synchronize()
+    rl = next(iter(tr.roles.values()))
+    assert rl.arch == "mlp" and rl.buf["vin"].shape[-1] == tr.state_width == 3 * 256 + 4 + 4 + 2
+    assert tr.param_digest() != before and all(v == v and abs(v) < 1e6 for v in stats.values()), stats
+    assert "net.8.weight" in tr.state_dict()["cop_0"]["value"] and "net.4.bias" in tr.state_dict()["thief_0"]["policy"]
+    assert env._sim.device_errors() == 0
+    env.close()

@@ -387,3 +387,68 @@ def test_non_recurrent_pair_and_the_two_model_initialisers():
     assert [m.out_features for m in val.net if isinstance(m, torch.nn.Linear)] == [512, 256, 128, 64, 1]
     rec = initialize_lstm_models_for_mappo(agents, R)
     assert isinstance(rec["cop_1"]["policy"], LSTMPolicy) and isinstance(rec["cop_1"]["value"], LSTMValue)
+
+
+@pytest.mark.parametrize("kind", ["policy", "value"])
+def test_stacked_non_recurrent_networks_equal_the_per_agent_modules(kind):
+    """The trainer's non-recurrent variant (TrainerConfig.recurrent = False: policy_net.py:9-45, value_net.py:8-34): forward values
+    and every parameter gradient of the role-stacked evaluation against the reference-shaped ``Policy`` / ``Value`` of each agent."""
+    from as_cops_and_thieves_amd.selfplay.models import Policy, Value
+    torch.manual_seed(0)
+    R, G, T, B, W = 16, 2, 3, 4, 140
+    fp = FlatParams(role_param_shapes(R, "mlp", W), G, "cpu", torch.float32)
+    init_from_modules(fp, R, [21, 22], "mlp", W)
+    net = StackedNet(kind, R, fp, "mlp", W)
+    assert net.layers == 0 and net.in_width == (2 * R if kind == "policy" else W)
+    x = torch.randn(G, T, B, net.in_width)
+    st = net.initial_state(B)
+    out, st2 = net.forward(x, st, None)
+    assert st2[0].numel() == 0                                        # no recurrent state
+    fp.grad.zero_()
+    (out ** 2).sum().backward()
+    for g in range(G):
+        m = Policy(R) if kind == "policy" else Value(W)
+        m.load_state_dict(agent_state_dict(fp, g)[kind])             # the reference modules' parameter names: features_extractor.*, net.*
+        o = m(x[g].reshape(T * B, -1)).reshape(T, B, -1)
+        assert torch.allclose(o, out[g], atol=1e-5)
+        (o ** 2).sum().backward()
+        for n, q in m.named_parameters():
+            off, k, shp = fp.offsets[f"{kind}.{n}"]
+            assert torch.allclose(fp.grad[g, off:off + k].view(shp), q.grad, rtol=1e-4, atol=1e-6 * float(q.grad.abs().max() + 1)), n
+    sel = torch.tensor([2, 0])
+    out_sel, _ = net.forward(x, net.initial_state(2), None, select=sel)      # a PPO minibatch: sequences `sel` of the buffer
+    assert torch.allclose(out_sel, out[:, :, sel].detach(), atol=1e-6)
+
+
+def test_trainer_runs_the_non_recurrent_pair(tmp_path):
+    """MAPPOTrainer with recurrent=False: the critics read the whole flattened shared state (packing.pack_value_input), updates move
+    the parameters, and the checkpoint carries the reference modules' names and loads into models.Policy / Value."""
+    from as_cops_and_thieves_amd import packing
+    from as_cops_and_thieves_amd.selfplay.models import Policy, Value, state_width
+    env = _env()
+    rc = RoleConfig(learning_epochs=1, mini_batches=2, random_timesteps=0, learning_starts=0, kl_threshold=0.0)
+    tr = MAPPOTrainer(env, {"cop": rc, "thief": rc}, TrainerConfig(horizon=4, bptt=4, timesteps=8, policy_freeze_duration=0,
+                                                                  opponent_freeze_duration=0, recurrent=False), seed=3)
+    rl = next(iter(tr.roles.values()))
+    W = state_width(len(env.possible_agents), env.nc, 16)
+    assert rl.arch == "mlp" and rl.buf["vin"].shape[-1] == W == packing.pack_value_input(env.state()).shape[1]
+    before = tr.param_digest()
+    stats = tr.train(8)
+    assert tr.param_digest() != before and all(np.isfinite(v) for v in stats.values())
+    sd = tr.state_dict()
+    assert sd["__cat__"]["recurrent"] is False
+    assert sorted(sd["cop_0"]["value"]) == sorted(Value(W).state_dict()) and sorted(sd["cop_0"]["policy"]) == sorted(Policy(16).state_dict())
+    pol, val = Policy(16), Value(W)
+    pol.load_state_dict(sd["thief_0"]["policy"]); val.load_state_dict(sd["thief_0"]["value"])
+    obs, _ = env.reset()
+    pin, vin = tr._inputs(rl, obs, env.state())
+    g = rl.agents.index("thief_0")
+    logits, _ = rl.policy.forward(pin.unsqueeze(1), rl.p_state, None)
+    values, _ = rl.value.forward(vin.unsqueeze(1), rl.v_state, None)
+    assert torch.allclose(logits[g, 0], pol(pin[g]), atol=1e-5) and torch.allclose(values[g, 0], val(vin[g]), atol=1e-5)
+    torch.save(sd, tmp_path / "ck.pt")
+    tr2 = MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=4, bptt=4, recurrent=False), seed=9)
+    tr2.load_state_dict(torch.load(tmp_path / "ck.pt", weights_only=True))
+    assert tr2.param_digest() == tr.param_digest()
+    with pytest.raises(KeyError):                                      # a recurrent trainer does not take a non-recurrent checkpoint
+        MAPPOTrainer(_env(), {"cop": rc, "thief": rc}, TrainerConfig(horizon=4, bptt=4), seed=9).load_state_dict(sd)
