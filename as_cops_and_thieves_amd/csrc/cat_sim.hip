@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <sched.h>
 #include <vector>
 
 #include "cat_sim.h"
@@ -2531,7 +2532,10 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
                     const double dd = dx * dx + dy * dy;
                     const double a0 = (X0 * dx + Y0 * dy) / dd, a1 = (X1 * dx + Y0 * dy) / dd, a2 = (X0 * dx + Y1 * dy) / dd, a3 = (X1 * dx + Y1 * dy) / dd;
                     const double amin = std::fmin(std::fmin(a0, a1), std::fmin(a2, a3)), amax = std::fmax(std::fmax(a0, a1), std::fmax(a2, a3));
-                    const double ms = eps * nscale;   // a margin across the ray, in the units of pmin / pmax
+                    // a margin across the ray, in the units of pmin / pmax: a ray passing that far outside a hull's end vertex still meets the
+                    // ROUNDED shape -- which needs a wall radius well above the margin.  With wall_radius ~ 0 the bb coincides with the hull,
+                    // a thin ray in that sliver misses the bb and the wall is never visited: no slack then.
+                    const double ms = (rsum - ray_radius) > 1e3 * eps ? eps * nscale : 0.0;
                     const size_t n = list.size();
                     f_lo.assign(n, 1e300); b_hi.assign(n, -1e300);
                     hulls.resize(n);
@@ -2607,6 +2611,10 @@ static void build_grids(const double *bb, int S, int R, const double *rdx, const
     std::vector<GridRowOut> rows((size_t)d.ny);
     {
         unsigned nt = std::thread::hardware_concurrency();
+        {   // the CPUs this process may run on (a container's share), not the machine's
+            cpu_set_t set;
+            if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && (unsigned)CPU_COUNT(&set) < nt) nt = (unsigned)CPU_COUNT(&set);
+        }
         if (nt > 16) nt = 16;
         if (nt < 1) nt = 1;
         if ((int)nt > d.ny) nt = (unsigned)d.ny;
@@ -2873,10 +2881,13 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
                 return CAT_ERR_BAD_MAP;
             }
         {
+            // bb overlap is a loose bound on simultaneous CONTACTS (slanted or star-shaped walls overlap boxes without touching):
+            // CAT_ALLOW_DEEP_WALL_OVERLAP=1 accepts such a map, with CAT_DEVERR_CONTACT_DROPPED as the run-time check
             const int depth = max_wall_bb_depth(f.data() + 2, d.S, cfg->agent_radius);
-            if (depth > CAT_WALL_CACHE) {
+            const char *allow = getenv("CAT_ALLOW_DEEP_WALL_OVERLAP");
+            if (depth > CAT_WALL_CACHE && !(allow && atoi(allow) != 0)) {
                 snprintf(g_create_err, sizeof g_create_err, "map blob %d: an agent can touch the bounding boxes of %d walls at once; the state record "
-                         "caches %d wall contacts per agent (CAT_WALL_CACHE)", m, depth, CAT_WALL_CACHE);
+                         "caches %d wall contacts per agent (CAT_WALL_CACHE); CAT_ALLOW_DEEP_WALL_OVERLAP=1 accepts the map", m, depth, CAT_WALL_CACHE);
                 return CAT_ERR_BAD_MAP;
             }
         }
@@ -2961,7 +2972,8 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
                 }
                 for (cell = 4.0; cell < 256.0; cell *= 2.0) {
                     const double rows = std::ceil((hi[0] - lo[0] + 2.0 * reach) / cell + 2.0) * std::ceil((hi[1] - lo[1] + 2.0 * reach) / cell + 2.0) * cfg->n_rays;
-                    if (rows * 8.0 <= 384e6) break;   // eight bytes per row unless a map's lists need the wide byte format
+                    // eight bytes per row unless a map's lists need the wide byte format; a sim of several maps shares the budget of two
+                    if (rows * 8.0 <= 384e6 * std::fmin(1.0, 2.0 / n_maps)) break;
                 }
             }
             build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, cfg->n_rays, tab->ray_dx, tab->ray_dy, reach, cfg->bbtree_gate != 0,

@@ -658,7 +658,9 @@ class MAPPOTrainer:
                 continue
             in_random = frozenset(k for k, rl in self.roles.items() if t0 < rl.cfg.random_timesteps)
             self.collect(random_actions=in_random)
-            ready = [k for k, rl in self.roles.items() if k not in in_random and self.timestep >= rl.cfg.learning_starts]
+            # skrl updates an agent whenever its timestep has reached ITS learning_starts, whatever its random_timesteps (a config
+            # with learning_starts below random_timesteps trains on uniformly random transitions, as in the reference's stack)
+            ready = [k for k, rl in self.roles.items() if self.timestep >= rl.cfg.learning_starts]
             if ready:
                 self.update(only=None if len(ready) == len(self.roles) else ready)
         return self.read_stats()
@@ -672,10 +674,11 @@ class MAPPOTrainer:
             return 0
         H = tc.horizon
         end = min(rl.cfg.random_timesteps for rl in self.roles.values())
+        first_update = min(rl.cfg.learning_starts for rl in self.roles.values())
         n = 0
-        # rollout n starts at t0 + n H inside EVERY learner's random phase: train() then has every learner in `in_random`, none in
-        # `ready` -- no network is consulted for an action and no update follows the rollout
-        while t0 + (n + 1) * H <= timesteps and t0 + n * H < end:
+        # rollout n starts at t0 + n H inside EVERY learner's random phase (no network is consulted for an action) and ends before
+        # any learner's learning_starts (no update follows it, so nothing of it is ever read)
+        while t0 + (n + 1) * H <= timesteps and t0 + n * H < end and t0 + (n + 1) * H < first_update:
             n += 1
         return n * H
 

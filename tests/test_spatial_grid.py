@@ -177,7 +177,7 @@ def test_segment_query_over_the_listed_walls_equals_the_query_over_all_walls(nam
     L.cat_grid_free_host(h)
 
 
-def _random_polygon_map(tmp_path, seed, n_blocks):
+def _random_polygon_map(tmp_path, seed, n_blocks, wall_radius=None):
     """Convex blocks of every kind the rules have to get right: slivers, slanted boxes, triangles, blocks that touch along an
     edge, overlap, or sit a hair (less than the ray radius) apart, and a ring of border walls."""
     import json
@@ -206,14 +206,18 @@ def _random_polygon_map(tmp_path, seed, n_blocks):
     f = tmp_path / f"random_{seed}.json"
     f.write_text(json.dumps({"window": {"w_px": 640, "h_px": 480}, "canvas": {"w": 640, "h": 480},
                              "objects": {"blocks": blocks}, "agents": agents}))
-    return Map(f).compile()
+    return Map(f).compile() if wall_radius is None else Map(f).compile(wall_radius)
 
 
-@pytest.mark.parametrize("seed,cell,gate", [(1, 4, 1), (2, 8, 1), (3, 4, 1), (4, 16, 1), (5, 4, 0), (6, 6, 1)])
-def test_listed_walls_give_the_full_query_result_on_random_polygon_maps(tmp_path, seed, cell, gate):
+@pytest.mark.parametrize("seed,cell,gate,wall_radius", [(1, 4, 1, None), (2, 8, 1, None), (3, 4, 1, None), (4, 16, 1, None), (5, 4, 0, None),
+                                                        (6, 6, 1, None),
+                                                        (7, 4, 1, 0.0), (8, 8, 1, 0.0), (9, 4, 0, 0.0)])   # wall_radius 0: a wall's bb IS its hull's
+def test_listed_walls_give_the_full_query_result_on_random_polygon_maps(tmp_path, seed, cell, gate, wall_radius):
+    """wall_radius = 0 (SimConfig allows it): the occlusion rule's slack across the ray relies on the ROUNDED shape
+    reaching past the hull's end vertices, which a zero radius does not give -- the rule then counts a hull only strictly inside."""
     from oracle.cat_oracle import OracleSim
-    cmap = _random_polygon_map(tmp_path, seed, 30)
-    cfg = SimConfig(n_envs=1, n_rays=64, bbtree_gate=gate)
+    cmap = _random_polygon_map(tmp_path, seed, 30, wall_radius)
+    cfg = SimConfig(n_envs=1, n_rays=64, bbtree_gate=gate, **({} if wall_radius is None else {"wall_radius": wall_radius}))
     L, h, rdx, rdy = _grid(cmap, cfg, cell)
     orc = OracleSim(cfg, [cmap])
     rng = np.random.default_rng(100 + seed)

@@ -34,9 +34,10 @@ for sh in $shapes; do
   done
   grep -E '"Name"|tick_kernel|rollout_kernel|reset_kernel' $d/trace/t_kernel_stats.csv > profiles/${tag}_${sh}_kernel_stats.csv
   { echo "# tick_kernel / reset_kernel: the last 25 launches; rollout_kernel: the last 4 (64 ticks each)"; python3 tools/pmc_summary.py --last 25 --only tick,reset $d/pmc*/p_counter_collection.csv; python3 tools/pmc_summary.py --last 4 --only rollout $d/pmc*/p_counter_collection.csv; } > profiles/${tag}_${sh}_pmc_summary.txt
-  python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel tick_kernel > /dev/null
-  python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel rollout_kernel --ticks-per-launch 64 > /dev/null
   grep -v amdgpu.ids $d/bench_under_rocprof.json | tail -1 > profiles/${tag}_${sh}_bench_under_rocprof.json
+  bi=$(python3 -c "import json; print(json.load(open('profiles/${tag}_${sh}_bench_under_rocprof.json'))['config']['burn_in_steps'])")   # what the run used
+  python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel tick_kernel --burn-in $bi > /dev/null
+  python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel rollout_kernel --ticks-per-launch 64 --burn-in $bi > /dev/null
   if [ $sh = lab ]; then
     for c in "FETCH_SIZE" "WRITE_SIZE"; do
       i=$((i+1))
@@ -45,7 +46,7 @@ for sh in $shapes; do
     python3 tools/pmc_summary.py --only tick $d/reset*/p_counter_collection.csv > profiles/${tag}_pmc_from_reset.txt
     cp profiles/${tag}_lab_kernel_stats.csv profiles/${tag}_final_kernel_stats.csv
     cp profiles/${tag}_lab_pmc_summary.txt profiles/${tag}_final_pmc_summary.txt
-    python3 tools/make_traffic_json.py $tag > /dev/null
+    python3 tools/make_traffic_json.py $tag --burn-in $bi > /dev/null
     cp profiles/${tag}_lab_bench_under_rocprof.json profiles/${tag}_final_bench_under_rocprof.json
   fi
   echo "$sh done" >> $out/progress.txt
