@@ -11,7 +11,7 @@
 // What each device function reproduces (paths relative to the reference repo; [CP x] = the
 // Chipmunk2D 7.0.x function of that name, a third-party dependency of the reference whose
 // published algorithm is followed -- SURVEY.md appendix A):
-//   tick_kernel   BaseEnv.step                       src/environments/base_env.py:354-413
+//   step_kernel / rollout_kernel   BaseEnv.step (one tick / T ticks per launch)   src/environments/base_env.py:354-413
 //   reset_kernel  BaseEnv.reset                      src/environments/base_env.py:286-352
 //   agent_setup, fan_chunk   Entity.get_observation/_query_body   src/agents/entity.py:159-241
 //   rewards_and_positions    Cop.reward / Thief.reward            src/agents/cop.py:49-75, thief.py:48-69
@@ -125,8 +125,10 @@ struct Params {
 };
 
 // Problem dimensions as seen by the device code: either read from the parameter block (DynDims) or compile-time
-// constants for the rosters / ray counts that are instantiated (FixDims): constant LDS offsets, unrolled agent
-// loops and far fewer live scalars (the generic kernel spills ~150 SGPRs to VGPR lanes, the fixed ones ~25).
+// constants for the rosters / ray counts that are instantiated (FixDims): constant LDS offsets and unrolled agent loops.
+// Round 4, as the compiler reports them (tools/regs.sh): step_kernel / rollout_kernel 115 - 121 VGPRs and 36 - 51 spilled SGPRs,
+// reset_kernel 103 - 107 VGPRs and 12 - 22; no scratch in any instantiation (rounds 1 - 3, tick_kernel: 127 - 128 VGPRs, 64 - 78
+// spilled SGPRs fixed, 107 - 134 + 64 B of scratch generic -- see "opaque roots" below).
 struct DynDims {
     static __device__ __forceinline__ int A(const Params &p) { return p.A; }
     static __device__ __forceinline__ int R(const Params &p) { return p.R; }
@@ -214,8 +216,8 @@ struct LaunchArgs {
     const unsigned char *mask;
     const double *positions;
     int use_done_mask;
-    int auto_reset;                 // tick_kernel: episodes that end this tick are reset inside the same launch
-    unsigned long long synth_tick;  // tick_kernel with actions == NULL: Philox actions of this tick
+    int auto_reset;                 // step / rollout: episodes that end with a tick are reset inside the same launch
+    unsigned long long synth_tick;  // step / rollout with actions == NULL: Philox actions of this tick (rollout: of the first tick)
     int T;                          // rollout_kernel: ticks per launch (outputs and actions carry a leading T)
 };
 
@@ -1698,7 +1700,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
 }
 
 template <class D>
-__device__ __forceinline__ void stage_map(const Params &p, char *smem, const MapDesc &md)
+__device__ __forceinline__ void stage_map(const Params &p, char *smem, const MapDesc &md, const BlockDesc *desc = nullptr, BlockDesc *desc_dst = nullptr)
 {
     const int nrest = geo_rest_doubles(md), nf = kBB * md.S + nrest;      // doubles of geometry in LDS
     double *dst = reinterpret_cast<double *>(smem);
@@ -1732,6 +1734,17 @@ __device__ __forceinline__ void stage_map(const Params &p, char *smem, const Map
     }
     double *rd = reinterpret_cast<double *>(smem + p.lds_map_bytes - 16 * D::R(p));
     for (int i = threadIdx.x; i < D::R(p); i += blockDim.x) { rd[2 * i] = G(p.ray_dx)[i]; rd[2 * i + 1] = G(p.ray_dy)[i]; }
+    // the workgroup's BlockDesc -> LDS, from the registers the caller loaded it into (no second trip to memory); member by member:
+    // a struct copy would put the source on the stack
+    if (desc_dst && threadIdx.x == 0) {
+        const MapDesc &m = desc->md;
+        const GridDesc &g = desc->gd;
+        MapDesc &dm = desc_dst->md;
+        GridDesc &dg = desc_dst->gd;
+        dm.S = m.S; dm.P = m.P; dm.A = m.A; dm.n_regions = m.n_regions; dm.f64_off = m.f64_off; dm.i32_off = m.i32_off; dm.cmax = m.cmax; dm.PP = m.PP;
+        dg.x0 = g.x0; dg.y0 = g.y0; dg.inv_cell = g.inv_cell; dg.nx = g.nx; dg.ny = g.ny; dg.off_base = g.off_base; dg.ent_base = g.ent_base;
+        dg.coff_base = g.coff_base; dg.cent_base = g.cent_base; dg.crow_base = g.crow_base; dg.pad2 = g.pad2; dg.row_base = g.row_base; dg.pad1 = g.pad1;
+    }
     __syncthreads();
 }
 
@@ -1859,66 +1872,115 @@ __device__ __forceinline__ void slot_writeback(const Lds &Ls, const Params &p, c
     }
 }
 
+// Large kernels whose inlined phases share one loop (run_units, the resident rollout's scheduler): whatever is invariant across
+// the loop -- lane-derived LDS addresses, output pointers plus lane offsets, compare masks, fields of Params and of the launch
+// arguments -- the compiler hoists in front of it and then keeps alive through every phase (first build of the rollout kernel:
+// 141 spilled VGPRs, 760 B of scratch per lane; the one-tick kernel: 64 - 134 SGPRs spilled, scratch in the generic
+// instantiation).  So each phase starts from opaque copies of its roots (lane id, parameter pointer, kernarg pointer) and
+// re-derives what it needs, the workgroup's map / grid descriptors are re-read from an LDS copy by the phase that needs them
+// (BlockDesc behind the control words), and nothing but the scheduler's own few scalars lives across phases.
+// (opaque_v is only ever given a lane id: the range is handed back to the compiler, which otherwise unrolls every lane-strided
+// loop -- the wide stores of the write-back -- for an unknown start: 283 global stores in the one-tick kernel instead of 27)
+__device__ __forceinline__ int opaque_v(int v) { asm volatile("" : "+v"(v)); __builtin_assume((unsigned)v < (unsigned)kLanes); return v; }
+typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsK;   // the by-value launch arguments, in the kernarg segment
+typedef const Params __attribute__((address_space(4))) *ParamsK;   // the parameter block is never written while a kernel runs: constant address space -> scalar loads
+// kernarg layout of the three env kernels: [const Params *][LaunchArgs] (8-byte aligned)
+__device__ __forceinline__ LaunchArgsK kernarg_launch_args()
+{
+    return (LaunchArgsK)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+}
+// the workgroup's descriptors in LDS (written by stage_map before its barrier)
+__device__ __forceinline__ const BlockDesc *block_desc_lds(char *smem, const Params &p, int W)
+{
+    return reinterpret_cast<const BlockDesc *>(smem + p.lds_map_bytes + 16 * W);
+}
+// What a kernel's prologue needs of the parameter block (env id, descriptors, state record, map staging, LDS carve), requested
+// in ONE burst of scalar loads and pinned: left to itself the compiler loads each field where it is first used -- behind the
+// prologue's branches -- and the launch starts with a chain of four dependent round trips to a cold scalar cache instead of two
+// (measured: + 1 600 cycles in front of the map staging).  The copy lives in registers only (every field access is resolved at
+// compile time); fields that are not listed here must not be read through it.  (Pinning the WHOLE block, so that the serial front
+// after the barrier reads registers too, was built: 75 spilled SGPRs in the one-tick kernel.)
+__device__ __forceinline__ Params prologue_params(ParamsK pk)
+{
+    Params q;
+    q.lds_map_bytes = pk->lds_map_bytes; q.lds_env_bytes = pk->lds_env_bytes; q.lds_union_bytes = pk->lds_union_bytes; q.wpb = pk->wpb;
+    q.A = pk->A; q.R = pk->R; q.NP = pk->NP; q.maxc = pk->maxc; q.n_cops = pk->n_cops; q.rec_bytes = pk->rec_bytes; q.hot_bytes = pk->hot_bytes;
+    q.work_env = pk->work_env; q.block_desc = pk->block_desc; q.state = pk->state;
+    q.geo_f64 = pk->geo_f64; q.geo_i32 = pk->geo_i32; q.ray_dx = pk->ray_dx; q.ray_dy = pk->ray_dy;
+    q.cop_lut = pk->cop_lut; q.thief_lut = pk->thief_lut;
+    // ONE pin for all of them: the loads above are issued together and waited for once
+    asm volatile("" : "+s"(q.lds_map_bytes), "+s"(q.lds_env_bytes), "+s"(q.lds_union_bytes), "+s"(q.wpb), "+s"(q.A), "+s"(q.R), "+s"(q.NP),
+                      "+s"(q.maxc), "+s"(q.n_cops), "+s"(q.rec_bytes), "+s"(q.hot_bytes), "+s"(q.work_env), "+s"(q.block_desc), "+s"(q.state),
+                      "+s"(q.geo_f64), "+s"(q.geo_i32), "+s"(q.ray_dx), "+s"(q.ray_dy), "+s"(q.cop_lut), "+s"(q.thief_lut));
+    return q;
+}
+
 // The shared part of both kernels.  Units of a published slot, claimed in order by any wave of the workgroup:
 // ray chunks 0 .. nchunks-1, then (tick only) Space.step.  A wave starts with its own slot.  The wave that completes
 // a slot's last unit writes that slot back: rewards, state record and outputs to HBM.
 // L.flags of a slot = {step_count to store, captured, timeout, reset_count to store or -1}.
 template <class D>
-__device__ __forceinline__ void run_units(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
-                                          const GridDesc &gd, char *smem, int wave, int lane, int tick, PhaseClock &pc)
+__device__ __forceinline__ void run_units(const Params *pp0, LaunchArgsK lap0, char *smem, int W, int wave, int lane0, int tick, PhaseClock &pc)
 {
-    const int W = p.wpb, S = md.S;
-    const int nchunks = fan_units<D>(p);
-    // fetched now, used at the write-back: the reward lookup then costs one global round trip, not two
-    GAS const float *cop_lut = launder(G(p.cop_lut)), *thief_lut = launder(G(p.thief_lut));
     unsigned fin_mask = 0u;
     bool own_first = true;
+    int *const ctrl0 = reinterpret_cast<int *>(smem + launder((ParamsK)pp0)->lds_map_bytes);   // one scalar, kept across the loop
+    // fetched now, used at every write-back: the reward lookup then costs one global round trip, not two
+    GAS const float *cop_lut = launder(G(launder((ParamsK)pp0)->cop_lut)), *thief_lut = launder(G(launder((ParamsK)pp0)->thief_lut));
     for (;;) {
-        // one LDS round trip for the whole workgroup: lane s < W reads the control words of slot s
-        int e_l = -1, nu_l = 0, cl_l = 0;
-        if (lane < W) {
-            e_l = L.ctrl[4 * lane + 3];   // written before the workgroup barrier
-            nu_l = __hip_atomic_load(&L.ctrl[4 * lane + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            cl_l = __hip_atomic_load(&L.ctrl[4 * lane + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int slot, e_s, last_unit;
+        {   // one LDS round trip for the whole workgroup: lane s < W reads the control words of slot s
+            const int lane = opaque_v(lane0);
+            int *const ctrl = ctrl0;
+            int e_l = -1, nu_l = 0, cl_l = 0;
+            if (lane < W) {
+                e_l = ctrl[4 * lane + 3];   // written before the workgroup barrier
+                nu_l = __hip_atomic_load(&ctrl[4 * lane + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                cl_l = __hip_atomic_load(&ctrl[4 * lane + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const unsigned open = (unsigned)__ballot(e_l >= 0 && nu_l > 0 && cl_l < nu_l);      // published, units left to claim
+            const unsigned unpublished = (unsigned)__ballot(e_l >= 0 && nu_l == 0);
+            if (open == 0u) {
+                if (unpublished == 0u) break;
+                __builtin_amdgcn_s_sleep(8);   // an owner is still in its serial part
+                continue;
+            }
+            // the own slot first, then the next open slot after the own index (spreads the helpers over the slots)
+            if (own_first && ((open >> wave) & 1u)) slot = wave;
+            else {
+                const unsigned rot = wave == 0 ? open : ((open >> wave) | (open << (32 - wave)));
+                slot = (wave + __builtin_ctz(rot)) & 31;   // bits >= W are never set (W <= 16)
+            }
+            own_first = false;
+            slot = uni(slot);
+            e_s = __builtin_amdgcn_readlane(e_l, slot);              // the scan already holds them
+            last_unit = __builtin_amdgcn_readlane(nu_l, slot) - 1;
+            if (slot != wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // another wave's slot
         }
-        const unsigned open = (unsigned)__ballot(e_l >= 0 && nu_l > 0 && cl_l < nu_l);      // published, units left to claim
-        const unsigned unpublished = (unsigned)__ballot(e_l >= 0 && nu_l == 0);
-        if (open == 0u) {
-            if (unpublished == 0u) break;
-            __builtin_amdgcn_s_sleep(8);   // an owner is still in its serial part
-            continue;
-        }
-        // the own slot first, then the next open slot after the own index (spreads the helpers over the slots)
-        int slot;
-        if (own_first && ((open >> wave) & 1u)) slot = wave;
-        else {
-            const unsigned rot = wave == 0 ? open : ((open >> wave) | (open << (32 - wave)));
-            slot = (wave + __builtin_ctz(rot)) & 31;   // bits >= W are never set (W <= 16)
-        }
-        own_first = false;
-        slot = uni(slot);
-        const int e_s = __builtin_amdgcn_readlane(e_l, slot);              // the scan already holds them
-        const int last_unit = __builtin_amdgcn_readlane(nu_l, slot) - 1;
-        if (slot != wave) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // another wave's slot
-        const Lds Ls = carve<D>(p, smem, md, slot, wave);
-        int c = ctrl_add(&L.ctrl[4 * slot + 0], lane);
+        int c = ctrl_add(&ctrl0[4 * slot + 0], opaque_v(lane0));
         while (c <= last_unit) {
+            const int lane = opaque_v(lane0);
+            const Params &p = *(const Params *)launder((ParamsK)pp0);
+            const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
+            int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+            const BlockDesc *const K = block_desc_lds(smem, p, W);
+            const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
             const int unit = c;
-            if (unit < nchunks) {   // entity.py:143-144, base_env.py:388-390 / :334-344
-                if constexpr (D::kFan == 1) fan_group<D>(Ls, p, la, gd, e_s, lane, S, md.cmax, tick, unit, pc);
-                else fan_chunk<D>(Ls, p, la, gd, e_s, lane, S, md.cmax, tick, unit, pc);
+            if (unit < fan_units<D>(p)) {   // entity.py:143-144, base_env.py:388-390 / :334-344
+                if constexpr (D::kFan == 1) fan_group<D>(Ls, p, la, K->gd, e_s, lane, uni(K->md.S), K->md.cmax, tick, unit, pc);
+                else fan_chunk<D>(Ls, p, la, K->gd, e_s, lane, uni(K->md.S), K->md.cmax, tick, unit, pc);
             }
             else {
                 PHASE(pc, 9);
-                physics_env<D>(Ls, p, S, lane, pc);                                // base_env.py:392
+                physics_env<D>(Ls, p, uni(K->md.S), lane, pc);                     // base_env.py:392
                 PHASE(pc, 10);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the unit's LDS writes, before it counts as done
             // "done" and the next claim in one LDS round trip (if this was the slot's last unit the claim returns past the end)
             int d = 0;
             if (lane == 0) {
-                d = __hip_atomic_fetch_add(&L.ctrl[4 * slot + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                c = __hip_atomic_fetch_add(&L.ctrl[4 * slot + 0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                d = __hip_atomic_fetch_add(&ctrl[4 * slot + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                c = __hip_atomic_fetch_add(&ctrl[4 * slot + 0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             d = uni(d); c = uni(c);
             if (d == last_unit) fin_mask |= 1u << slot;   // this wave completed the slot
@@ -1927,14 +1989,20 @@ __device__ __forceinline__ void run_units(const Lds &L, const Params &p, const L
     PHASE(pc, 16);
     if (fin_mask) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the other waves' units of those slots
     PHASE(pc, 21);
+    // ---- write-backs of the slots this wave completed: all output stores at the very end of the kernel
 #ifdef CAT_PHASE_TIMING
     bool wb_first = true;
 #endif
     while (fin_mask) {
+        const int lane = opaque_v(lane0);
+        const Params &p = *(const Params *)launder((ParamsK)pp0);
+        const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
+        int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+        const BlockDesc *const K = block_desc_lds(smem, p, W);
         const int slot = uni(__builtin_ctz(fin_mask));
         fin_mask &= fin_mask - 1;
-        const Lds Ls = carve<D>(p, smem, md, slot, wave);
-        const int e_s = uni(L.ctrl[4 * slot + 3]);
+        const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
+        const int e_s = uni(ctrl[4 * slot + 3]);
         const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
         PHASE(pc, 22);
 #ifdef CAT_PHASE_TIMING
@@ -2004,60 +2072,11 @@ __device__ __forceinline__ int slot_front(const Lds &L, const Params &p, const L
     return n_units;
 }
 
-// BaseEnv.step (base_env.py:354-413).  A workgroup of wpb waves advances wpb envs sharing one map.  Wave w OWNS
-// env slot w: it loads the state, decides termination, applies the actions, publishes the ray-fan setup, runs the
-// physics and writes everything back.  The ray fan itself is cut into 64-ray chunks that ANY wave of the
-// workgroup may claim (LDS counters): the SIMD arbitrates oldest-first, so with one env per wave the youngest
-// waves of a SIMD finish far behind the oldest and the launch ends on a lone wave; with shared chunks the
-// waves that get ahead take the others' chunks and the workgroup finishes together.  The observations read
-// the tick-start snapshot (pos, circle caches, leaf bbs) and Space.step reads nothing the observations
-// produce, so the owner's physics may overlap the chunks other waves run for it.
-template <class D>
-__global__ __launch_bounds__(kMaxWaves *kLanes) void tick_kernel(const Params *__restrict__ pp, const LaunchArgs la)
-{
-    const Params &p = *pp;
-    extern __shared__ __align__(16) char smem[];
-    const int W = uni((int)(blockDim.x / kLanes));
-    const int wave = uni(threadIdx.x / kLanes), lane = threadIdx.x % kLanes;
-    PhaseClock pc;
-#ifdef CAT_WAVE_SPREAD
-    const unsigned long long spread_t0 = __builtin_readcyclecounter();
-#endif
-    // the serial front of the launch is a chain of dependent global round trips (parameters -> descriptors -> geometry,
-    // env id -> state / actions) during which no wave has work: descriptors come with one load per workgroup, and the
-    // agents' actions are requested as soon as the env id is known, beside the state record
-    const int env = uni(p.work_env[blockIdx.x * W + wave]);
-    int act_pref = 0;
-    if (la.actions && env >= 0 && lane < D::A(p)) act_pref = la.actions[(size_t)env * D::A(p) + lane];
-    const MapDesc md = p.block_desc[blockIdx.x].md;
-    const GridDesc gd = p.block_desc[blockIdx.x].gd;
-    const Lds L = carve<D>(p, smem, md, wave, wave);
-    if (lane < 4) L.ctrl[4 * wave + lane] = lane == 3 ? env : 0;   // claimed, done, published, env id
-    StateRegs sregs;
-    fetch_state<D>(sregs, p, env, lane);
-    stage_map<D>(p, smem, md);   // ends with the workgroup barrier
-    PHASE(pc, 0);
-    const bool has = env >= 0;
-    if (has) {
-        commit_state<D>(L, sregs, p, lane);
-        load_cold<D>(L, p, env, lane);
-        PHASE(pc, 1);
-        const int n_units = slot_front<D>(L, p, la, md, gd, env, lane, act_pref, la.synth_tick, pc);
-        publish_slot(L, wave, lane, n_units);
-    }
-    run_units<D>(L, p, la, md, gd, smem, wave, lane, 1, pc);
-#ifdef CAT_WAVE_SPREAD
-    if (lane == 0 && env >= 0 && env < 65536) { g_wave_t[2 * env] = spread_t0; g_wave_t[2 * env + 1] = __builtin_readcyclecounter(); }
-#endif
-    PHASE(pc, 11);
-    pc.flush(lane);
-}
-
 // ------------------------------------------------------------------ resident rollout ----------
 // T consecutive ticks of BaseEnv.step in ONE launch (the random-action phases of the reference's loops: src/driver.py:65-69,
 // random_timesteps of src/configs/mappo_config.py:9; with an action tape: any fixed-policy replay).  The map is staged once, a
 // slot's state record stays in its LDS env area for all T ticks (HBM sees it after the last one), and EVERY tick's outputs go to
-// row t of caller buffers with a leading T.  Per tick the arithmetic is tick_kernel's (slot_front, the same work units, the same
+// row t of caller buffers with a leading T.  Per tick the arithmetic is the one-tick step's (slot_front, the same work units, the same
 // write-back), so the results equal T calls of cat_step_fused bit for bit.
 //
 // Scheduling.  The one-tick kernel pays, per launch, the dispatch floor, the map staging, the state record both ways and one slot's
@@ -2079,44 +2098,36 @@ __device__ __forceinline__ int rw_epoch(unsigned w) { return (int)(w >> 14); }
 __device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
 __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 
-// The scheduler loop below holds three large inlined phases (front, work unit, write-back).  Whatever is invariant across the loop
-// -- lane-derived LDS addresses, output pointers plus lane offsets, compare masks, fields of Params and of the launch arguments --
-// the compiler hoists in front of it and then has to keep alive through every phase (first build: 141 spilled VGPRs, 760 B of
-// scratch per lane).  So each phase starts from opaque copies of its roots (lane id, parameter pointer, kernarg pointer) and
-// re-derives what it needs: nothing but the scheduler's own few scalars lives across phases.
-__device__ __forceinline__ int opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
-typedef const LaunchArgs __attribute__((address_space(4))) *LaunchArgsK;
-typedef const Params __attribute__((address_space(4))) *ParamsK;   // the parameter block is never written while a kernel runs: constant address space -> scalar loads   // the by-value launch arguments, in the kernarg segment
-
-template <class D>
-__global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params *__restrict__ pp0, const LaunchArgs la0)
+template <class D, bool kOneTick>
+__device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, const LaunchArgs &la0)
 {
     extern __shared__ __align__(16) char smem[];
     const int lane0 = threadIdx.x % kLanes;
     const int wave = uni(threadIdx.x / kLanes);
-    // kernarg layout: [const Params *][LaunchArgs] (8-byte aligned)
-    const LaunchArgsK lap0 = (LaunchArgsK)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+    const LaunchArgsK lap0 = kernarg_launch_args();
     PhaseClock pc;
     int env, T, W;
+    GAS const float *lut_c, *lut_t;
     {   // ---- prologue: descriptors -> LDS, control words, state record -> LDS, map staging
-        const Params &p = *pp0;
+        const Params q = prologue_params((ParamsK)pp0);        // the pre-barrier part reads this register copy
+        const Params &p = *(const Params *)(ParamsK)pp0;
+        lut_c = G(q.cop_lut); lut_t = G(q.thief_lut);          // four scalars kept for the write-backs: the reward lookup is then one round trip
         const int lane = lane0;
         W = uni((int)(blockDim.x / kLanes));
-        T = la0.T;
-        env = uni(p.work_env[blockIdx.x * W + wave]);
-        int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
-        const MapDesc md0 = p.block_desc[blockIdx.x].md;
-        if (wave == 0 && lane < (int)(sizeof(BlockDesc) / 4))
-            reinterpret_cast<int *>(smem + p.lds_map_bytes + 16 * W)[lane] = reinterpret_cast<GAS const int *>(G(p.block_desc) + blockIdx.x)[lane];
+        T = kOneTick ? 1 : la0.T;
+        env = uni(q.work_env[blockIdx.x * W + wave]);
+        int *const ctrl = reinterpret_cast<int *>(smem + q.lds_map_bytes);
+        const BlockDesc bd0 = q.block_desc[blockIdx.x];
+        const MapDesc &md0 = bd0.md;
         // control words of slot `wave`: claim word (above), units done in this epoch, -, env id
         if (lane < 4) ctrl[4 * wave + lane] = lane == 3 ? env : ((lane == 0 && env < 0) ? (int)kRwFinished : 0);
         StateRegs sregs;
-        fetch_state<D>(sregs, p, env, lane);
-        stage_map<D>(p, smem, md0);   // ends with the workgroup barrier
+        fetch_state<D>(sregs, q, env, lane);
+        stage_map<D>(q, smem, md0, &bd0, const_cast<BlockDesc *>(block_desc_lds(smem, q, W)));   // ends with the workgroup barrier
         PHASE(pc, 0);
         if (env >= 0) {
-            const Lds L = carve<D>(p, smem, md0, wave, wave);
-            commit_state<D>(L, sregs, p, lane);
+            const Lds L = carve<D>(q, smem, md0, wave, wave);
+            commit_state<D>(L, sregs, q, lane);
             load_cold<D>(L, p, env, lane);
             PHASE(pc, 1);
         }
@@ -2129,7 +2140,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             const Params &p = *(const Params *)launder((ParamsK)pp0);
             const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
             int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
-            const BlockDesc *const K = reinterpret_cast<const BlockDesc *>(smem + p.lds_map_bytes + 16 * W);   // the workgroup's descriptors, in LDS
+            const BlockDesc *const K = block_desc_lds(smem, p, W);   // the workgroup's descriptors, in LDS
             const int slot = pend, t = pend_t;
             pend = -1;
             const int e_s = uni(ctrl[4 * slot + 3]);
@@ -2157,7 +2168,10 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             if (lane < W) w_l = __hip_atomic_load((unsigned *)&ctrl[4 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned open = (unsigned)__ballot(rw_next(w_l) < rw_units(w_l));
             if (open == 0u) {
-                if (__ballot(w_l != kRwFinished) == 0ull) break;   // every slot of the workgroup has finished its T ticks
+                // leave when nothing can be published any more: every slot has finished its T ticks -- with one tick per launch, when
+                // every slot HAS published (its units are all claimed; the waves running them write it back): a wave that stayed would
+                // only spin on the control words beside waves that still compute
+                if (__ballot(kOneTick ? (w_l == 0u) : (w_l != kRwFinished)) == 0ull) break;
                 __builtin_amdgcn_s_sleep(4);                        // fronts / write-backs under way on other waves
                 PHASE(pc, 21);
                 continue;
@@ -2189,7 +2203,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             const Params &p = *(const Params *)launder((ParamsK)pp0);
             const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
             int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
-            const BlockDesc *const K = reinterpret_cast<const BlockDesc *>(smem + p.lds_map_bytes + 16 * W);
+            const BlockDesc *const K = block_desc_lds(smem, p, W);
             const int e_s = uni(ctrl[4 * slot + 3]);
             const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
             const long long eo = (long long)t * p.N + e_s;   // row of the [T, N, ...] output buffers
@@ -2217,7 +2231,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             const Params &p = *(const Params *)launder((ParamsK)pp0);
             const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
             int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
-            const BlockDesc *const K = reinterpret_cast<const BlockDesc *>(smem + p.lds_map_bytes + 16 * W);
+            const BlockDesc *const K = block_desc_lds(smem, p, W);
             lds_acquire();
             PHASE(pc, 16);
             const int e_s = uni(ctrl[4 * slot + 3]);
@@ -2226,7 +2240,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
             const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
             const bool last = t + 1 >= T;
 #ifndef CAT_ABL_NOWB
-            slot_writeback<D>(Ls, p, la, e_s, eo, lane, 1, last, step2, captured2, timeout2, rcount, G(p.cop_lut), G(p.thief_lut), pc);
+            slot_writeback<D>(Ls, p, la, e_s, eo, lane, 1, last, step2, captured2, timeout2, rcount, lut_c, lut_t, pc);
 #else
             (void)eo; (void)step2; (void)captured2; (void)timeout2; (void)rcount; (void)la;
 #endif
@@ -2240,33 +2254,61 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
 }
 
 template <class D>
+__global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params *__restrict__ pp0, const LaunchArgs la0)
+{
+    rollout_body<D, false>(pp0, la0);
+}
+
+// BaseEnv.step (base_env.py:354-413), ONE tick per launch: what cat_step / cat_step_fused launch.  The same scheduler with T fixed
+// at 1 at compile time (the launch arguments are cat_step's).  Rounds 1 - 3 had a kernel of its own for this (tick_kernel: wave w
+// owned slot w for the front, units claimed own-slot-first, every write-back after the unit loop); rebuilt on this round's
+// per-phase roots it measured 1 - 3 % behind this one on every BASELINE shape (labyrinth x4096 33.0 against 32.0 us, agh-map 65.2 /
+// 64.7, 3v2 x8192 101.4 / 101.5, five maps x16384 173.8 / 169.8, 90 rays 41.8 / 41.1; the round-3 binary: 31.9 / 64.9 / 100.4 / 171.7 /
+// 41.6) and was removed.
+template <class D>
+__global__ __launch_bounds__(kMaxWaves *kLanes) void step_kernel(const Params *__restrict__ pp0, const LaunchArgs la0)
+{
+    rollout_body<D, true>(pp0, la0);
+}
+
+template <class D>
 __device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md,
                                            const GridDesc &gd, int env, int wave, int lane);
 
 // BaseEnv.reset (base_env.py:286-352) for masked envs
 template <class D>
-__global__ __launch_bounds__(kMaxWaves *kLanes) void reset_kernel(const Params *__restrict__ pp, const LaunchArgs la)
+__global__ __launch_bounds__(kMaxWaves *kLanes) void reset_kernel(const Params *__restrict__ pp0, const LaunchArgs la0)
 {
-    const Params &p = *pp;
     extern __shared__ __align__(16) char smem[];
-    const int W = uni((int)(blockDim.x / kLanes));
-    const int wave = uni(threadIdx.x / kLanes), lane = threadIdx.x % kLanes;
-    const int env = uni(p.work_env[blockIdx.x * W + wave]);
-    bool need = env >= 0;
-    if (need) {
-        if (la.use_done_mask)
-            need = ((GAS const int *)(G(p.state) + (size_t)env * D::rec_bytes(p) + 96 * D::A(p)))[2] != 0;   // the hot part's `done`
-        else if (la.mask) need = la.mask[env] != 0;
-    }
-    if (!__syncthreads_or(need ? 1 : 0)) return;  // nothing to reset in this workgroup: skip the map staging
-    const MapDesc md = p.maps[p.block_map[blockIdx.x]];
-    const GridDesc gd = p.grids[p.block_map[blockIdx.x]];
-    const Lds L = carve<D>(p, smem, md, wave, wave);
-    if (lane < 4) L.ctrl[4 * wave + lane] = lane == 3 ? (need ? env : -1) : 0;   // claimed, done, published, env id
-    stage_map<D>(p, smem, md);   // ends with the workgroup barrier
+    const int lane0 = threadIdx.x % kLanes;
+    const int wave = uni(threadIdx.x / kLanes);
+    const LaunchArgsK lap0 = kernarg_launch_args();
     PhaseClock pc;
-    if (need) reset_slot<D>(L, p, la, md, gd, env, wave, lane);
-    run_units<D>(L, p, la, md, gd, smem, wave, lane, 0, pc);   // waves with nothing to reset help with the others' ray chunks
+    int W;
+    {
+        const Params &p = *pp0;
+        const int lane = lane0;
+        W = uni((int)(blockDim.x / kLanes));
+        const int env = uni(p.work_env[blockIdx.x * W + wave]);
+        bool need = env >= 0;
+        if (need) {
+            if (la0.use_done_mask)
+                need = ((GAS const int *)(G(p.state) + (size_t)env * D::rec_bytes(p) + 96 * D::A(p)))[2] != 0;   // the hot part's `done`
+            else if (la0.mask) need = la0.mask[env] != 0;
+        }
+        if (!__syncthreads_or(need ? 1 : 0)) return;  // nothing to reset in this workgroup: skip the map staging
+        const BlockDesc bd0 = p.block_desc[blockIdx.x];
+        const MapDesc &md0 = bd0.md;
+        const GridDesc &gd0 = bd0.gd;
+        int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+        if (lane < 4) ctrl[4 * wave + lane] = lane == 3 ? (need ? env : -1) : 0;   // claimed, done, published, env id
+        stage_map<D>(p, smem, md0, &bd0, const_cast<BlockDesc *>(block_desc_lds(smem, p, W)));   // ends with the workgroup barrier
+        if (need) {
+            const Lds L = carve<D>(p, smem, md0, wave, wave);
+            reset_slot<D>(L, p, la0, md0, gd0, env, wave, lane);
+        }
+    }
+    run_units<D>(pp0, lap0, smem, W, wave, lane0, 0, pc);   // waves with nothing to reset help with the others' ray chunks
 }
 
 // Spawn sampling + Entity.reset of one env, then its ray-fan setup is published (reset_kernel).
@@ -2744,22 +2786,22 @@ static void finalize_rows(GridHost &g, int id_bits = 0, bool wide = false)
 // Kernel instantiations: fixed dimensions for the rosters / ray counts of the BASELINE configurations and of the
 // reference's defaults, the generic one for everything else (CAT_GENERIC_KERNEL=1 forces it: A/B tests).
 using KernelFn = void (*)(const Params *, const LaunchArgs);
-template <class D> static void kernels_of(int fan, KernelFn &tick, KernelFn &reset, KernelFn &rollout)
+template <class D> static void kernels_of(int fan, KernelFn &reset, KernelFn &rollout, KernelFn &step)
 {
-    if (fan == 1) { tick = tick_kernel<WithFan<D, 1>>; reset = reset_kernel<WithFan<D, 1>>; rollout = rollout_kernel<WithFan<D, 1>>; }
-    else { tick = tick_kernel<WithFan<D, 0>>; reset = reset_kernel<WithFan<D, 0>>; rollout = rollout_kernel<WithFan<D, 0>>; }
+    if (fan == 1) { reset = reset_kernel<WithFan<D, 1>>; rollout = rollout_kernel<WithFan<D, 1>>; step = step_kernel<WithFan<D, 1>>; }
+    else { reset = reset_kernel<WithFan<D, 0>>; rollout = rollout_kernel<WithFan<D, 0>>; step = step_kernel<WithFan<D, 0>>; }
 }
 // fan: 0 = chunk by chunk, 1 = agent groups with compacted rays (cat_create decides from the maps; CAT_FAN=chunks forces 0)
-static const char *select_kernels(int A, int R, int n_cops, int fan, KernelFn &tick, KernelFn &reset, KernelFn &rollout)
+static const char *select_kernels(int A, int R, int n_cops, int fan, KernelFn &reset, KernelFn &rollout, KernelFn &step)
 {
     const char *e = getenv("CAT_GENERIC_KERNEL");
     const bool generic = e && atoi(e) != 0;
-    if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(fan, tick, reset, rollout); return "3 agents (2 cops), 64 rays"; }
+    if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(fan, reset, rollout, step); return "3 agents (2 cops), 64 rays"; }
 #ifndef CAT_QUICK_BUILD   // diagnostic builds (tools/build_variant.sh -DCAT_QUICK_BUILD): the headline instantiation + the generic one only
-    if (!generic && A == 3 && n_cops == 2 && R == 90) { kernels_of<FixDims<3, 90, 2>>(fan, tick, reset, rollout); return "3 agents (2 cops), 90 rays"; }
-    if (!generic && A == 5 && n_cops == 3 && R == 64) { kernels_of<FixDims<5, 64, 3>>(fan, tick, reset, rollout); return "5 agents (3 cops), 64 rays"; }
+    if (!generic && A == 3 && n_cops == 2 && R == 90) { kernels_of<FixDims<3, 90, 2>>(fan, reset, rollout, step); return "3 agents (2 cops), 90 rays"; }
+    if (!generic && A == 5 && n_cops == 3 && R == 64) { kernels_of<FixDims<5, 64, 3>>(fan, reset, rollout, step); return "5 agents (3 cops), 64 rays"; }
 #endif
-    kernels_of<DynDims>(fan, tick, reset, rollout);
+    kernels_of<DynDims>(fan, reset, rollout, step);
     return "generic";
 }
 
@@ -2793,7 +2835,7 @@ struct cat_sim {
     Params *dev_p;
     int device;
     int n_blocks, wpb;
-    KernelFn tick_fn = nullptr, reset_fn = nullptr, rollout_fn = nullptr;   // the instantiation matching (agents, rays, cops)
+    KernelFn reset_fn = nullptr, rollout_fn = nullptr, step_fn = nullptr;   // the instantiations matching (agents, rays, cops): cat_reset*, cat_rollout_fused, cat_step*
     const char *kernel_variant = "";
     hipEvent_t t_start = nullptr, t_stop = nullptr;   // cat_arm_kernel_timing
     size_t lds_bytes;
@@ -2825,6 +2867,7 @@ static int dev_alloc(cat_sim *s, T **ptr, size_t count, const void *init)
 }
 
 extern "C" int cat_abi_version(void) { return CAT_ABI_VERSION; }
+extern "C" const char *cat_one_tick_kernel(const cat_sim *sim) { return sim ? "step_kernel" : ""; }
 extern "C" const char *cat_last_error(const cat_sim *sim) { return sim ? sim->err : g_create_err; }
 extern "C" int cat_num_agents(const cat_sim *sim) { return sim ? sim->p.A : CAT_ERR_BAD_ARG; }
 extern "C" int cat_num_shapes(const cat_sim *sim, int m)
@@ -3148,9 +3191,9 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     p.lds_map_bytes = ls.map; p.lds_env_bytes = ls.env; p.lds_union_bytes = ls.uni; p.wpb = wpb;
     s->wpb = wpb;
     s->lds_bytes = ls.total(wpb);
-    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, s->tick_fn, s->reset_fn, s->rollout_fn);
+    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, s->reset_fn, s->rollout_fn, s->step_fn);
     if (s->lds_bytes > 64 * 1024) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->tick_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->step_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
         hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->rollout_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
@@ -3202,12 +3245,12 @@ extern "C" int cat_reset_done(cat_sim *s, const cat_outputs *out, void *stream)
     return launch_reset(s, nullptr, nullptr, out, 1, stream);
 }
 
-// tick_kernel launch; when cat_arm_kernel_timing armed a pair of HIP events they are attached to THIS dispatch
+// step_kernel / rollout_kernel launch; when cat_arm_kernel_timing armed a pair of HIP events they are attached to THIS dispatch
 // (recorded at the kernel's own begin and end, not at the surrounding stream positions), one shot.
 static void launch_tick(cat_sim *s, const LaunchArgs &la, void *stream, KernelFn fn = nullptr)
 {
     const dim3 grid(s->n_blocks), block(s->wpb * kLanes);
-    if (!fn) fn = s->tick_fn;
+    if (!fn) fn = s->step_fn;
     if (s->t_start && s->t_stop) {
         hipExtLaunchKernelGGL(fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->t_start, s->t_stop, 0,
                               s->dev_p, la);

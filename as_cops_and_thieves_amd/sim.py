@@ -97,6 +97,11 @@ class CatSim:
         if rc != 0:
             raise CatSimError(f"{what}: {nat.ERRORS.get(rc, rc)}: {self._L.cat_last_error(self._h).decode()}")
 
+    @property
+    def one_tick_kernel(self) -> str:
+        """The kernel ``step`` / ``step_fused`` launch ("step_kernel"; diagnostic builds of earlier sources: "tick_kernel")."""
+        return self._L.cat_one_tick_kernel(self._h).decode() if hasattr(self._L, "cat_one_tick_kernel") else "tick_kernel"
+
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 

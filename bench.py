@@ -3,7 +3,7 @@
 
 One "step" = one tick of the whole env batch on every GPU: cat_step_fused = synthetic Philox actions
 generated in the step kernel + the full BaseEnv.step pipeline + the auto-reset of the episodes that end
-with the tick, ONE tick_kernel launch.  Workload =
+with the tick, ONE step_kernel launch.  Workload =
 BASELINE.json configs[1]: 2 cops vs 1 thief, labyrinth map, 4096 envs per GPU, 64 rays/agent.
 Env slots shard across GPUs with no data-path collective (weak scaling); only the timing uses a
 barrier + MAX all-reduce.  Prints ONE JSON line on rank 0; at N = 1 it also carries `extra`: the other
@@ -95,7 +95,7 @@ def cpu_baseline(cfg, cmap, budget_s: float = 12.0):
 
 
 def event_stride(steps: int) -> int:
-    """Which tick_kernel launches of the timed region carry their own pair of HIP events: every 8th on a long run; NONE (0) when
+    """Which step_kernel launches of the timed region carry their own pair of HIP events: every 8th on a long run; NONE (0) when
     K <= 40 -- a dispatch with events attached costs ~4 us of host / command-processor time (K = 20: 37.4 us per step with every
     launch bracketed, 34.5 with every 2nd, 32.4 with none), which a 20-step region does not absorb.  A short region is
     timed by ONE pair of events recorded on the kernel's stream around all K launches instead (timed_steps)."""
@@ -170,7 +170,7 @@ def build_sim(map_name: str, cops: int, thieves: int, envs: int, rays: int, rank
 
 def timed_steps(sim, steps: int, warmup: int, fence, hip: "HipEvents", first_tick: int = 0):
     """W untimed + K timed rollout steps (cat_step_fused: in-kernel Philox actions + tick + auto-reset, ONE launch per
-    step).  Long regions: every event_stride(K)-th tick_kernel launch carries a pair of HIP events attached to the
+    step).  Long regions: every event_stride(K)-th step_kernel launch carries a pair of HIP events attached to the
     dispatch itself (hipExtLaunchKernelGGL start/stop events, on the stream the kernel is launched on), so kernel_ms is
     the kernel's own duration, as in a rocprofv3 kernel trace.  Short regions (K <= 40, the driver's --steps 20): one pair of
     HIP events recorded on that stream around ALL K launches, kernel_ms = their span / K -- every launch of the region is timed,
@@ -384,6 +384,7 @@ def main() -> None:
         r_el = max_over_ranks(r_el, device=None if rehearse else dev)
         roll = (r_el, r_kms, r_n)
     episodes = int(sim.get_state()["reset_count"].sum().item())
+    one_tick_kernel = sim.one_tick_kernel      # "step_kernel": one tick through the resident rollout scheduler (rounds 1 - 3: "tick_kernel")
     sim.close()
     offsets = [cfg.env_id_offset]
     if world > 1:   # which global env ids each rank simulated (disjoint contiguous shards)
@@ -411,12 +412,13 @@ def main() -> None:
         bytes2 = algorithmic_bytes_per_env_step(c2.n_agents, c2.n_rays) * c2.n_envs
         r_el, r_kms, r_n = timed_rollout(s2, TR, fence, hip, first_tick=100 + k_steps)
         r_el = max_over_ranks(r_el, device=None if rehearse else dev)
+        kern2 = s2.one_tick_kernel
         s2.close()
         key = {"map": w["map"], "envs": w["envs"], "rays": w.get("rays", args.rays), "cops": w["cops"], "thieves": w["thieves"]}
         ent = {"value": world * c2.n_envs * k_steps / e2, "unit": "env-steps/s", "steps": k_steps,
-               "ms_per_step": 1e3 * e2 / k_steps, "kernel_ms": k2, "envs_per_gpu": c2.n_envs,
+               "ms_per_step": 1e3 * e2 / k_steps, "kernel": kern2, "kernel_ms": k2, "envs_per_gpu": c2.n_envs,
                "roofline_frac": bytes2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        replay_profile(ent, key, "tick_kernel")
+        replay_profile(ent, key, kern2)
         res = {"T": TR, "launches_timed": r_n, "value": world * c2.n_envs * TR * r_n / r_el, "unit": "env-steps/s",
                "kernel_ms_per_tick": r_kms, "roofline_frac": bytes2 / (r_kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                "what": "cat_rollout_fused: T ticks per launch, map staged once, state records resident in LDS, every tick's outputs written"}
@@ -447,7 +449,7 @@ def main() -> None:
         # replayed from the committed PMC summary of this exact workload and labelled as such
         traffic = valu = traffic_source = traffic_regime = traffic_from_reset = None
         wl = {"map": args.map, "envs": cfg.n_envs, "rays": R, "cops": args.cops, "thieves": args.thieves}
-        prof = find_profile(wl, "tick_kernel")   # newest round whose workload matches
+        prof = find_profile(wl, one_tick_kernel)   # newest round whose workload and kernel match
         if prof is not None:
             traffic, valu = prof["hbm_bytes_per_launch"], prof.get("valu")
             traffic_regime = prof.get("regime", "from reset (--burn-in 0: 25 launches straight after the reset)")
@@ -481,7 +483,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_regime": traffic_regime,
                          "traffic_from_reset": traffic_from_reset, "traffic_source": traffic_source,
-                         "kernel": "tick_kernel", "kernel_ms": tick_ms, "kernel_launches_timed": n_timed, "kernel_ms_method": tick_method,
+                         "kernel": one_tick_kernel, "kernel_ms": tick_ms, "kernel_launches_timed": n_timed, "kernel_ms_method": tick_method,
                          "algorithmic_bytes_per_launch": bytes_launch, "valu": valu, "valu_source": traffic_source,
                          "hbm_stream_copy_GBs": copy_gbs,
                          "frac_of_stream_copy": (achieved / copy_gbs) if copy_gbs else None,

@@ -32,21 +32,22 @@ for sh in $shapes; do
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d/pmc$i -o p -- python3 bench.py $a > /dev/null 2> $d/pmc$i.err
     echo "$sh pmc pass $i done" >> $out/progress.txt
   done
-  grep -E '"Name"|tick_kernel|rollout_kernel|reset_kernel' $d/trace/t_kernel_stats.csv > profiles/${tag}_${sh}_kernel_stats.csv
-  { echo "# tick_kernel / reset_kernel: the last 25 launches; rollout_kernel: the last 4 (64 ticks each)"; python3 tools/pmc_summary.py --last 25 --only tick,reset $d/pmc*/p_counter_collection.csv; python3 tools/pmc_summary.py --last 4 --only rollout $d/pmc*/p_counter_collection.csv; } > profiles/${tag}_${sh}_pmc_summary.txt
+  grep -E '"Name"|tick_kernel|step_kernel|rollout_kernel|reset_kernel' $d/trace/t_kernel_stats.csv > profiles/${tag}_${sh}_kernel_stats.csv
+  { echo "# tick_kernel / step_kernel (whichever serves this sim's one-tick calls) / reset_kernel: the last 25 launches; rollout_kernel: the last 4 (64 ticks each)"; python3 tools/pmc_summary.py --last 25 --only tick_kernel,step_kernel,reset_kernel $d/pmc*/p_counter_collection.csv; python3 tools/pmc_summary.py --last 4 --only rollout_kernel $d/pmc*/p_counter_collection.csv; } > profiles/${tag}_${sh}_pmc_summary.txt
   grep -v amdgpu.ids $d/bench_under_rocprof.json | tail -1 > profiles/${tag}_${sh}_bench_under_rocprof.json
   bi=$(python3 -c "import json; print(json.load(open('profiles/${tag}_${sh}_bench_under_rocprof.json'))['config']['burn_in_steps'])")   # what the run used
-  python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel tick_kernel --burn-in $bi > /dev/null
+  k1=$(python3 -c "import json; print(json.load(open('profiles/${tag}_${sh}_bench_under_rocprof.json'))['roofline']['kernel'])")   # tick_kernel or step_kernel
+  python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel $k1 --burn-in $bi > /dev/null
   python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel rollout_kernel --ticks-per-launch 64 --burn-in $bi > /dev/null
   if [ $sh = lab ]; then
     for c in "FETCH_SIZE" "WRITE_SIZE"; do
       i=$((i+1))
       timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d/reset$i -o p -- python3 bench.py $a --burn-in 0 > /dev/null 2> $d/reset$i.err
     done
-    python3 tools/pmc_summary.py --only tick $d/reset*/p_counter_collection.csv > profiles/${tag}_pmc_from_reset.txt
+    python3 tools/pmc_summary.py --only tick_kernel,step_kernel $d/reset*/p_counter_collection.csv > profiles/${tag}_pmc_from_reset.txt
     cp profiles/${tag}_lab_kernel_stats.csv profiles/${tag}_final_kernel_stats.csv
     cp profiles/${tag}_lab_pmc_summary.txt profiles/${tag}_final_pmc_summary.txt
-    python3 tools/make_traffic_json.py $tag --burn-in $bi > /dev/null
+    python3 tools/make_traffic_json.py $tag --kernel $k1 --burn-in $bi > /dev/null
     cp profiles/${tag}_lab_bench_under_rocprof.json profiles/${tag}_final_bench_under_rocprof.json
   fi
   echo "$sh done" >> $out/progress.txt

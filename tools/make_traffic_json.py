@@ -40,12 +40,12 @@ def counters(path, kernel):
 
 
 val = counters(summary, a.kernel)
-from_reset = counters(reset_file, a.kernel) if (a.kernel == "tick_kernel" and not a.shape and reset_file.exists()) else None
+from_reset = counters(reset_file, a.kernel) if (a.kernel != "rollout_kernel" and not a.shape and reset_file.exists()) else None
 waves, T = val["SQ_WAVES"], a.ticks_per_launch
 hbm = lambda v: int(round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024))
 per_step = waves * T          # one wave per env slot: wave-instructions per env-step = counter / (waves x ticks per launch)
-regime = ("running batch (the last 25 tick_kernel launches of `bench.py --steps 20 --warmup 5`, after its burn-in ticks (mid-episode): the "
-          "launches the bench line times)" if a.kernel == "tick_kernel" else
+regime = (f"running batch (the last 25 {a.kernel} launches of `bench.py --steps 20 --warmup 5`, after its burn-in ticks (mid-episode): the "
+          "launches the bench line times)" if a.kernel != "rollout_kernel" else
           f"running batch (the last 4 rollout_kernel launches of the same command: {T} ticks per launch, after the one-launch-per-tick region)")
 out = {
     "workload": f"{key['map']} {key['cops']}v{key['thieves']}, {key['envs']} envs, {key['rays']} rays",
