@@ -318,6 +318,16 @@ __device__ __forceinline__ void philox_env(const Params &p, int env, unsigned c1
                (unsigned)(p.seed >> 32), out);
 }
 
+// The same stream for the spawn sampling (rare path): the key in VGPRs, so that its ten round keys are not precomputed as twenty
+// wave-uniform scalars that the surrounding code then has to spill
+__device__ __forceinline__ void philox_env_v(const Params &p, int env, unsigned c1, unsigned c2, unsigned c3, unsigned out[4])
+{
+    unsigned long long gid = (unsigned long long)(p.env_id_offset + env);
+    unsigned k0 = (unsigned)p.seed, k1 = (unsigned)(p.seed >> 32);
+    asm volatile("" : "+v"(k0), "+v"(k1));
+    philox4x32((unsigned)gid, c1, c2, c3 ^ ((unsigned)(gid >> 32) << 24), k0, k1, out);
+}
+
 __device__ __forceinline__ double u53(unsigned a, unsigned b)
 {
     return (double)(((unsigned long long)(a >> 5) << 26) | (unsigned long long)(b >> 6)) * (1.0 / 9007199254740992.0);
@@ -2023,51 +2033,63 @@ __device__ __forceinline__ void spawn_and_reset(const Lds &L, const Params &p, c
 // episode that ends with this tick, and the per-agent ray-fan setup.  Leaves L.flags for the write-back and returns the
 // number of work units to publish (ray-fan units [+ Space.step]).  act_pref: lane i's action when la.actions is set.
 template <class D>
-__device__ __forceinline__ int slot_front(const Lds &L, const Params &p, const LaunchArgs &la, const MapDesc &md, const GridDesc &gd,
+__device__ __forceinline__ int slot_front(const Lds &L, ParamsK pk, const LaunchArgs &la, const MapDesc &md, const GridDesc &gd,
                                           int env, int lane, int act_pref, unsigned long long synth_tick, PhaseClock &pc)
 {
-    const int S = md.S, A = D::A(p);
-    const int nchunks = fan_units<D>(p);
-    const int step = uni(L.cnt[0]) + 1;                                 // :372
-    const int captured = termination_captured<D>(L, p, S, lane);           // :378
-    const int timeout = (!captured && step >= p.max_step) ? 1 : 0;
-    copy_snapshot(L, A, lane);
-
-    // Entity._perform_action (entity.py:126-134), lane = agent.  (As a wave-uniform loop over the agents -- the
-    // synthetic-action Philox rounds and the sqrt/divide chain of each agent one after the other, on the scalar
-    // unit -- this was 6 us of the tick, in the part of the kernel every wave of the launch executes in step.)
-    if (lane < A) {
-        const int i = lane;
-        const double m_inv = 1.0 / p.mass;
-        int act;
-        if (la.actions) act = act_pref;
-        else { unsigned rnd[4]; philox_env(p, env, (unsigned)synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
-        if ((unsigned)act > 3u) atomicOr(p.err_word, CAT_DEVERR_BAD_ACTION);   // applied as "no impulse", and flagged
-        double jx = 0.0, jy = 0.0;
-        if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
-        else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
-        double vx = L.vel[2 * i] + jx * m_inv, vy = L.vel[2 * i + 1] + jy * m_inv;
-        double len = sqrt(vx * vx + vy * vy);
-        if (len > p.max_speed) { vx = vx / len * p.max_speed; vy = vy / len * p.max_speed; }
-        L.vel[2 * i] = vx; L.vel[2 * i + 1] = vy;
-    }
-    wave_sync();
-    PHASE(pc, 2);
-    int n_units = nchunks + 1, rcount = -1, step_store = step;
-    if (la.auto_reset && (captured || timeout)) {
-        // The episode ends with this tick and the caller wants the slot reset in the same call: the terminal
-        // observations would be overwritten by the reset's (the rewards of a terminal tick are constants), so the
-        // slot's ray chunks are those of the NEW episode.  The reset needs the stepped state (stale circle caches
-        // and leaf bbs, quirk Q1), so the owner runs Space.step here instead of queueing it.
-        physics_env<D>(L, p, S, lane, pc);                        // :392
-        rcount = uni(L.cnt[1]) + 1;
-        spawn_and_reset<D>(L, p, la, md, env, (unsigned)rcount, lane);   // base_env.py:286-352
-        wave_sync();
+    // three sub-phases, each from a freshly laundered parameter pointer: what one has loaded does not stay alive through the next
+    // (the rare auto-reset path inlines Space.step and the spawn sampling between the two common ones)
+    int captured, timeout, step;
+    {
+        const Params &p = *(const Params *)launder(pk);
+        const int S = md.S, A = D::A(p);
+        step = uni(L.cnt[0]) + 1;                                           // :372
+        captured = termination_captured<D>(L, p, S, lane);                     // :378
+        timeout = (!captured && step >= p.max_step) ? 1 : 0;
         copy_snapshot(L, A, lane);
-        n_units = nchunks; step_store = 0;
+
+        // Entity._perform_action (entity.py:126-134), lane = agent.  (As a wave-uniform loop over the agents -- the
+        // synthetic-action Philox rounds and the sqrt/divide chain of each agent one after the other, on the scalar
+        // unit -- this was 6 us of the tick, in the part of the kernel every wave of the launch executes in step.)
+        if (lane < A) {
+            const int i = lane;
+            const double m_inv = 1.0 / p.mass;
+            int act;
+            if (la.actions) act = act_pref;
+            else { unsigned rnd[4]; philox_env(p, env, (unsigned)synth_tick, (unsigned)i, 0xAC710u, rnd); act = (int)(rnd[0] & 3u); }
+            if ((unsigned)act > 3u) atomicOr(p.err_word, CAT_DEVERR_BAD_ACTION);   // applied as "no impulse", and flagged
+            double jx = 0.0, jy = 0.0;
+            if (act == 0) jx = -p.impulse; else if (act == 1) jy = p.impulse;
+            else if (act == 2) jx = p.impulse; else if (act == 3) jy = -p.impulse;
+            double vx = L.vel[2 * i] + jx * m_inv, vy = L.vel[2 * i + 1] + jy * m_inv;
+            double len = sqrt(vx * vx + vy * vy);
+            if (len > p.max_speed) { vx = vx / len * p.max_speed; vy = vy / len * p.max_speed; }
+            L.vel[2 * i] = vx; L.vel[2 * i + 1] = vy;
+        }
+        wave_sync();
+        PHASE(pc, 2);
     }
-    agent_setup<D>(L, p, gd, lane);                              // entity.py:143-144, :388-390 (setup part)
-    PHASE(pc, 4);
+    int n_units, rcount = -1, step_store = step;
+    {
+        const Params &p = *(const Params *)launder(pk);
+        n_units = fan_units<D>(p) + 1;
+        if (la.auto_reset && (captured || timeout)) {
+            // The episode ends with this tick and the caller wants the slot reset in the same call: the terminal
+            // observations would be overwritten by the reset's (the rewards of a terminal tick are constants), so the
+            // slot's ray chunks are those of the NEW episode.  The reset needs the stepped state (stale circle caches
+            // and leaf bbs, quirk Q1), so the owner runs Space.step here instead of queueing it.
+            physics_env<D>(L, p, uni(md.S), lane, pc);                // :392
+            rcount = uni(L.cnt[1]) + 1;
+            spawn_and_reset<D>(L, p, la, md, env, (unsigned)rcount, lane);   // base_env.py:286-352
+            wave_sync();
+            copy_snapshot(L, D::A(p), lane);
+            n_units -= 1; step_store = 0;
+        }
+    }
+    {
+        const Params &p = *(const Params *)launder(pk);
+        agent_setup<D>(L, p, gd, lane);                              // entity.py:143-144, :388-390 (setup part)
+        PHASE(pc, 4);
+    }
     if (lane == 0) { L.flags[0] = step_store; L.flags[1] = captured; L.flags[2] = timeout; L.flags[3] = rcount; }
     return n_units;
 }
@@ -2149,7 +2171,7 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
             if (la.actions && lane < D::A(p)) ap = la.actions[((size_t)t * p.N + e_s) * D::A(p) + lane];
             if (lane == 0) ctrl[4 * slot + 1] = 0;
 #ifndef CAT_ABL_NOFRONT
-            const int n2 = slot_front<D>(Ls, p, la, K->md, K->gd, e_s, lane, ap, la.synth_tick + (unsigned long long)t, pc);
+            const int n2 = slot_front<D>(Ls, (ParamsK)pp0, la, K->md, K->gd, e_s, lane, ap, la.synth_tick + (unsigned long long)t, pc);
 #else
             const int n2 = fan_units<D>(p) + 1;
             if (lane == 0) { Ls.flags[0] = 1; Ls.flags[1] = 0; Ls.flags[2] = 0; Ls.flags[3] = -1; }
@@ -2347,13 +2369,13 @@ __device__ __forceinline__ void spawn_and_reset(const Lds &L, const Params &p, c
             if (nr <= 0) { sx = start[2 * i]; sy = start[2 * i + 1]; }      // :323-332 Entity.reset()
             else {
                 unsigned rnd[4];
-                philox_env(p, env, rc, (unsigned)i, 0x100u, rnd);
+                philox_env_v(p, env, rc, (unsigned)i, 0x100u, rnd);
                 GAS const double *rg = regions + 4 * (r0 + (int)(rnd[0] % (unsigned)nr));  // :144-145
                 const double rgx = rg[0], rgy = rg[1], rgw = rg[2], rgh = rg[3];
                 bool ok = false;
                 sx = rgx + rgw / 2; sy = rgy + rgh / 2;                     // :163-166 fallback
                 for (int att = 0; att < 20 && !ok; att++) {                 // :151
-                    philox_env(p, env, rc, (unsigned)i, 0x200u + (unsigned)att, rnd);
+                    philox_env_v(p, env, rc, (unsigned)i, 0x200u + (unsigned)att, rnd);
                     const double x = rgx + ((rgx + rgw) - rgx) * u53(rnd[0], rnd[1]);  // map_utils.py:9-10
                     const double y = rgy + ((rgy + rgh) - rgy) * u53(rnd[2], rnd[3]);
                     // Space.point_query_nearest(pos, radius, ray_filter) is None  (:154-157)
