@@ -164,12 +164,22 @@ template <class D> __device__ __forceinline__ int group_agents(const Params &p)
     const int cpa = (D::R(p) + 63) / 64;
     return cpa <= 2 ? 2 : 1;
 }
-// ray-fan work units of an env slot
-template <class D> __device__ __forceinline__ int fan_units(const Params &p)
+// ... and in the scheduler kernels (step_kernel, rollout_kernel), for rosters whose rays fill more than four chunks: as many agents as fill four (3v2 at 64 rays:
+// units of 4 + 1 agents instead of 2 + 2 + 1).  With T ticks per launch the slots of a workgroup run out of phase and a slot needs
+// less parallelism inside itself; fewer units pay fewer prologues and pack their rounds fuller: 3v2 x8192 79.7 -> 76.8 us per tick.
+// (2v1 in ONE unit: 21.0 us against 20.5 with two, and 24.8 against 22.4 at T = 16: kept at two agents per unit.)
+template <class D> __device__ __forceinline__ int group_agents_resident(const Params &p)
 {
-    if constexpr (D::kFan == 1) { const int g = group_agents<D>(p); return (D::A(p) + g - 1) / g; }
+    const int cpa = (D::R(p) + 63) / 64, most = cpa <= 4 ? 4 / cpa : 1;
+    return D::A(p) * cpa > 4 && most > group_agents<D>(p) ? most : group_agents<D>(p);
+}
+// ray-fan work units of an env slot (gsz: agents per unit of the group form)
+template <class D> __device__ __forceinline__ int fan_units(const Params &p, int gsz)
+{
+    if constexpr (D::kFan == 1) return (D::A(p) + gsz - 1) / gsz;
     else return D::A(p) * ((D::R(p) + 63) / 64);
 }
+template <class D> __device__ __forceinline__ int fan_units(const Params &p) { return fan_units<D>(p, group_agents<D>(p)); }
 
 // Diagnostic build only (-DCAT_PHASE_TIMING): per-phase shader-clock totals, summed over waves
 // into a debug buffer no other kernel code reads.  The shipped library is built without it.
@@ -1032,14 +1042,14 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
 // Requires (cat_create): every candidate list fits a four-byte row (fields of wall id + 1), shape ids S + A fit 6 bits, R <= kGroupRays.
 template <class D>
 __device__ void fan_group(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, long long env, int lane,
-                          int S, float cmax, int rew_mode, int g, PhaseClock &pc)
+                          int S, float cmax, int rew_mode, int g, int gsz, PhaseClock &pc)
 {
     const int A = D::A(p), R = D::R(p);
     const double r2 = p.ray_radius;
     const unsigned d_empty = f64_to_f16(p.ray_length);  // np.full(R, ray_length, float16) entity.py:200
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int cpa = (R + kLanes - 1) / kLanes;   // chunks per agent
-    const int gsz = group_agents<D>(p), i0 = g * gsz, i1 = (i0 + gsz < A) ? i0 + gsz : A;
+    const int i0 = g * gsz, i1 = (i0 + gsz < A) ? i0 + gsz : A;
     const int gate = launder(uni(p.gate)), n_cops = launder(uni(D::n_cops(p)));
     const double wall_r = launder(p.wall_r), rc = launder(p.rc);
     const int my_cell = lane < A ? L.acell[lane] : -1;
@@ -1703,7 +1713,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
     L.itemidx = L.itm + kItemCap;
     L.arow = reinterpret_cast<unsigned *>(u + kFanBytes);
-    const int grays = group_agents<D>(p) * ((D::R(p) + 63) / 64) * 64;   // rays of one agent group: what the arrays are sized for
+    const int grays = 4 * kLanes;   // most rays of one agent group (four chunks): what the arrays are sized for
     L.alist = reinterpret_cast<unsigned char *>(L.arow + grays);
     L.adyn = L.alist + grays;
     return L;
@@ -1977,7 +1987,7 @@ __device__ __forceinline__ void run_units(const Params *pp0, LaunchArgsK lap0, c
             const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
             const int unit = c;
             if (unit < fan_units<D>(p)) {   // entity.py:143-144, base_env.py:388-390 / :334-344
-                if constexpr (D::kFan == 1) fan_group<D>(Ls, p, la, K->gd, e_s, lane, uni(K->md.S), K->md.cmax, tick, unit, pc);
+                if constexpr (D::kFan == 1) fan_group<D>(Ls, p, la, K->gd, e_s, lane, uni(K->md.S), K->md.cmax, tick, unit, group_agents<D>(p), pc);
                 else fan_chunk<D>(Ls, p, la, K->gd, e_s, lane, uni(K->md.S), K->md.cmax, tick, unit, pc);
             }
             else {
@@ -2034,7 +2044,7 @@ __device__ __forceinline__ void spawn_and_reset(const Lds &L, const Params &p, c
 // number of work units to publish (ray-fan units [+ Space.step]).  act_pref: lane i's action when la.actions is set.
 template <class D>
 __device__ __forceinline__ int slot_front(const Lds &L, ParamsK pk, const LaunchArgs &la, const MapDesc &md, const GridDesc &gd,
-                                          int env, int lane, int act_pref, unsigned long long synth_tick, PhaseClock &pc)
+                                          int env, int lane, int act_pref, unsigned long long synth_tick, int n_fan, PhaseClock &pc)
 {
     // three sub-phases, each from a freshly laundered parameter pointer: what one has loaded does not stay alive through the next
     // (the rare auto-reset path inlines Space.step and the spawn sampling between the two common ones)
@@ -2071,7 +2081,7 @@ __device__ __forceinline__ int slot_front(const Lds &L, ParamsK pk, const Launch
     int n_units, rcount = -1, step_store = step;
     {
         const Params &p = *(const Params *)launder(pk);
-        n_units = fan_units<D>(p) + 1;
+        n_units = n_fan + 1;
         if (la.auto_reset && (captured || timeout)) {
             // The episode ends with this tick and the caller wants the slot reset in the same call: the terminal
             // observations would be overwritten by the reset's (the rewards of a terminal tick are constants), so the
@@ -2170,14 +2180,17 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
             int ap = 0;
             if (la.actions && lane < D::A(p)) ap = la.actions[((size_t)t * p.N + e_s) * D::A(p) + lane];
             if (lane == 0) ctrl[4 * slot + 1] = 0;
+            const int n_fan = fan_units<D>(p, group_agents_resident<D>(p));
 #ifndef CAT_ABL_NOFRONT
-            const int n2 = slot_front<D>(Ls, (ParamsK)pp0, la, K->md, K->gd, e_s, lane, ap, la.synth_tick + (unsigned long long)t, pc);
+            const int n2 = slot_front<D>(Ls, (ParamsK)pp0, la, K->md, K->gd, e_s, lane, ap, la.synth_tick + (unsigned long long)t, n_fan, pc);
 #else
-            const int n2 = fan_units<D>(p) + 1;
+            const int n2 = n_fan + 1;
             if (lane == 0) { Ls.flags[0] = 1; Ls.flags[1] = 0; Ls.flags[2] = 0; Ls.flags[3] = -1; }
             (void)ap;
 #endif
             lds_release();
+            // (publishing with unit 0 already claimed for this wave, and re-claiming the slot tick's next unit without a scan, were
+            // built: labyrinth T = 64 26.7 us per tick against 20.5 -- waves then stay on their slots and "help the hindmost" is gone)
             if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], rw_make(t + 1, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             hint = slot;
             PHASE(pc, 3);
@@ -2229,9 +2242,10 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
             const int e_s = uni(ctrl[4 * slot + 3]);
             const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
             const long long eo = (long long)t * p.N + e_s;   // row of the [T, N, ...] output buffers
-            if (unit < fan_units<D>(p)) {
+            const int gsz = group_agents_resident<D>(p);   // also with one tick per launch: 3v2 x8192 98.8 against 100.5 us
+            if (unit < fan_units<D>(p, gsz)) {
 #ifndef CAT_ABL_NOFAN      // diagnostic builds: a phase compiled out, for instruction counts by difference (tools/ablate_rollout.sh)
-                if constexpr (D::kFan == 1) fan_group<D>(Ls, p, la, K->gd, eo, lane, uni(K->md.S), K->md.cmax, 1, unit, pc);
+                if constexpr (D::kFan == 1) fan_group<D>(Ls, p, la, K->gd, eo, lane, uni(K->md.S), K->md.cmax, 1, unit, gsz, pc);
                 else fan_chunk<D>(Ls, p, la, K->gd, eo, lane, uni(K->md.S), K->md.cmax, 1, unit, pc);
 #endif
             } else {
@@ -2841,7 +2855,8 @@ static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool grou
     z.map = up((kBB * maxS + rest) * 8 + 2 * maxS * 4, 16) + 16 * R;
     const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
     const int cpa = (R + 63) / 64;
-    const int fan_bytes = kFanBytes + (group_fan ? (cpa <= 2 ? 2 : 1) * cpa * 64 * (4 + 1 + 1) : 0);   // group_agents() x cpa x 64 rays: arow, alist, adyn
+    const int fan_bytes = kFanBytes + (group_fan ? 4 * 64 * (4 + 1 + 1) : 0);   // four chunks of rays per agent group: arow, alist, adyn
+    (void)cpa;
     z.uni = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 16);
     const int rec_bytes = 96 * A + 16 + ((A * kK + NPs) * 8 + (2 * A * kK + NPs) * 4 + 15) / 16 * 16;
     int eb = rec_bytes + 8 * A * 8;                                // record, spawn/snapshot
