@@ -1838,11 +1838,24 @@ __device__ __forceinline__ void store_state(const Lds &L, const Params &p, int e
 }
 
 #ifdef CAT_WAVE_SPREAD
-__device__ unsigned long long g_wave_t[2 * 65536];   // per env slot: wave start / end clock of the last launch
+// Diagnostic build only (-DCAT_WAVE_SPREAD, tools/wave_spread.py): the timeline of the last step_kernel launch on the 100 MHz realtime counter (one
+// domain for the whole device).  g_wave_t, per wave: start, after the staging barrier, own front published, scheduler exit; shader clock at
+// start / exit.  g_slot_t, per env slot: front start, publish, unit u start / end (2 + 2u, 3 + 2u; u < 5), write-back start / end (12, 13).
+__device__ unsigned long long g_wave_t[8 * 65536];
+__device__ unsigned long long g_slot_t[16 * 65536];
 extern "C" int cat_debug_spread(unsigned long long *out, int n)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_t), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_t), sizeof(unsigned long long) * 8 * n) == hipSuccess ? 0 : -1;
 }
+extern "C" int cat_debug_slot_times(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slot_t), sizeof(unsigned long long) * 16 * n) == hipSuccess ? 0 : -1;
+}
+#define SSPREAD(slot_, i) do { if (kOneTick && lane0 == 0 && (i) < 14) g_slot_t[16 * (blockIdx.x * (blockDim.x / kLanes) + (slot_)) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define WSPREAD(i) do { if (kOneTick && lane0 == 0) g_wave_t[8 * (blockIdx.x * (blockDim.x / kLanes) + wave) + (i)] = (i) < 4 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); } while (0)
+#else
+#define WSPREAD(i) do {} while (0)
+#define SSPREAD(slot_, i) do {} while (0)
 #endif
 // Workgroup control words (LDS, L.ctrl): lane 0 operates, the result is broadcast.  Relaxed accesses; the
 // callers place the workgroup-scope release / acquire fences where data is handed over.
@@ -2138,6 +2151,7 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
     const int wave = uni(threadIdx.x / kLanes);
     const LaunchArgsK lap0 = kernarg_launch_args();
     PhaseClock pc;
+    WSPREAD(0); WSPREAD(4);
     int env, T, W;
     GAS const float *lut_c, *lut_t;
     {   // ---- prologue: descriptors -> LDS, control words, state record -> LDS, map staging
@@ -2157,6 +2171,7 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
         fetch_state<D>(sregs, q, env, lane);
         stage_map<D>(q, smem, md0, &bd0, const_cast<BlockDesc *>(block_desc_lds(smem, q, W)));   // ends with the workgroup barrier
         PHASE(pc, 0);
+        WSPREAD(1);
         if (env >= 0) {
             const Lds L = carve<D>(q, smem, md0, wave, wave);
             commit_state<D>(L, sregs, q, lane);
@@ -2175,6 +2190,7 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
             const BlockDesc *const K = block_desc_lds(smem, p, W);   // the workgroup's descriptors, in LDS
             const int slot = pend, t = pend_t;
             pend = -1;
+            SSPREAD(slot, 0);
             const int e_s = uni(ctrl[4 * slot + 3]);
             const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
             int ap = 0;
@@ -2194,6 +2210,7 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
             if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], rw_make(t + 1, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             hint = slot;
             PHASE(pc, 3);
+            WSPREAD(2); SSPREAD(slot, 1);
         }
         int slot, unit, n_units, t;
         {   // ---- look for an open unit and claim it
@@ -2243,6 +2260,7 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
             const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
             const long long eo = (long long)t * p.N + e_s;   // row of the [T, N, ...] output buffers
             const int gsz = group_agents_resident<D>(p);   // also with one tick per launch: 3v2 x8192 98.8 against 100.5 us
+            SSPREAD(slot, 2 + 2 * unit);
             if (unit < fan_units<D>(p, gsz)) {
 #ifndef CAT_ABL_NOFAN      // diagnostic builds: a phase compiled out, for instruction counts by difference (tools/ablate_rollout.sh)
                 if constexpr (D::kFan == 1) fan_group<D>(Ls, p, la, K->gd, eo, lane, uni(K->md.S), K->md.cmax, 1, unit, gsz, pc);
@@ -2256,6 +2274,7 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
                 PHASE(pc, 10);
             }
             lds_release();   // the unit's LDS writes, before it counts as done
+            SSPREAD(slot, 3 + 2 * unit);
             int d = 0;
             if (lane == 0) d = __hip_atomic_fetch_add(&ctrl[4 * slot + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             fin = uni(d) == n_units - 1;
@@ -2270,6 +2289,7 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
             const BlockDesc *const K = block_desc_lds(smem, p, W);
             lds_acquire();
             PHASE(pc, 16);
+            SSPREAD(slot, 12);
             const int e_s = uni(ctrl[4 * slot + 3]);
             const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
             const long long eo = (long long)t * p.N + e_s;
@@ -2281,11 +2301,13 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
             (void)eo; (void)step2; (void)captured2; (void)timeout2; (void)rcount; (void)la;
 #endif
             wave_sync();   // the write-back has read the slot's staging and flags; the next front overwrites them
+            SSPREAD(slot, 13);
             if (!last) { pend = slot; pend_t = t + 1; }
             else if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], kRwFinished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     PHASE(pc, 11);
+    WSPREAD(3); WSPREAD(5);
     pc.flush(lane0);
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase shader-cycle shares of rollout_kernel (a -DCAT_PHASE_TIMING build, CAT_TIMING_LIB=...; never the shipped
-library).  usage: CAT_TIMING_LIB=build/var/timing.so python tools/rollout_phase.py [map] [envs] [T]"""
+library).  usage: CAT_TIMING_LIB=build/var/timing.so python tools/rollout_phase.py [map] [envs] [T]   (T = 0: step_kernel, one tick per launch)"""
 import ctypes as C, os, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -23,8 +23,13 @@ L.cat_debug_phase_cycles(buf, 1)
 reps = 4
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for r in range(reps):
-    sim.rollout_fused(T, None, tick=600 + r * T, auto_reset=True)
+if T == 0:   # T = 0: the one-tick path (step_kernel through cat_step_fused), 64 launches
+    T = 64; reps = 1
+    for r in range(T):
+        sim.step_fused(None, tick=600 + r, auto_reset=True)
+else:
+    for r in range(reps):
+        sim.rollout_fused(T, None, tick=600 + r * T, auto_reset=True)
 e1.record(); torch.cuda.synchronize()
 L.cat_debug_phase_cycles(buf, 1)
 names = {0: "prologue: stage_map", 1: "prologue: state -> LDS", 2: "front: termination + actions", 4: "front: agent setup", 3: "front: publish",
