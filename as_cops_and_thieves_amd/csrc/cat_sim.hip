@@ -231,6 +231,26 @@ struct LaunchArgs {
     int T;                          // rollout_kernel: ticks per launch (outputs and actions carry a leading T)
 };
 
+// What a kernel's prologue needs of the parameter block (env id, descriptors, state record, map staging, LDS carve), as a THIRD
+// kernel argument by value: it then arrives with the kernarg segment's first scalar loads instead of behind two more dependent round
+// trips (kernarg -> Params pointer -> Params fields -> work list / descriptor -> geometry: the staging barrier stood 2.4 us after a
+// wave's start, 0.64 of them for the parameter fields and 0.68 for env id + descriptor; tools/wave_spread.py).  `uniform`: every
+// workgroup of the sim has the same map and the work list is the identity (one map, no helper waves): env id and descriptor then need
+// no load at all (bd).  Filled once by cat_create.
+struct Prologue {
+    int lds_map_bytes, lds_env_bytes, lds_union_bytes, wpb, A, R, NP, maxc, n_cops, rec_bytes, hot_bytes, N;
+    int uniform, pad0;
+    const int *work_env;
+    const BlockDesc *block_desc;
+    char *state;
+    const double *geo_f64;
+    const int *geo_i32;
+    const double *ray_dx, *ray_dy;
+    const float *cop_lut, *thief_lut;
+    BlockDesc bd;
+};
+static_assert(sizeof(LaunchArgs) % 8 == 0 && alignof(Prologue) == 8, "kernarg layout: [const Params *][LaunchArgs][Prologue]");
+
 // ------------------------------------------------------------------ small helpers -----------
 // Pointers read out of the Params block are generic to the compiler, which then emits FLAT accesses:
 // those count on vmcnt AND lgkmcnt, so every LDS wait also drains them (no prefetch survives).  An
@@ -1852,7 +1872,7 @@ extern "C" int cat_debug_slot_times(unsigned long long *out, int n)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slot_t), sizeof(unsigned long long) * 16 * n) == hipSuccess ? 0 : -1;
 }
 #define SSPREAD(slot_, i) do { if (kOneTick && lane0 == 0 && (i) < 14) g_slot_t[16 * (blockIdx.x * (blockDim.x / kLanes) + (slot_)) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define WSPREAD(i) do { if (kOneTick && lane0 == 0) g_wave_t[8 * (blockIdx.x * (blockDim.x / kLanes) + wave) + (i)] = (i) < 4 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); } while (0)
+#define WSPREAD(i) do { if (kOneTick && lane0 == 0) g_wave_t[8 * (blockIdx.x * (blockDim.x / kLanes) + wave) + (i)] = ((i) < 4 || (i) > 5) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); } while (0)
 #else
 #define WSPREAD(i) do {} while (0)
 #define SSPREAD(slot_, i) do {} while (0)
@@ -1933,19 +1953,46 @@ __device__ __forceinline__ const BlockDesc *block_desc_lds(char *smem, const Par
 // (measured: + 1 600 cycles in front of the map staging).  The copy lives in registers only (every field access is resolved at
 // compile time); fields that are not listed here must not be read through it.  (Pinning the WHOLE block, so that the serial front
 // after the barrier reads registers too, was built: 75 spilled SGPRs in the one-tick kernel.)
-__device__ __forceinline__ Params prologue_params(ParamsK pk)
+typedef const Prologue __attribute__((address_space(4))) *PrologueK;
+__device__ __forceinline__ PrologueK kernarg_prologue()
+{
+    return (PrologueK)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8 + sizeof(LaunchArgs));
+}
+__device__ __forceinline__ Params prologue_params(PrologueK pk, int &uniform)
 {
     Params q;
     q.lds_map_bytes = pk->lds_map_bytes; q.lds_env_bytes = pk->lds_env_bytes; q.lds_union_bytes = pk->lds_union_bytes; q.wpb = pk->wpb;
     q.A = pk->A; q.R = pk->R; q.NP = pk->NP; q.maxc = pk->maxc; q.n_cops = pk->n_cops; q.rec_bytes = pk->rec_bytes; q.hot_bytes = pk->hot_bytes;
+    q.N = pk->N; uniform = pk->uniform;
     q.work_env = pk->work_env; q.block_desc = pk->block_desc; q.state = pk->state;
     q.geo_f64 = pk->geo_f64; q.geo_i32 = pk->geo_i32; q.ray_dx = pk->ray_dx; q.ray_dy = pk->ray_dy;
     q.cop_lut = pk->cop_lut; q.thief_lut = pk->thief_lut;
     // ONE pin for all of them: the loads above are issued together and waited for once
     asm volatile("" : "+s"(q.lds_map_bytes), "+s"(q.lds_env_bytes), "+s"(q.lds_union_bytes), "+s"(q.wpb), "+s"(q.A), "+s"(q.R), "+s"(q.NP),
-                      "+s"(q.maxc), "+s"(q.n_cops), "+s"(q.rec_bytes), "+s"(q.hot_bytes), "+s"(q.work_env), "+s"(q.block_desc), "+s"(q.state),
+                      "+s"(q.maxc), "+s"(q.n_cops), "+s"(q.rec_bytes), "+s"(q.hot_bytes), "+s"(q.N), "+s"(uniform), "+s"(q.work_env), "+s"(q.block_desc), "+s"(q.state),
                       "+s"(q.geo_f64), "+s"(q.geo_i32), "+s"(q.ray_dx), "+s"(q.ray_dy), "+s"(q.cop_lut), "+s"(q.thief_lut));
     return q;
+}
+// member by member (a struct copy would go through the stack)
+__device__ __forceinline__ void copy_desc(BlockDesc &d, const BlockDesc &s)
+{
+    d.md.S = s.md.S; d.md.P = s.md.P; d.md.A = s.md.A; d.md.n_regions = s.md.n_regions; d.md.f64_off = s.md.f64_off; d.md.i32_off = s.md.i32_off;
+    d.md.cmax = s.md.cmax; d.md.PP = s.md.PP;
+    d.gd.x0 = s.gd.x0; d.gd.y0 = s.gd.y0; d.gd.inv_cell = s.gd.inv_cell; d.gd.nx = s.gd.nx; d.gd.ny = s.gd.ny; d.gd.off_base = s.gd.off_base;
+    d.gd.ent_base = s.gd.ent_base; d.gd.coff_base = s.gd.coff_base; d.gd.cent_base = s.gd.cent_base; d.gd.crow_base = s.gd.crow_base; d.gd.pad2 = s.gd.pad2;
+    d.gd.row_base = s.gd.row_base; d.gd.pad1 = s.gd.pad1;
+}
+// The workgroup's env id (wave's slot) and descriptor: computed / read from the kernarg copy where the sim is uniform, else loaded.
+// The descriptor's vector load from the kernarg segment is issued at once: it depends on nothing that is loaded.
+__device__ __forceinline__ void prologue_env_desc(const Params &q, int uniform, int W, int wave, int &env, BlockDesc &bd0)
+{
+    copy_desc(bd0, *(const BlockDesc *)(const void *)&kernarg_prologue()->bd);
+    const int e = blockIdx.x * W + wave;
+    env = e < q.N ? e : -1;
+    if (!uniform) {
+        env = uni(q.work_env[e]);
+        copy_desc(bd0, q.block_desc[blockIdx.x]);
+    }
 }
 
 // The shared part of both kernels.  Units of a published slot, claimed in order by any wave of the workgroup:
@@ -2155,16 +2202,21 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
     int env, T, W;
     GAS const float *lut_c, *lut_t;
     {   // ---- prologue: descriptors -> LDS, control words, state record -> LDS, map staging
-        const Params q = prologue_params((ParamsK)pp0);        // the pre-barrier part reads this register copy
+        int uniform;
+        const Params q = prologue_params(kernarg_prologue(), uniform);   // the pre-barrier part reads this register copy
         const Params &p = *(const Params *)(ParamsK)pp0;
         lut_c = G(q.cop_lut); lut_t = G(q.thief_lut);          // four scalars kept for the write-backs: the reward lookup is then one round trip
         const int lane = lane0;
         W = uni((int)(blockDim.x / kLanes));
         T = kOneTick ? 1 : la0.T;
-        env = uni(q.work_env[blockIdx.x * W + wave]);
+        WSPREAD(6);   // the parameter burst has arrived
         int *const ctrl = reinterpret_cast<int *>(smem + q.lds_map_bytes);
-        const BlockDesc bd0 = q.block_desc[blockIdx.x];
+        BlockDesc bd0;
+        prologue_env_desc(q, uniform, W, wave, env, bd0);
         const MapDesc &md0 = bd0.md;
+#ifdef CAT_WAVE_SPREAD
+        { int e_ = env, s_ = md0.S; asm volatile("" : "+s"(e_), "+v"(s_)); WSPREAD(7); }   // env id and descriptor have arrived
+#endif
         // control words of slot `wave`: claim word (above), units done in this epoch, -, env id
         if (lane < 4) ctrl[4 * wave + lane] = lane == 3 ? env : ((lane == 0 && env < 0) ? (int)kRwFinished : 0);
         StateRegs sregs;
@@ -2312,7 +2364,7 @@ __device__ __forceinline__ void rollout_body(const Params *__restrict__ pp0, con
 }
 
 template <class D>
-__global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params *__restrict__ pp0, const LaunchArgs la0)
+__global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params *__restrict__ pp0, const LaunchArgs la0, const Prologue)
 {
     rollout_body<D, false>(pp0, la0);
 }
@@ -2324,7 +2376,7 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel(const Params
 // 64.7, 3v2 x8192 101.4 / 101.5, five maps x16384 173.8 / 169.8, 90 rays 41.8 / 41.1; the round-3 binary: 31.9 / 64.9 / 100.4 / 171.7 /
 // 41.6) and was removed.
 template <class D>
-__global__ __launch_bounds__(kMaxWaves *kLanes) void step_kernel(const Params *__restrict__ pp0, const LaunchArgs la0)
+__global__ __launch_bounds__(kMaxWaves *kLanes) void step_kernel(const Params *__restrict__ pp0, const LaunchArgs la0, const Prologue)
 {
     rollout_body<D, true>(pp0, la0);
 }
@@ -2335,7 +2387,7 @@ __device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const 
 
 // BaseEnv.reset (base_env.py:286-352) for masked envs
 template <class D>
-__global__ __launch_bounds__(kMaxWaves *kLanes) void reset_kernel(const Params *__restrict__ pp0, const LaunchArgs la0)
+__global__ __launch_bounds__(kMaxWaves *kLanes) void reset_kernel(const Params *__restrict__ pp0, const LaunchArgs la0, const Prologue)
 {
     extern __shared__ __align__(16) char smem[];
     const int lane0 = threadIdx.x % kLanes;
@@ -2345,22 +2397,25 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void reset_kernel(const Params *
     int W;
     {
         const Params &p = *pp0;
+        int uniform;
+        const Params q = prologue_params(kernarg_prologue(), uniform);   // what comes before the barrier reads this register copy
         const int lane = lane0;
         W = uni((int)(blockDim.x / kLanes));
-        const int env = uni(p.work_env[blockIdx.x * W + wave]);
+        int env;
+        BlockDesc bd0;
+        prologue_env_desc(q, uniform, W, wave, env, bd0);
         bool need = env >= 0;
         if (need) {
             if (la0.use_done_mask)
-                need = ((GAS const int *)(G(p.state) + (size_t)env * D::rec_bytes(p) + 96 * D::A(p)))[2] != 0;   // the hot part's `done`
+                need = ((GAS const int *)(G(q.state) + (size_t)env * D::rec_bytes(q) + 96 * D::A(q)))[2] != 0;   // the hot part's `done`
             else if (la0.mask) need = la0.mask[env] != 0;
         }
         if (!__syncthreads_or(need ? 1 : 0)) return;  // nothing to reset in this workgroup: skip the map staging
-        const BlockDesc bd0 = p.block_desc[blockIdx.x];
         const MapDesc &md0 = bd0.md;
         const GridDesc &gd0 = bd0.gd;
-        int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+        int *const ctrl = reinterpret_cast<int *>(smem + q.lds_map_bytes);
         if (lane < 4) ctrl[4 * wave + lane] = lane == 3 ? (need ? env : -1) : 0;   // claimed, done, published, env id
-        stage_map<D>(p, smem, md0, &bd0, const_cast<BlockDesc *>(block_desc_lds(smem, p, W)));   // ends with the workgroup barrier
+        stage_map<D>(q, smem, md0, &bd0, const_cast<BlockDesc *>(block_desc_lds(smem, q, W)));   // ends with the workgroup barrier
         if (need) {
             const Lds L = carve<D>(p, smem, md0, wave, wave);
             reset_slot<D>(L, p, la0, md0, gd0, env, wave, lane);
@@ -2843,7 +2898,7 @@ static void finalize_rows(GridHost &g, int id_bits = 0, bool wide = false)
 
 // Kernel instantiations: fixed dimensions for the rosters / ray counts of the BASELINE configurations and of the
 // reference's defaults, the generic one for everything else (CAT_GENERIC_KERNEL=1 forces it: A/B tests).
-using KernelFn = void (*)(const Params *, const LaunchArgs);
+using KernelFn = void (*)(const Params *, const LaunchArgs, const Prologue);
 template <class D> static void kernels_of(int fan, KernelFn &reset, KernelFn &rollout, KernelFn &step)
 {
     if (fan == 1) { reset = reset_kernel<WithFan<D, 1>>; rollout = rollout_kernel<WithFan<D, 1>>; step = step_kernel<WithFan<D, 1>>; }
@@ -2894,6 +2949,7 @@ struct cat_sim {
     Params *dev_p;
     int device;
     int n_blocks, wpb;
+    Prologue pro;
     KernelFn reset_fn = nullptr, rollout_fn = nullptr, step_fn = nullptr;   // the instantiations matching (agents, rays, cops): cat_reset*, cat_rollout_fused, cat_step*
     const char *kernel_variant = "";
     hipEvent_t t_start = nullptr, t_stop = nullptr;   // cat_arm_kernel_timing
@@ -3266,6 +3322,19 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         if (rc != CAT_OK) return fail(rc);
         s->dev_p = dp;
     }
+    {   // the prologue's copy (third kernel argument)
+        Prologue &q = s->pro;
+        memset(&q, 0, sizeof q);
+        q.lds_map_bytes = p.lds_map_bytes; q.lds_env_bytes = p.lds_env_bytes; q.lds_union_bytes = p.lds_union_bytes; q.wpb = p.wpb;
+        q.A = p.A; q.R = p.R; q.NP = p.NP; q.maxc = p.maxc; q.n_cops = p.n_cops; q.rec_bytes = p.rec_bytes; q.hot_bytes = p.hot_bytes; q.N = p.N;
+        q.work_env = p.work_env; q.block_desc = p.block_desc; q.state = p.state; q.geo_f64 = p.geo_f64; q.geo_i32 = p.geo_i32;
+        q.ray_dx = p.ray_dx; q.ray_dy = p.ray_dy; q.cop_lut = p.cop_lut; q.thief_lut = p.thief_lut;
+        bool ident = n_maps == 1 && (int)work.size() == s->n_blocks * wpb;
+        for (size_t k = 0; ident && k < work.size(); k++) ident = work[k] == ((int)k < N ? (int)k : -1);
+        q.uniform = ident ? 1 : 0;
+        q.bd.md = descs[block_map[0]];
+        q.bd.gd = s->grid.desc.empty() ? GridDesc{} : s->grid.desc[block_map[0]];
+    }
     *out = s;
     return CAT_OK;
 }
@@ -3289,7 +3358,7 @@ static int launch_reset(cat_sim *s, const uint8_t *mask, const double *positions
     if (out) la.out = *out;
     la.mask = mask; la.positions = positions; la.use_done_mask = use_done;
     hipLaunchKernelGGL(s->reset_fn, dim3(s->n_blocks), dim3(s->wpb * kLanes), s->lds_bytes,
-                       static_cast<hipStream_t>(stream), s->dev_p, la);
+                       static_cast<hipStream_t>(stream), s->dev_p, la, s->pro);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -3312,10 +3381,10 @@ static void launch_tick(cat_sim *s, const LaunchArgs &la, void *stream, KernelFn
     if (!fn) fn = s->step_fn;
     if (s->t_start && s->t_stop) {
         hipExtLaunchKernelGGL(fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->t_start, s->t_stop, 0,
-                              s->dev_p, la);
+                              s->dev_p, la, s->pro);
         s->t_start = s->t_stop = nullptr;
     } else {
-        hipLaunchKernelGGL(fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->dev_p, la);
+        hipLaunchKernelGGL(fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->dev_p, la, s->pro);
     }
 }
 

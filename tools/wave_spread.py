@@ -40,6 +40,9 @@ for rep in range(3):
     for i, nm in enumerate(("wave start", "after the staging barrier", "own front published", "scheduler exit")):
         v = rt[:, i]
         print(f"  {nm:28s} min {v.min():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  p99 {np.percentile(v, 99):6.2f}  max {v.max():6.2f} us")
+    for i, nm in ((6, "parameter burst arrived"), (7, "env id + descriptor arrived")):
+        v = (t[:, i] - t[:, 0].min()) * 0.01
+        print(f"  {nm:28s} min {v.min():6.2f}  p10 {np.percentile(v, 10):6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  p99 {np.percentile(v, 99):6.2f}  max {v.max():6.2f} us;  after the wave's own start: median {np.median((t[:, i] - t[:, 0]) * 0.01):.2f}")
     dur = t[:, 5] - t[:, 4]
     print(f"  wave lifetime (shader clock)  min {dur.min()}  median {int(np.median(dur))}  p90 {int(np.percentile(dur, 90))}  max {dur.max()} cycles;  {np.median(dur) / max(np.median(rt[:, 3] - rt[:, 0]), 1e-9) / 1e3:.2f} GHz")
     W = 16
