@@ -22,7 +22,7 @@ OUT_FIELDS = ("obs_distance", "obs_type", "hit_shape", "shared_distance", "share
 STATE_FIELDS = ("pos", "vel", "vbias", "tc", "leaf_bb", "wall_shape", "wall_age", "wall_jn",
                 "pair_age", "pair_jn", "step_count", "reset_count")
 WALL_CACHE = 8
-DEVERR_BAD_ACTION, DEVERR_CONTACT_DROPPED = 1, 2
+DEVERR_BAD_ACTION, DEVERR_CONTACT_DROPPED, DEVERR_SCHEDULER = 1, 2, 4
 
 ERRORS = {-1: "CAT_ERR_BAD_CONFIG", -2: "CAT_ERR_BAD_MAP", -3: "CAT_ERR_BAD_SLOT_MAP",
           -4: "CAT_ERR_NO_DEVICE", -5: "CAT_ERR_HIP", -6: "CAT_ERR_BAD_ARG"}

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <type_traits>
 #include <sched.h>
 #include <vector>
 
@@ -122,6 +123,8 @@ struct Params {
     // LDS carve (bytes)
     int lds_map_bytes, lds_env_bytes, lds_union_bytes;
     int wpb;                // waves per workgroup (= blockDim.x / 64)
+    int lds_pool_off, pool_mask;   // ray pool of the *_pool kernels: byte offset in LDS, capacity - 1 (a power of two >= wpb * A * R); 0: no pool
+    int grp_rays;           // rays the arow / alist / adyn arrays of a scratch union hold (fan_group)
 };
 
 // Problem dimensions as seen by the device code: either read from the parameter block (DynDims) or compile-time
@@ -239,7 +242,7 @@ struct LaunchArgs {
 // no load at all (bd).  Filled once by cat_create.
 struct Prologue {
     int lds_map_bytes, lds_env_bytes, lds_union_bytes, wpb, A, R, NP, maxc, n_cops, rec_bytes, hot_bytes, N;
-    int uniform, pad0;
+    int uniform, lds_pool_off, pool_mask, grp_rays;
     const int *work_env;
     const BlockDesc *block_desc;
     char *state;
@@ -1733,7 +1736,7 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
     L.itemidx = L.itm + kItemCap;
     L.arow = reinterpret_cast<unsigned *>(u + kFanBytes);
-    const int grays = 4 * kLanes;   // most rays of one agent group (four chunks): what the arrays are sized for
+    const int grays = p.grp_rays;   // most rays of one agent group (four chunks, fewer where the workgroup's ray pool needs the LDS): what the arrays are sized for
     L.alist = reinterpret_cast<unsigned char *>(L.arow + grays);
     L.adyn = L.alist + grays;
     return L;
@@ -1963,13 +1966,13 @@ __device__ __forceinline__ Params prologue_params(PrologueK pk, int &uniform)
     Params q;
     q.lds_map_bytes = pk->lds_map_bytes; q.lds_env_bytes = pk->lds_env_bytes; q.lds_union_bytes = pk->lds_union_bytes; q.wpb = pk->wpb;
     q.A = pk->A; q.R = pk->R; q.NP = pk->NP; q.maxc = pk->maxc; q.n_cops = pk->n_cops; q.rec_bytes = pk->rec_bytes; q.hot_bytes = pk->hot_bytes;
-    q.N = pk->N; uniform = pk->uniform;
+    q.N = pk->N; uniform = pk->uniform; q.lds_pool_off = pk->lds_pool_off; q.pool_mask = pk->pool_mask; q.grp_rays = pk->grp_rays;
     q.work_env = pk->work_env; q.block_desc = pk->block_desc; q.state = pk->state;
     q.geo_f64 = pk->geo_f64; q.geo_i32 = pk->geo_i32; q.ray_dx = pk->ray_dx; q.ray_dy = pk->ray_dy;
     q.cop_lut = pk->cop_lut; q.thief_lut = pk->thief_lut;
     // ONE pin for all of them: the loads above are issued together and waited for once
     asm volatile("" : "+s"(q.lds_map_bytes), "+s"(q.lds_env_bytes), "+s"(q.lds_union_bytes), "+s"(q.wpb), "+s"(q.A), "+s"(q.R), "+s"(q.NP),
-                      "+s"(q.maxc), "+s"(q.n_cops), "+s"(q.rec_bytes), "+s"(q.hot_bytes), "+s"(q.N), "+s"(uniform), "+s"(q.work_env), "+s"(q.block_desc), "+s"(q.state),
+                      "+s"(q.maxc), "+s"(q.n_cops), "+s"(q.rec_bytes), "+s"(q.hot_bytes), "+s"(q.N), "+s"(uniform), "+s"(q.lds_pool_off), "+s"(q.pool_mask), "+s"(q.grp_rays), "+s"(q.work_env), "+s"(q.block_desc), "+s"(q.state),
                       "+s"(q.geo_f64), "+s"(q.geo_i32), "+s"(q.ray_dx), "+s"(q.ray_dy), "+s"(q.cop_lut), "+s"(q.thief_lut));
     return q;
 }
@@ -2379,6 +2382,456 @@ template <class D>
 __global__ __launch_bounds__(kMaxWaves *kLanes) void step_kernel(const Params *__restrict__ pp0, const LaunchArgs la0, const Prologue)
 {
     rollout_body<D, true>(pp0, la0);
+}
+
+// ------------------------------------------------------------------ pooled ray fan -----------
+template <class T> __device__ __forceinline__ T *slot_ptr(T *p0, int sl, int envb) { return (T *)((char *)const_cast<typename std::remove_const<T>::type *>(p0) + sl * envb); }
+// step_kernel_pooled / rollout_kernel_pooled (light maps whose rays fit the pool: wpb * A * R <= 4096).  In the unit form above a slot's
+// fan runs as rounds of ITS OWN active rays -- the labyrinth's two units hold 52 and 26 rays: rounds cost the same at 26 lanes as at
+// 64 (tools/wave_spread.py: the thief's fan 5.4 us, the two cops' 6.8).  Here a slot's front sorts its rays itself (pool_sort: a ray with
+// no candidate gets EMPTY at once, the others become 8-byte entries -- row word | slot, agent, ray, cone mask -- of ONE ring of LDS per
+// workgroup), and any wave takes the next 64 entries whatever slots they come from (pool_round: the round body of fan_group with the
+// slot per lane).  The per-ray arithmetic is fan_group's, so the results are bit-identical.  A slot's tick is complete when its
+// A * R rays and its Space.step have been counted (ctrl word 1); the wave that counts the last writes it back.
+constexpr unsigned kPoolValid = 0x80000000u;
+constexpr double kPoolEmptyRows = 0.25;   // cat_create: the pooled kernels serve a sim whose candidate table has at least this share of empty rows
+#ifndef CAT_POOL_ROUND
+#define CAT_POOL_ROUND 60
+#endif
+#ifndef CAT_POOL_MIN_PARTIAL
+#define CAT_POOL_MIN_PARTIAL 40
+#endif
+#ifndef CAT_POOL_PATIENCE
+#define CAT_POOL_PATIENCE 3
+#endif
+constexpr int kPoolRound = CAT_POOL_ROUND;            // rays of a full round
+constexpr int kPoolMinPartial = CAT_POOL_MIN_PARTIAL; // a wave with nothing else to do takes fewer than a full round only from this many on ...
+constexpr int kPoolPatience = CAT_POOL_PATIENCE;      // ... or after this many idle looks (fronts under way will add to the ring; the end of a launch drains it)
+constexpr int kSpinLimit = 1 << 22;   // a ring entry that never arrives / a lost wake-up: leave with CAT_DEVERR_SCHEDULER instead of hanging the device
+__device__ __forceinline__ int *pool_ctl(char *smem, const Params &p, int W) { return reinterpret_cast<int *>(smem + p.lds_map_bytes + 16 * W + kWgConstBytes - 8); }   // head, tail
+static_assert(sizeof(BlockDesc) <= kWgConstBytes - 8, "the pool counters live behind the BlockDesc");
+
+// The rays of one slot (its front just ran agent_setup): EMPTY observations for the candidate-less ones, ring entries for the others.
+// Returns the number of rays resolved here.  env: the slot's row of the output buffers (hit_shape only).
+template <class D>
+__device__ __forceinline__ int pool_sort(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, long long env, int slot, int lane,
+                                         int *pctl, unsigned long long *pool)
+{
+    const int A = D::A(p), R = D::R(p);
+    const unsigned d_empty = f64_to_f16(p.ray_length);  // np.full(R, ray_length, float16) entity.py:200
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int cpa = (R + kLanes - 1) / kLanes, nch = A * cpa;
+    const int my_cell = lane < A ? L.acell[lane] : -1;
+    const int my_dk0 = lane < A * A ? L.dk0[lane] : 0, my_dcnt = lane < A * A ? L.dcnt[lane] : 0;
+    const int pmask = p.pool_mask;
+    int n_res = 0;
+    for (int c0 = 0; c0 < nch; c0 += 4) {   // four chunks at a time: their packed rows are requested together
+        unsigned wrow[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (c0 + q < nch) {
+                const int i = (c0 + q) / cpa, k = ((c0 + q) - i * cpa) * kLanes + lane;
+                const int cell = __builtin_amdgcn_readlane(my_cell, i);
+                const size_t r = (cell < 0 || k >= R) ? 0 : (size_t)cell * R + k;
+                wrow[q] = ((GAS const unsigned *)G(p.grid_rows))[gd.row_base + r];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (c0 + q < nch) {
+                const int i = (c0 + q) / cpa, k = ((c0 + q) - i * cpa) * kLanes + lane;
+                const int cell = __builtin_amdgcn_readlane(my_cell, i);
+                const bool in = k < R;
+                const unsigned rowv = (in && cell >= 0) ? wrow[q] : 0u;   // non-zero: the ray has candidate walls
+                unsigned dynmask = 0;
+                if (in)
+                    for (int j = 0; j < A; j++) {
+                        if (j == i) continue;
+                        const int dc = __builtin_amdgcn_readlane(my_dcnt, i * A + j) & 0xFFFF, dk = __builtin_amdgcn_readlane(my_dk0, i * A + j);
+                        int rel = k - dk; if (rel < 0) rel += R;
+                        if (rel < dc) dynmask |= 1u << j;
+                    }
+                const bool act = rowv != 0u || dynmask != 0u;
+                const unsigned long long m = __ballot(act);
+                const int n = __popcll(m);
+                int base = 0;
+                if (n) {
+                    if (lane == 0) base = __hip_atomic_fetch_add(&pctl[1], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    base = uni(base);
+                }
+                if (act) {
+                    const unsigned meta = kPoolValid | ((unsigned)slot << 24) | ((unsigned)i << 16) | (dynmask << 8) | (unsigned)k;
+                    __hip_atomic_store(&pool[(base + __popcll(m & lt_mask)) & pmask], ((unsigned long long)meta << 32) | rowv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (in) {   // nothing along this ray: its observation is final
+                    const int o = i * R + k;
+                    L.od[o] = (unsigned short)d_empty;
+                    L.ot[o] = (unsigned char)CAT_EMPTY;
+                    if (la.out.hit_shape) la.out.hit_shape[(size_t)env * A * R + o] = -1;  // parity/debug only
+                }
+                n_res += __popcll(__ballot(in && !act));
+            }
+        }
+    }
+    return n_res;
+}
+
+// One round: entries [base, base + n) of the ring, n <= 64, lane = entry.  L0: slot 0's view with the calling wave's scratch union.
+// Returns the mask of the slots whose tick this round completed.
+template <class D>
+__device__ __forceinline__ unsigned pool_round(const Lds &L0, const Params &p, const LaunchArgs &la, int S, float cmax, int base, int n, int lane, int *ctrl,
+                               unsigned long long *pool, PhaseClock &pc)
+{
+    const int A = D::A(p), R = D::R(p), envb = p.lds_env_bytes;
+    const double r2 = p.ray_radius;
+    const unsigned d_empty = f64_to_f16(p.ray_length);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int gate = launder(uni(p.gate)), n_cops = launder(uni(D::n_cops(p)));
+    const double wall_r = launder(p.wall_r), rc = launder(p.rc);
+    const int idb = launder(uni(p.row_id_bits)), cmul = launder(uni(p.row_cnt_mul));   // four-byte rows: fields of idb bits = id + 1 (finalize_rows)
+    auto row_count = [&](unsigned w) -> int { return w ? (((31 - __builtin_clz(w)) * cmul) >> 16) + 1 : 0; };
+    bool on = lane < n;
+    unsigned w0 = 0u, meta = 0u;
+    if (on) {   // the entry may still be on its way from the front that reserved it
+        unsigned long long *e = &pool[(base + lane) & p.pool_mask];
+        unsigned long long v = 0ull;
+        int spins = 0;
+        do { v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (!(v >> 63) && ++spins < kSpinLimit);
+        if (!(v >> 63)) { atomicOr(p.err_word, CAT_DEVERR_SCHEDULER); on = false; }
+        __hip_atomic_store(e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        w0 = (unsigned)v; meta = (unsigned)(v >> 32);
+    }
+    lds_acquire();
+    const int s = (int)((meta >> 24) & 15u), i = (int)((meta >> 16) & 7u), k = (int)(meta & 255u);
+    const unsigned dynmask = on ? ((meta >> 8) & 255u) : 0u;
+    if (!on) w0 = 0u;
+    unsigned *const rlist = L0.arow;   // [64] this round's entries (slot, agent, ray), read back by the item stage
+    rlist[lane] = meta;
+    const double *const fpos = slot_ptr(L0.fpos, s, envb), *const ftc = slot_ptr(L0.ftc, s, envb), *const fleaf = slot_ptr(L0.fleaf, s, envb);
+    const double2 org = *reinterpret_cast<const double2 *>(fpos + 2 * i);     // fresh body.position (entity.py:186)
+    const double ax = org.x, ay = org.y;
+    const int cnt_w = row_count(w0);
+    const int cnt = cnt_w + __popc(dynmask);
+    double rdx, rdy, rix, riy;
+    {
+        const double bx = ax + L0.rayd[2 * k], by = ay + L0.rayd[2 * k + 1];  // entity.py:191-193
+        rdx = bx - ax; rdy = by - ay; rix = 1.0 / rdx; riy = 1.0 / rdy;
+    }
+    double best_a = 1.0;
+    int best_fi = -1;   // id << 6 | feature of the accepted item
+    int jj0 = 0;
+    wave_sync();
+    PHASE(pc, 20);
+    while (__ballot(cnt > jj0) != 0ull) {
+        // ---- pack the items (ray, jj) for jj in [jj0, jj1) j-major
+        int n_items = 0, jj = jj0;
+        for (; jj < jj0 + kPassJ; jj++) {
+            const bool has = cnt > jj;
+            if (__ballot(has) == 0ull) break;
+            int id = 0;
+            double tbb = 0.0;
+            if (has) {
+                if (jj < cnt_w) id = (int)((w0 >> (idb * jj)) & ((1u << idb) - 1u)) - 1;      // the row holds the whole list
+                else {
+                    unsigned dj = dynmask;
+                    for (int q = jj - cnt_w; q > 0; q--) dj &= dj - 1;
+                    id = S + __builtin_ctz(dj);
+                }
+                // the BBTree gate value, by the ray's own lane.  A candidate whose t_bb is not below the
+                // ray's best alpha NOW can never be visited (best only decreases): it gets no item.
+                if (gate) tbb = bb_segment_query((id < S) ? (L0.bb + kBB * id) : (fleaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy);
+            }
+            const bool live = has && tbb < best_a;
+            const unsigned long long m = __ballot(live);
+            const int c = __popcll(m);
+            if (n_items + c > kItemCap) break;
+            int t = 0xFFFF;
+            if (live) {
+                t = n_items + __popcll(m & lt_mask);
+                L0.itm[t] = (unsigned short)(lane | (id << 6));
+                L0.itbb[t] = tbb;
+            }
+            L0.itemidx[(jj - jj0) * kLanes + lane] = (unsigned short)t;
+            n_items += c;
+        }
+        const int jj1 = jj;
+        wave_sync();
+        PHASE(pc, 5);
+        // ---- one item per lane
+        for (int t0 = 0; t0 < n_items; t0 += kLanes) {
+            const int t = t0 + lane;
+            if (t < n_items) {
+                const int d = L0.itm[t];
+                const int il = d & 63, id = (d >> 6) & 63;
+                const unsigned m2 = rlist[il];
+                const int s2 = (int)((m2 >> 24) & 15u), ia = (int)((m2 >> 16) & 7u), k2 = (int)(m2 & 255u);
+                const double *const fpos2 = slot_ptr(L0.fpos, s2, envb), *const ftc2 = slot_ptr(L0.ftc, s2, envb);
+                const double2 o2 = *reinterpret_cast<const double2 *>(fpos2 + 2 * ia);
+                const double cbx = o2.x + L0.rayd[2 * k2], cby = o2.y + L0.rayd[2 * k2 + 1];
+                double alpha = 2.0;   // 2.0 = no hit (never below a best alpha <= 1)
+                int feat = 0;
+                {
+                    const bool wall = id < S;
+                    const int j = wall ? 0 : id - S;
+                    const int *const an2 = slot_ptr(L0.anear, s2, envb);
+                    const bool inside = wall ? (id == an2[2 * ia] || id == an2[2 * ia + 1]) : ((((unsigned)slot_ptr(L0.adn, s2, envb)[ia] >> j) & 1u) != 0u);
+                    if (inside) { alpha = 0.0; feat = kFeatNear; }
+                    else {   // an accepted circle hit at alpha == 1 could never beat the initial best of 1: "t < 1" is equivalent
+                        int f;
+                        poly_query_feat(L0, cmax, wall, wall ? id : 0, wall ? wall_r : rc, ftc2[2 * j], ftc2[2 * j + 1], o2.x, o2.y, cbx, cby, r2, alpha, f);
+                        feat = f < 0 ? 0 : f;
+                    }
+                }
+                L0.ialpha[t] = alpha; L0.itm[t] = (unsigned short)((id << 6) | feat);
+            }
+        }
+        wave_sync();
+        PHASE(pc, 6);
+        // ---- each ray walks its own items in index order
+        for (int q = jj0; q < jj1; q++) {
+            const int t = cnt > q ? (int)L0.itemidx[(q - jj0) * kLanes + lane] : 0xFFFF;
+            if (t != 0xFFFF) {
+                const double al = L0.ialpha[t];
+                if (al < best_a && L0.itbb[t] < best_a) { best_a = al; best_fi = L0.itm[t]; }   // t_exit == best alpha
+            }
+        }
+        wave_sync();
+        PHASE(pc, 7);
+        jj0 = jj1;
+    }
+    // ---- hit point -> f16 distance and class (entity.py:200-215, :222-241)
+    unsigned d16 = d_empty, ty = CAT_EMPTY;
+    int best = -1;
+    if (best_fi >= 0) {
+        const double bx = ax + L0.rayd[2 * k], by = ay + L0.rayd[2 * k + 1];
+        best = best_fi >> 6;
+        const int f = best_fi & 63;
+        const double t = best_a;
+        double px = bx, py = by;  // alpha = 0 hits keep the segment end as their point
+        if (f != kFeatNear) {
+            const bool wall = best < S;
+            const int fc = wall ? L0.fc[best] : 0, first = fc & 0xFFFF, count = fc >> 16;
+            if (wall && f < count) {
+                const double2 nn = *reinterpret_cast<const double2 *>(L0.planes + 8 * (first + f));
+                px = (ax * (1.0 - t) + bx * t) - nn.x * r2;
+                py = (ay * (1.0 - t) + by * t) - nn.y * r2;
+            } else {   // corner circle of the hull or the agent's circle: the same formula around a different centre
+                double2 v = *reinterpret_cast<const double2 *>(L0.planes + 8 * (first + (wall ? f - count : 0)) + 2);
+                if (!wall) { v.x = ftc[2 * (best - S)]; v.y = ftc[2 * (best - S) + 1]; }
+                circle_hit_point(v.x, v.y, ax, ay, bx, by, t, r2, px, py);
+            }
+        }
+        d16 = obs_distance_f16(px, py, ax, ay);
+        ty = (best < S) ? CAT_WALL : ((best - S) >= n_cops ? CAT_THIEF : CAT_COP);
+    }
+    if (on) {  // observations go to the slot's staging in LDS; one coalesced burst to HBM at its write-back
+        const int o = i * R + k;
+        slot_ptr(L0.od, s, envb)[o] = (unsigned short)d16;
+        slot_ptr(L0.ot, s, envb)[o] = (unsigned char)ty;
+        if (la.out.hit_shape) {   // parity/debug only: row (tick, env) of the slot
+            const long long eo = (long long)(rw_epoch((unsigned)ctrl[4 * s]) - 1) * p.N + ctrl[4 * s + 3];
+            la.out.hit_shape[(size_t)eo * A * R + o] = best;
+        }
+        const unsigned want = i < n_cops ? CAT_THIEF : CAT_COP;
+        // min over the agent's rays (other rounds add theirs); non-negative f16: bit order = value order
+        if (ty == want) __hip_atomic_fetch_min(&slot_ptr(L0.dmin, s, envb)[i], d16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    PHASE(pc, 8);
+    lds_release();   // this round's observations, before its rays count as done
+    bool fin = false;
+    if (on) fin = __hip_atomic_fetch_add(&ctrl[4 * s + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1 == A * R + 1;
+    unsigned long long fm = __ballot(fin);
+    unsigned done = 0u;
+    while (fm) {
+        const int l = __builtin_ctzll(fm);
+        fm &= fm - 1;
+        done |= 1u << __builtin_amdgcn_readlane(s, l);
+    }
+    return done;
+}
+
+template <class D, bool kOneTick>
+__device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0, const LaunchArgs &la0)
+{
+    extern __shared__ __align__(16) char smem[];
+    const int lane0 = threadIdx.x % kLanes;
+    const int wave = uni(threadIdx.x / kLanes);
+    const LaunchArgsK lap0 = kernarg_launch_args();
+    PhaseClock pc;
+    WSPREAD(0); WSPREAD(4);
+    int env, T, W;
+    GAS const float *lut_c, *lut_t;
+    {   // ---- prologue: descriptors -> LDS, control words, empty ring, state record -> LDS, map staging
+        int uniform;
+        const Params q = prologue_params(kernarg_prologue(), uniform);   // the pre-barrier part reads this register copy
+        const Params &p = *(const Params *)(ParamsK)pp0;
+        lut_c = G(q.cop_lut); lut_t = G(q.thief_lut);
+        const int lane = lane0;
+        W = uni((int)(blockDim.x / kLanes));
+        T = kOneTick ? 1 : la0.T;
+        int *const ctrl = reinterpret_cast<int *>(smem + q.lds_map_bytes);
+        BlockDesc bd0;
+        prologue_env_desc(q, uniform, W, wave, env, bd0);
+        const MapDesc &md0 = bd0.md;
+        // control words of slot `wave`: claim word (epoch << 14 | units << 7 | next; the only claimable unit is Space.step), rays + units counted
+        // in this tick, the tick its next front runs, env id
+        if (lane < 4) ctrl[4 * wave + lane] = lane == 3 ? env : ((lane == 0 && env < 0) ? (int)kRwFinished : 0);
+        {
+            u32x4 *pz = reinterpret_cast<u32x4 *>(smem + q.lds_pool_off);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            for (int o = threadIdx.x; o < (q.pool_mask + 1) / 2; o += blockDim.x) pz[o] = z;
+            if (threadIdx.x == 0) { int *pc2 = pool_ctl(smem, q, W); pc2[0] = 0; pc2[1] = 0; }
+        }
+        StateRegs sregs;
+        fetch_state<D>(sregs, q, env, lane);
+        stage_map<D>(q, smem, md0, &bd0, const_cast<BlockDesc *>(block_desc_lds(smem, q, W)));   // ends with the workgroup barrier
+        PHASE(pc, 0);
+        WSPREAD(1);
+        if (env >= 0) {
+            const Lds L = carve<D>(q, smem, md0, wave, wave);
+            commit_state<D>(L, sregs, q, lane);
+            load_cold<D>(L, p, env, lane);
+            PHASE(pc, 1);
+        }
+    }
+    unsigned todo = env >= 0 ? 1u << wave : 0u;   // slots whose next front this wave is to run (their tick: ctrl word 2)
+    unsigned wbm = 0u;                             // slots whose tick this wave completed: it writes them back
+    int hint = wave, idle = 0;
+    for (;;) {
+        while (todo) {   // ---- the serial front of a slot, its rays into the ring, its Space.step published
+            const int lane = opaque_v(lane0);
+            const Params &p = *(const Params *)launder((ParamsK)pp0);
+            const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
+            int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+            const BlockDesc *const K = block_desc_lds(smem, p, W);
+            const int slot = uni(__builtin_ctz(todo));
+            todo &= todo - 1;
+            SSPREAD(slot, 0);
+            const int e_s = uni(ctrl[4 * slot + 3]), t = uni(ctrl[4 * slot + 2]);
+            const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
+            int ap = 0;
+            if (la.actions && lane < D::A(p)) ap = la.actions[((size_t)t * p.N + e_s) * D::A(p) + lane];
+            if (lane == 0) ctrl[4 * slot + 1] = 0;
+            const int n2 = slot_front<D>(Ls, (ParamsK)pp0, la, K->md, K->gd, e_s, lane, ap, la.synth_tick + (unsigned long long)t, 0, pc);   // 1: Space.step to come; 0: it ran inside (reset)
+            lds_release();
+            if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], rw_make(t + 1, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            PHASE(pc, 3);
+            const int n_res = pool_sort<D>(Ls, p, la, K->gd, (long long)t * p.N + e_s, slot, lane, pool_ctl(smem, p, W), reinterpret_cast<unsigned long long *>(smem + p.lds_pool_off));
+            lds_release();
+            const int add = n_res + (n2 == 0 ? 1 : 0);
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(&ctrl[4 * slot + 1], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (uni(old) + add == D::A(p) * D::R(p) + 1) wbm |= 1u << slot;
+            hint = slot;
+            WSPREAD(2); SSPREAD(slot, 1);
+        }
+        while (wbm) {   // ---- this wave completed these slots' ticks: write them back; their next fronts are this wave's next job
+            const int lane = opaque_v(lane0);
+            const Params &p = *(const Params *)launder((ParamsK)pp0);
+            const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
+            int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+            const BlockDesc *const K = block_desc_lds(smem, p, W);
+            const int slot = uni(__builtin_ctz(wbm));
+            wbm &= wbm - 1;
+            lds_acquire();
+            PHASE(pc, 16);
+            SSPREAD(slot, 12);
+            const int e_s = uni(ctrl[4 * slot + 3]), t = uni(ctrl[4 * slot + 2]);
+            const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
+            const long long eo = (long long)t * p.N + e_s;
+            const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
+            const bool last = t + 1 >= T;
+            slot_writeback<D>(Ls, p, la, e_s, eo, lane, 1, last, step2, captured2, timeout2, rcount, lut_c, lut_t, pc);
+            wave_sync();   // the write-back has read the slot's staging and flags; the next front overwrites them
+            SSPREAD(slot, 13);
+            if (!last) { if (lane == 0) ctrl[4 * slot + 2] = t + 1; todo |= 1u << slot; }
+            else if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], kRwFinished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (todo) continue;
+        // ---- look for work: a full round of the ring, else an open Space.step, else what the ring holds
+        int base, n, slot = -1;
+        {
+            const int lane = opaque_v(lane0);
+            const Params &p = *(const Params *)launder((ParamsK)pp0);
+            int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+            int *const pctl = pool_ctl(smem, p, W);
+            unsigned w_l = kRwFinished;
+            if (lane < W) w_l = __hip_atomic_load((unsigned *)&ctrl[4 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int hd = 0, tl = 0;
+            if (lane == 0) { hd = __hip_atomic_load(&pctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); tl = __hip_atomic_load(&pctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            hd = uni(hd); tl = uni(tl);
+            const int avail = tl - hd;
+            const unsigned open = (unsigned)__ballot(rw_next(w_l) < rw_units(w_l));
+            if (avail >= kPoolRound || (open == 0u && (avail >= kPoolMinPartial || (avail > 0 && idle >= kPoolPatience)))) {
+                base = hd; n = avail < kPoolRound ? avail : kPoolRound;
+                int seen = hd;
+                if (lane == 0) __hip_atomic_compare_exchange_strong(&pctl[0], &seen, hd + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (uni(seen) != hd) continue;   // another wave took them: look again
+            } else if (open != 0u) {
+                // the Space.step of the slot FURTHEST BEHIND (lowest epoch), ties round the ring from the slot this wave worked on last
+                n = 0; base = 0;
+                unsigned key = 0xFFFFFFFFu;
+                if (rw_next(w_l) < rw_units(w_l)) key = ((unsigned)rw_epoch(w_l) << 5) | (unsigned)((lane - hint) & 31);
+#define CAT_ROW_MIN(SH) { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x120 + SH, 0xF, 0xF, false); key = o_ < key ? o_ : key; }
+                CAT_ROW_MIN(8) CAT_ROW_MIN(4) CAT_ROW_MIN(2) CAT_ROW_MIN(1)
+#undef CAT_ROW_MIN
+                slot = uni((hint + (int)(key & 31u)) & 31);
+                const unsigned wv = (unsigned)__builtin_amdgcn_readlane((int)w_l, slot);
+                unsigned seen = wv;
+                if (lane == 0)
+                    __hip_atomic_compare_exchange_strong((unsigned *)&ctrl[4 * slot], &seen, wv + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((unsigned)uni((int)seen) != wv) continue;
+                hint = slot;
+            } else {
+                // nothing to take: leave when nothing can come any more -- every slot has finished its T ticks; with one tick per launch, when
+                // every slot HAS published (its rays are in rounds under way on other waves, which write it back)
+                if (avail == 0 && __ballot(kOneTick ? (w_l == 0u) : (w_l != kRwFinished)) == 0ull) break;   // (a remainder below kPoolMinPartial is taken after kPoolPatience looks)
+                if (++idle > kSpinLimit) { if (lane == 0) atomicOr(p.err_word, CAT_DEVERR_SCHEDULER); break; }   // never in a correct run
+                __builtin_amdgcn_s_sleep(4);
+                PHASE(pc, 21);
+                continue;
+            }
+            idle = 0;
+            lds_acquire();
+            PHASE(pc, 22);
+        }
+        {   // ---- a round of rays (entity.py:143-144, base_env.py:388-390) or a slot's Space.step (base_env.py:392)
+            const int lane = opaque_v(lane0);
+            const Params &p = *(const Params *)launder((ParamsK)pp0);
+            const LaunchArgs &la = *(const LaunchArgs *)launder(lap0);
+            int *const ctrl = reinterpret_cast<int *>(smem + p.lds_map_bytes);
+            const BlockDesc *const K = block_desc_lds(smem, p, W);
+            if (n > 0) {
+                const Lds L0 = carve<D>(p, smem, K->md, 0, wave);
+                wbm |= pool_round<D>(L0, p, la, uni(K->md.S), K->md.cmax, base, n, lane, ctrl, reinterpret_cast<unsigned long long *>(smem + p.lds_pool_off), pc);
+            } else {
+                const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
+                SSPREAD(slot, 2);
+                PHASE(pc, 9);
+                physics_env<D>(Ls, p, uni(K->md.S), lane, pc);
+                PHASE(pc, 10);
+                lds_release();   // the unit's LDS writes, before it counts as done
+                SSPREAD(slot, 3);
+                int old = 0;
+                if (lane == 0) old = __hip_atomic_fetch_add(&ctrl[4 * slot + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (uni(old) + 1 == D::A(p) * D::R(p) + 1) wbm |= 1u << slot;
+            }
+            PHASE(pc, 23);
+        }
+    }
+    PHASE(pc, 11);
+    WSPREAD(3); WSPREAD(5);
+    pc.flush(lane0);
+}
+
+template <class D>
+__global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel_pooled(const Params *__restrict__ pp0, const LaunchArgs la0, const Prologue)
+{
+    rollout_body_pool<D, false>(pp0, la0);
+}
+template <class D>
+__global__ __launch_bounds__(kMaxWaves *kLanes) void step_kernel_pooled(const Params *__restrict__ pp0, const LaunchArgs la0, const Prologue)
+{
+    rollout_body_pool<D, true>(pp0, la0);
 }
 
 template <class D>
@@ -2905,10 +3358,21 @@ template <class D> static void kernels_of(int fan, KernelFn &reset, KernelFn &ro
     else { reset = reset_kernel<WithFan<D, 0>>; rollout = rollout_kernel<WithFan<D, 0>>; step = step_kernel<WithFan<D, 0>>; }
 }
 // fan: 0 = chunk by chunk, 1 = agent groups with compacted rays (cat_create decides from the maps; CAT_FAN=chunks forces 0)
-static const char *select_kernels(int A, int R, int n_cops, int fan, KernelFn &reset, KernelFn &rollout, KernelFn &step)
+// pool: the sim's rays fit a workgroup ring (cat_create): the step / rollout entries run the pooled fan (instantiated for the headline roster and generically)
+static const char *select_kernels(int A, int R, int n_cops, int fan, bool pool, KernelFn &reset, KernelFn &rollout, KernelFn &step)
 {
     const char *e = getenv("CAT_GENERIC_KERNEL");
     const bool generic = e && atoi(e) != 0;
+    if (pool && fan == 1) {
+        if (!generic && A == 3 && n_cops == 2 && R == 64) {
+            kernels_of<FixDims<3, 64, 2>>(fan, reset, rollout, step);
+            rollout = rollout_kernel_pooled<WithFan<FixDims<3, 64, 2>, 1>>; step = step_kernel_pooled<WithFan<FixDims<3, 64, 2>, 1>>;
+            return "3 agents (2 cops), 64 rays, pooled fan";
+        }
+        kernels_of<DynDims>(fan, reset, rollout, step);
+        rollout = rollout_kernel_pooled<WithFan<DynDims, 1>>; step = step_kernel_pooled<WithFan<DynDims, 1>>;
+        return "generic, pooled fan";
+    }
     if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(fan, reset, rollout, step); return "3 agents (2 cops), 64 rays"; }
 #ifndef CAT_QUICK_BUILD   // diagnostic builds (tools/build_variant.sh -DCAT_QUICK_BUILD): the headline instantiation + the generic one only
     if (!generic && A == 3 && n_cops == 2 && R == 90) { kernels_of<FixDims<3, 90, 2>>(fan, reset, rollout, step); return "3 agents (2 cops), 90 rays"; }
@@ -2923,7 +3387,7 @@ struct LdsSizes {
     int map, env, uni;
     size_t total(int wpb) const { return (size_t)map + (size_t)ctrl_bytes(wpb) + (size_t)wpb * ((size_t)env + (size_t)uni); }
 };
-static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool group_fan)
+static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool group_fan, int grp_rays = 4 * 64)
 {
     auto up = [](int x, int a) { return (x + a - 1) / a * a; };
     const int NP = A * (A - 1) / 2, NPs = NP > 0 ? NP : 1, maxc = A * kK + NP;
@@ -2932,7 +3396,7 @@ static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool grou
     z.map = up((kBB * maxS + rest) * 8 + 2 * maxS * 4, 16) + 16 * R;
     const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
     const int cpa = (R + 63) / 64;
-    const int fan_bytes = kFanBytes + (group_fan ? 4 * 64 * (4 + 1 + 1) : 0);   // four chunks of rays per agent group: arow, alist, adyn
+    const int fan_bytes = kFanBytes + (group_fan ? grp_rays * (4 + 1 + 1) : 0);   // the rays of an agent group (four chunks unless the ray pool needs the LDS): arow, alist, adyn
     (void)cpa;
     z.uni = up(phys_bytes > fan_bytes ? phys_bytes : fan_bytes, 16);
     const int rec_bytes = 96 * A + 16 + ((A * kK + NPs) * 8 + (2 * A * kK + NPs) * 4 + 15) / 16 * 16;
@@ -2982,7 +3446,7 @@ static int dev_alloc(cat_sim *s, T **ptr, size_t count, const void *init)
 }
 
 extern "C" int cat_abi_version(void) { return CAT_ABI_VERSION; }
-extern "C" const char *cat_one_tick_kernel(const cat_sim *sim) { return sim ? "step_kernel" : ""; }
+extern "C" const char *cat_one_tick_kernel(const cat_sim *sim) { return sim ? (sim->p.pool_mask ? "step_kernel_pooled" : "step_kernel") : ""; }
 extern "C" const char *cat_last_error(const cat_sim *sim) { return sim ? sim->err : g_create_err; }
 extern "C" int cat_num_agents(const cat_sim *sim) { return sim ? sim->p.A : CAT_ERR_BAD_ARG; }
 extern "C" int cat_num_shapes(const cat_sim *sim, int m)
@@ -3180,6 +3644,48 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
             return CAT_ERR_BAD_CONFIG;
         }
     }
+    // ---- the workgroup's ray pool (step_kernel_pooled / rollout_kernel_pooled): a ring of wpb * A * R eight-byte entries beside the env areas, where it fits
+    // The pooled kernels pay a sorting pass per slot and win where rounds of a slot's own rays run half empty: the share of (cell, ray)
+    // rows without any candidate decides (labyrinth 0.6: 29.0 against 31.0 us per tick at 4096 envs, 104 against 112 at 16384; lbirinth,
+    // whose rays all meet a wall: 48.5 against 46.0).  CAT_POOL=1 / 0 overrides.
+    int pool_cap = 0, grp_rays = 4 * kLanes;
+    double empty_rows = 0.0;
+    {   // ... sampled where episodes start: five points of every spawn region (the JSON start position of an agent without regions), every ray
+        size_t n_rows = 0, n_empty = 0;
+        for (size_t m = 0; m < grid_host.desc.size(); m++) {
+            const MapDesc &md = descs[m];
+            const GridDesc &gd = grid_host.desc[m];
+            const double *start = geo_f.data() + md.f64_off + 4 * md.S + geo_rest_doubles(md), *regions = start + 2 * md.A;
+            const int *region_off = geo_i.data() + md.i32_off + 2 * md.S;
+            auto sample = [&](double x, double y) {
+                const int cx = (int)floor((x - gd.x0) * gd.inv_cell), cy = (int)floor((y - gd.y0) * gd.inv_cell);
+                if (cx < 0 || cy < 0 || cx >= gd.nx || cy >= gd.ny) return;
+                const size_t r0 = (size_t)gd.off_base + ((size_t)cy * gd.nx + cx) * cfg->n_rays;
+                for (int k = 0; k < cfg->n_rays; k++) { n_rows++; n_empty += grid_host.off[r0 + k + 1] == grid_host.off[r0 + k]; }
+            };
+            for (int i = 0; i < md.A; i++) {
+                const int r0 = region_off[i], nr = region_off[i + 1] - r0;
+                if (nr <= 0) { sample(start[2 * i], start[2 * i + 1]); continue; }
+                for (int q = 0; q < nr; q++) {
+                    const double *rg = regions + 4 * (r0 + q);
+                    sample(rg[0] + rg[2] / 2, rg[1] + rg[3] / 2);
+                    for (int c = 0; c < 4; c++) sample(rg[0] + rg[2] * ((c & 1) ? 0.75 : 0.25), rg[1] + rg[3] * ((c & 2) ? 0.75 : 0.25));
+                }
+            }
+        }
+        empty_rows = n_rows ? (double)n_empty / (double)n_rows : 0.0;
+    }
+    bool want_pool = empty_rows >= kPoolEmptyRows;
+    if (const char *e = getenv("CAT_POOL")) want_pool = atoi(e) != 0;
+    if (fan == 1 && want_pool) {
+        int cap = 64;
+        while (cap < wpb * A * cfg->n_rays) cap *= 2;
+        const int cpa = (cfg->n_rays + 63) / 64, gsz = cpa <= 2 ? 2 : 1;   // group_agents(): what reset_kernel's fan_group holds at once
+        const int g2 = kLanes * std::min(4, std::min(A, gsz) * cpa);
+        const LdsSizes l2 = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, true, g2);
+        if (cap <= 4096 && A <= 8 && cfg->n_rays <= 256 && wpb <= 16 && l2.total(wpb) + 16 + (size_t)cap * 8 <= 160 * 1024) { pool_cap = cap; grp_rays = g2; ls = l2; }
+    }
+    if (getenv("CAT_VERBOSE")) fprintf(stderr, "[cat_sim] ray pool: %d entries (%s); rows without a candidate around the spawn points: %.3f\n", pool_cap, pool_cap ? "pooled fan kernels" : "unit form", empty_rows);
     // ---- work list: workgroups are map-homogeneous; env slots grouped by map, padded with -1
     std::vector<int> work, block_map;
     int helpers = 0;   // CAT_HELPERS (diagnostic): that many waves of every workgroup own no env slot and only take work units
@@ -3304,9 +3810,12 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     }
     p.maxE = maxS + A;
     p.lds_map_bytes = ls.map; p.lds_env_bytes = ls.env; p.lds_union_bytes = ls.uni; p.wpb = wpb;
+    p.grp_rays = grp_rays;
+    p.lds_pool_off = pool_cap ? (int)((ls.total(wpb) + 15) / 16 * 16) : 0;
+    p.pool_mask = pool_cap ? pool_cap - 1 : 0;
     s->wpb = wpb;
-    s->lds_bytes = ls.total(wpb);
-    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, s->reset_fn, s->rollout_fn, s->step_fn);
+    s->lds_bytes = pool_cap ? (size_t)p.lds_pool_off + (size_t)pool_cap * 8 : ls.total(wpb);
+    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, pool_cap != 0, s->reset_fn, s->rollout_fn, s->step_fn);
     if (s->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->step_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
@@ -3327,6 +3836,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         memset(&q, 0, sizeof q);
         q.lds_map_bytes = p.lds_map_bytes; q.lds_env_bytes = p.lds_env_bytes; q.lds_union_bytes = p.lds_union_bytes; q.wpb = p.wpb;
         q.A = p.A; q.R = p.R; q.NP = p.NP; q.maxc = p.maxc; q.n_cops = p.n_cops; q.rec_bytes = p.rec_bytes; q.hot_bytes = p.hot_bytes; q.N = p.N;
+        q.lds_pool_off = p.lds_pool_off; q.pool_mask = p.pool_mask; q.grp_rays = p.grp_rays;
         q.work_env = p.work_env; q.block_desc = p.block_desc; q.state = p.state; q.geo_f64 = p.geo_f64; q.geo_i32 = p.geo_i32;
         q.ray_dx = p.ray_dx; q.ray_dy = p.ray_dy; q.cop_lut = p.cop_lut; q.thief_lut = p.thief_lut;
         bool ident = n_maps == 1 && (int)work.size() == s->n_blocks * wpb;

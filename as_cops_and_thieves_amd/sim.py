@@ -198,6 +198,8 @@ class CatSim:
             raise ValueError("an action outside 0..3 was passed to the step kernel (it was applied as 'no impulse')")
         if flags & nat.DEVERR_CONTACT_DROPPED:
             raise CatSimError("a wall contact was dropped: an agent touched more than WALL_CACHE walls in one step")
+        if flags & nat.DEVERR_SCHEDULER:
+            raise CatSimError("internal: a work item of the pooled ray fan never arrived; the launch left instead of hanging and its results are invalid")
 
     def set_seed(self, seed: int) -> None:
         self.cfg.seed = int(seed) & (2**64 - 1)

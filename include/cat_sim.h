@@ -146,6 +146,7 @@ int cat_step(cat_sim *sim, const int32_t *actions, const cat_outputs *out, void 
    contact got no constraint (Chipmunk's arbiter hash has no such limit). */
 #define CAT_DEVERR_BAD_ACTION 1u
 #define CAT_DEVERR_CONTACT_DROPPED 2u
+#define CAT_DEVERR_SCHEDULER 4u   /* internal: a work item of the pooled ray fan never arrived (the launch left instead of hanging); results of that launch are invalid */
 int cat_device_errors(cat_sim *sim, uint32_t *flags, int clear, void *stream);
 
 /* One-LAUNCH form of the rollout tick: cat_step, the auto-reset of cat_reset_done (auto_reset != 0) and,

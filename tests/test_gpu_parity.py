@@ -88,6 +88,44 @@ def test_chunk_form_of_the_ray_fan_on_the_light_maps(name, rays, monkeypatch):
     assert stats["done"] >= 32
 
 
+@pytest.mark.parametrize("name,rays,cops,thieves,pool", [("labyrinth", 64, 2, 1, "0"), ("lbirinth", 64, 2, 1, "1"), ("squarinth", 64, 2, 1, "1"),
+                                                         ("squarinth", 90, 1, 1, "1"), ("grandbyrinth", 48, 2, 2, "1")])
+def test_pooled_and_unit_form_of_the_light_maps_fan(name, rays, cops, thieves, pool, monkeypatch):
+    """Where the rays of a workgroup fit an LDS ring (wpb * A * R <= 4096) cat_create picks between two schedulers of the group form: fan
+    units of a slot's own rays (step_kernel / rollout_kernel), or one pool of the active rays of ALL slots from which any wave takes rounds
+    (step_kernel_pooled / rollout_kernel_pooled), by the share of candidate-less rays around the spawn points.  The other parity tests run
+    what it picks (the labyrinth: pooled; lbirinth, squarinth: units); this one forces the other choice (CAT_POOL), with the generic
+    instantiation of the pooled kernels on rosters that have no fixed one, one-tick launches and a resident launch, against the oracle."""
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.maps import load_preset
+    from as_cops_and_thieves_amd.sim import CatSim
+    from oracle.cat_oracle import OracleSim
+    monkeypatch.setenv("CAT_POOL", pool)
+    cfg = SimConfig(n_envs=48, n_cops=cops, n_thieves=thieves, n_rays=rays, max_step_count=40, seed=23)
+    m = load_preset(name, cops, thieves).compile()
+    stats = _run(cfg, [m], np.zeros(48, np.int32), ticks=60, rng=np.random.default_rng(4), auto_reset=True)
+    assert stats["done"] >= 48
+    gpu = CatSim(cfg, [m], device="cuda:0")
+    if (cops, thieves) != (2, 2):   # (the four-agent roster only gets the pooled kernels if its ring fits the LDS left beside its larger env areas)
+        assert gpu.one_tick_kernel == ("step_kernel_pooled" if pool == "1" else "step_kernel")
+    print(name, rays, cops, thieves, gpu.one_tick_kernel)
+    cpu = OracleSim(cfg, [m])
+    gpu.reset(); cpu.reset()
+    rows = to_np(gpu.rollout_fused(50, None, tick=0, auto_reset=True))
+    torch.cuda.synchronize()
+    for t in range(50):
+        c = cpu.step(cpu.random_actions(t))
+        flags = {k: c[k].copy() for k in ("reward", "terminated", "truncated", "winner")}
+        cpu.reset(mask=c["terminated"].copy())
+        got = {k: v[t] for k, v in rows.items()}
+        assert_outputs_equal(got, cpu.out, keys=("obs_distance", "obs_type", "shared_distance", "shared_type", "team_positions"), ctx=f"{name} resident tick {t}")
+        assert_outputs_equal(got, flags, keys=tuple(flags), ctx=f"{name} resident tick {t}")
+    assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"{name} resident launch")
+    assert gpu.device_errors() == 0
+    gpu.close()
+
+
 @pytest.mark.parametrize("switch,value", [("CAT_GRID_HULLS", "0"), ("CAT_GRID_OCCLUSION", "0"), ("CAT_GRID_CELL", "16"), ("CAT_GRID_CELL", "5"),
                                           ("CAT_GRID_FIELDS", "0"), ("CAT_FAN", "chunks")])
 @pytest.mark.parametrize("name", ["agh-map", "labyrinth"])
