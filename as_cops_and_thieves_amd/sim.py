@@ -102,6 +102,11 @@ class CatSim:
         """The kernel ``step`` / ``step_fused`` launch ("step_kernel"; diagnostic builds of earlier sources: "tick_kernel")."""
         return self._L.cat_one_tick_kernel(self._h).decode() if hasattr(self._L, "cat_one_tick_kernel") else "tick_kernel"
 
+    @property
+    def rollout_kernel(self) -> str:
+        """The kernel ``rollout_fused`` launches: "rollout_kernel", or "rollout_kernel_pooled" where cat_create chose the pooled ray fan."""
+        return "rollout_kernel_pooled" if self.one_tick_kernel.endswith("_pooled") else "rollout_kernel"
+
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 

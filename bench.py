@@ -412,7 +412,7 @@ def main() -> None:
         bytes2 = algorithmic_bytes_per_env_step(c2.n_agents, c2.n_rays) * c2.n_envs
         r_el, r_kms, r_n = timed_rollout(s2, TR, fence, hip, first_tick=100 + k_steps)
         r_el = max_over_ranks(r_el, device=None if rehearse else dev)
-        kern2 = s2.one_tick_kernel
+        kern2, roll2 = s2.one_tick_kernel, s2.rollout_kernel
         s2.close()
         key = {"map": w["map"], "envs": w["envs"], "rays": w.get("rays", args.rays), "cops": w["cops"], "thieves": w["thieves"]}
         ent = {"value": world * c2.n_envs * k_steps / e2, "unit": "env-steps/s", "steps": k_steps,
@@ -422,7 +422,8 @@ def main() -> None:
         res = {"T": TR, "launches_timed": r_n, "value": world * c2.n_envs * TR * r_n / r_el, "unit": "env-steps/s",
                "kernel_ms_per_tick": r_kms, "roofline_frac": bytes2 / (r_kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                "what": "cat_rollout_fused: T ticks per launch, map staged once, state records resident in LDS, every tick's outputs written"}
-        replay_profile(res, key, "rollout_kernel")
+        res["kernel"] = roll2
+        replay_profile(res, key, roll2)
         ent["resident_rollout"] = res
         return ent
 
@@ -459,11 +460,11 @@ def main() -> None:
         if roll is not None:
             r_el, r_kms, r_n = roll
             res = {"T": TR, "launches_timed": r_n, "value": world * cfg.n_envs * TR * r_n / r_el, "unit": "env-steps/s",
-                   "kernel": "rollout_kernel", "kernel_ms_per_tick": r_kms, "kernel_ms_method": "HIP events attached to each dispatch, / T",
+                   "kernel": sim.rollout_kernel, "kernel_ms_per_tick": r_kms, "kernel_ms_method": "HIP events attached to each dispatch, / T",
                    "roofline_frac": bytes_launch / (r_kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "envs_per_gpu": cfg.n_envs,
                    "what": "cat_rollout_fused: T ticks per launch on the same running batch -- map staged once, state records resident in "
                            "LDS for the T ticks, EVERY tick's outputs written to [T, N, ...] buffers; the headline `value` stays one launch per tick"}
-            replay_profile(res, wl, "rollout_kernel")
+            replay_profile(res, wl, sim.rollout_kernel)
             extra = dict(extra or {})
             extra[f"{args.map} {args.cops}v{args.thieves} x{cfg.n_envs}, T={TR} resident rollout"] = res
         line = {

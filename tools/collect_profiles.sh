@@ -38,7 +38,8 @@ for sh in $shapes; do
   bi=$(python3 -c "import json; print(json.load(open('profiles/${tag}_${sh}_bench_under_rocprof.json'))['config']['burn_in_steps'])")   # what the run used
   k1=$(python3 -c "import json; print(json.load(open('profiles/${tag}_${sh}_bench_under_rocprof.json'))['roofline']['kernel'])")   # tick_kernel or step_kernel
   python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel $k1 --burn-in $bi > /dev/null
-  python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel rollout_kernel --ticks-per-launch 64 --burn-in $bi > /dev/null
+  k2=rollout_kernel; case $k1 in *_pooled) k2=rollout_kernel_pooled;; esac   # the resident launch of the same sim
+  python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel $k2 --ticks-per-launch 64 --burn-in $bi > /dev/null
   if [ $sh = lab ]; then
     for c in "FETCH_SIZE" "WRITE_SIZE"; do
       i=$((i+1))

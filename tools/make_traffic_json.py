@@ -24,7 +24,7 @@ ap.add_argument("--out", default=None)
 a = ap.parse_args()
 tag = a.tag
 key = json.loads(a.key)
-suffix = (f"_{a.shape}" if a.shape else "") + ("_rollout" if a.kernel == "rollout_kernel" else "")
+suffix = (f"_{a.shape}" if a.shape else "") + ("_rollout" if a.kernel.startswith("rollout_kernel") else "")
 summary = Path(a.summary) if a.summary else root / "profiles" / (f"{tag}_{a.shape}_pmc_summary.txt" if a.shape else f"{tag}_final_pmc_summary.txt")
 reset_file = Path(a.from_reset) if a.from_reset else root / "profiles" / f"{tag}_pmc_from_reset.txt"
 out_file = Path(a.out) if a.out else root / "profiles" / f"{tag}_traffic{suffix}.json"
@@ -40,12 +40,12 @@ def counters(path, kernel):
 
 
 val = counters(summary, a.kernel)
-from_reset = counters(reset_file, a.kernel) if (a.kernel != "rollout_kernel" and not a.shape and reset_file.exists()) else None
+from_reset = counters(reset_file, a.kernel) if (not a.kernel.startswith("rollout_kernel") and not a.shape and reset_file.exists()) else None
 waves, T = val["SQ_WAVES"], a.ticks_per_launch
 hbm = lambda v: int(round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024))
 per_step = waves * T          # one wave per env slot: wave-instructions per env-step = counter / (waves x ticks per launch)
 regime = (f"running batch (the last 25 {a.kernel} launches of `bench.py --steps 20 --warmup 5`, after its burn-in ticks (mid-episode): the "
-          "launches the bench line times)" if a.kernel != "rollout_kernel" else
+          "launches the bench line times)" if not a.kernel.startswith("rollout_kernel") else
           f"running batch (the last 4 rollout_kernel launches of the same command: {T} ticks per launch, after the one-launch-per-tick region)")
 out = {
     "workload": f"{key['map']} {key['cops']}v{key['thieves']}, {key['envs']} envs, {key['rays']} rays",
