@@ -384,7 +384,8 @@ def main() -> None:
         r_el = max_over_ranks(r_el, device=None if rehearse else dev)
         roll = (r_el, r_kms, r_n)
     episodes = int(sim.get_state()["reset_count"].sum().item())
-    one_tick_kernel = sim.one_tick_kernel      # "step_kernel": one tick through the resident rollout scheduler (rounds 1 - 3: "tick_kernel")
+    one_tick_kernel = sim.one_tick_kernel      # "step_kernel" / "step_kernel_pooled": one tick through the resident rollout scheduler (rounds 1 - 3: "tick_kernel")
+    rollout_kernel = sim.rollout_kernel        # the resident launch of the same sim
     sim.close()
     offsets = [cfg.env_id_offset]
     if world > 1:   # which global env ids each rank simulated (disjoint contiguous shards)
@@ -460,11 +461,11 @@ def main() -> None:
         if roll is not None:
             r_el, r_kms, r_n = roll
             res = {"T": TR, "launches_timed": r_n, "value": world * cfg.n_envs * TR * r_n / r_el, "unit": "env-steps/s",
-                   "kernel": sim.rollout_kernel, "kernel_ms_per_tick": r_kms, "kernel_ms_method": "HIP events attached to each dispatch, / T",
+                   "kernel": rollout_kernel, "kernel_ms_per_tick": r_kms, "kernel_ms_method": "HIP events attached to each dispatch, / T",
                    "roofline_frac": bytes_launch / (r_kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "envs_per_gpu": cfg.n_envs,
                    "what": "cat_rollout_fused: T ticks per launch on the same running batch -- map staged once, state records resident in "
                            "LDS for the T ticks, EVERY tick's outputs written to [T, N, ...] buffers; the headline `value` stays one launch per tick"}
-            replay_profile(res, wl, sim.rollout_kernel)
+            replay_profile(res, wl, rollout_kernel)
             extra = dict(extra or {})
             extra[f"{args.map} {args.cops}v{args.thieves} x{cfg.n_envs}, T={TR} resident rollout"] = res
         line = {
