@@ -2,8 +2,9 @@
 //
 // A workgroup of 1..16 wavefronts advances as many envs that share one map, whose geometry (hull planes +
 // shape bbs) is staged once per workgroup in LDS.  A wavefront owns one env for the serial part of the tick;
-// the ray fan -- cut into 64-ray chunks (fan_chunk), or into agent groups whose candidate-less rays are sorted out first
-// (fan_group: maps whose rays meet few walls) -- and the physics step are work units any wave of the workgroup may claim.
+// the ray fan -- cut into 64-ray chunks (fan_chunk), into agent groups whose candidate-less rays are sorted out first
+// (fan_group: maps whose rays meet few walls), or pooled over all slots of the workgroup (pool_sort / pool_round: the *_pooled kernels) --
+// and the physics step are work units any wave of the workgroup may claim.
 // All body state and ray arithmetic is FP64 with contraction off, so results are bit-comparable with a non-FMA
 // CPU evaluation of the same formulas.  No MFMA: the path is geometry/indexing, bounded by FP64 VALU issue and
 // LDS latency (DESIGN.md "Kernels").
@@ -11,9 +12,9 @@
 // What each device function reproduces (paths relative to the reference repo; [CP x] = the
 // Chipmunk2D 7.0.x function of that name, a third-party dependency of the reference whose
 // published algorithm is followed -- SURVEY.md appendix A):
-//   step_kernel / rollout_kernel   BaseEnv.step (one tick / T ticks per launch)   src/environments/base_env.py:354-413
+//   step_kernel / rollout_kernel (and their _pooled forms)   BaseEnv.step (one tick / T ticks per launch)   src/environments/base_env.py:354-413
 //   reset_kernel  BaseEnv.reset                      src/environments/base_env.py:286-352
-//   agent_setup, fan_chunk   Entity.get_observation/_query_body   src/agents/entity.py:159-241
+//   agent_setup, fan_chunk, fan_group, pool_sort, pool_round   Entity.get_observation/_query_body   src/agents/entity.py:159-241
 //   rewards_and_positions    Cop.reward / Thief.reward            src/agents/cop.py:49-75, thief.py:48-69
 //   emit_observations        get_shared_observations              src/environments/observation_spaces.py:67-131
 //   physics_env              pymunk Space.step -> [CP cpSpaceStep]  (call site base_env.py:392)
@@ -129,8 +130,8 @@ struct Params {
 
 // Problem dimensions as seen by the device code: either read from the parameter block (DynDims) or compile-time
 // constants for the rosters / ray counts that are instantiated (FixDims): constant LDS offsets and unrolled agent loops.
-// Round 4, as the compiler reports them (tools/regs.sh): step_kernel / rollout_kernel 115 - 121 VGPRs and 36 - 51 spilled SGPRs,
-// reset_kernel 103 - 107 VGPRs and 12 - 22; no scratch in any instantiation (rounds 1 - 3, tick_kernel: 127 - 128 VGPRs, 64 - 78
+// Round 4, as the compiler reports them (tools/regs.sh, profiles/r04_registers.txt): step_kernel / rollout_kernel 115 - 121 VGPRs and 9 - 17 spilled SGPRs fixed (23 - 41 generic),
+// the pooled pair 113 - 115 and 20 - 21 (37 - 38), reset_kernel 103 - 107 VGPRs and 6 - 22; no scratch in any instantiation (rounds 1 - 3, tick_kernel: 127 - 128 VGPRs, 64 - 78
 // spilled SGPRs fixed, 107 - 134 + 64 B of scratch generic -- see "opaque roots" below).
 struct DynDims {
     static __device__ __forceinline__ int A(const Params &p) { return p.A; }
