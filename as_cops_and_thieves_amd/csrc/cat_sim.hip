@@ -2409,8 +2409,8 @@ constexpr int kPoolRound = CAT_POOL_ROUND;            // rays of a full round
 constexpr int kPoolMinPartial = CAT_POOL_MIN_PARTIAL; // a wave with nothing else to do takes fewer than a full round only from this many on ...
 constexpr int kPoolPatience = CAT_POOL_PATIENCE;      // ... or after this many idle looks (fronts under way will add to the ring; the end of a launch drains it)
 constexpr int kSpinLimit = 1 << 22;   // a ring entry that never arrives / a lost wake-up: leave with CAT_DEVERR_SCHEDULER instead of hanging the device
-__device__ __forceinline__ int *pool_ctl(char *smem, const Params &p, int W) { return reinterpret_cast<int *>(smem + p.lds_map_bytes + 16 * W + kWgConstBytes - 16); }   // head, tail, fronts under way, -
-static_assert(sizeof(BlockDesc) <= kWgConstBytes - 16, "the pool counters live behind the BlockDesc");
+__device__ __forceinline__ int *pool_ctl(char *smem, const Params &p, int W) { return reinterpret_cast<int *>(smem + p.lds_map_bytes + 16 * W + kWgConstBytes - 8); }   // head, tail
+static_assert(sizeof(BlockDesc) <= kWgConstBytes - 8, "the pool counters live behind the BlockDesc");
 
 // The rays of one slot (its front just ran agent_setup): EMPTY observations for the candidate-less ones, ring entries for the others.
 // Returns the number of rays resolved here.  env: the slot's row of the output buffers (hit_shape only).
@@ -2680,7 +2680,7 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
             u32x4 *pz = reinterpret_cast<u32x4 *>(smem + q.lds_pool_off);
             const u32x4 z = {0u, 0u, 0u, 0u};
             for (int o = threadIdx.x; o < (q.pool_mask + 1) / 2; o += blockDim.x) pz[o] = z;
-            if (threadIdx.x == 0) { int *pc2 = pool_ctl(smem, q, W); pc2[0] = 0; pc2[1] = 0; pc2[2] = W; }   // every slot starts with a front (a slot without an env never takes its count back: only costs patience)
+            if (threadIdx.x == 0) { int *pc2 = pool_ctl(smem, q, W); pc2[0] = 0; pc2[1] = 0; }
         }
         StateRegs sregs;
         fetch_state<D>(sregs, q, env, lane);
@@ -2693,9 +2693,6 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
             load_cold<D>(L, p, env, lane);
             PHASE(pc, 1);
         }
-#ifdef CAT_POOL_FRONTS
-        else if (lane == 0) __hip_atomic_fetch_add(&pool_ctl(smem, q, W)[2], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a slot without an env runs no front
-#endif
     }
     unsigned todo = env >= 0 ? 1u << wave : 0u;   // slots whose next front this wave is to run (their tick: ctrl word 2)
     unsigned wbm = 0u;                             // slots whose tick this wave completed: it writes them back
@@ -2721,9 +2718,6 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
             PHASE(pc, 3);
             const int n_res = pool_sort<D>(Ls, p, la, K->gd, (long long)t * p.N + e_s, slot, lane, pool_ctl(smem, p, W), reinterpret_cast<unsigned long long *>(smem + p.lds_pool_off));
             lds_release();
-#ifdef CAT_POOL_FRONTS
-            if (lane == 0) __hip_atomic_fetch_add(&pool_ctl(smem, p, W)[2], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // this slot's rays are all in the ring
-#endif
             const int add = n_res + (n2 == 0 ? 1 : 0);
             int old = 0;
             if (lane == 0) old = __hip_atomic_fetch_add(&ctrl[4 * slot + 1], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2747,16 +2741,10 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
             const long long eo = (long long)t * p.N + e_s;
             const int step2 = uni(Ls.flags[0]), captured2 = uni(Ls.flags[1]), timeout2 = uni(Ls.flags[2]), rcount = uni(Ls.flags[3]);
             const bool last = t + 1 >= T;
-#ifdef CAT_POOL_FRONTS
-            if (!last && lane == 0) __hip_atomic_fetch_add(&pool_ctl(smem, p, W)[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // its next front will add to the ring
-#endif
             slot_writeback<D>(Ls, p, la, e_s, eo, lane, 1, last, step2, captured2, timeout2, rcount, lut_c, lut_t, pc);
             wave_sync();   // the write-back has read the slot's staging and flags; the next front overwrites them
             SSPREAD(slot, 13);
-            if (!last) {
-                if (lane == 0) ctrl[4 * slot + 2] = t + 1;
-                todo |= 1u << slot;
-            }
+            if (!last) { if (lane == 0) ctrl[4 * slot + 2] = t + 1; todo |= 1u << slot; }
             else if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], kRwFinished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (todo) continue;
@@ -2770,17 +2758,11 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
             unsigned w_l = kRwFinished;
             if (lane < W) w_l = __hip_atomic_load((unsigned *)&ctrl[4 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             int hd = 0, tl = 0;
-            int fronts = 1;
-            if (lane == 0) {
-                hd = __hip_atomic_load(&pctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); tl = __hip_atomic_load(&pctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef CAT_POOL_FRONTS
-                fronts = __hip_atomic_load(&pctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-            }
-            hd = uni(hd); tl = uni(tl); fronts = uni(fronts);
+            if (lane == 0) { hd = __hip_atomic_load(&pctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); tl = __hip_atomic_load(&pctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            hd = uni(hd); tl = uni(tl);
             const int avail = tl - hd;
             const unsigned open = (unsigned)__ballot(rw_next(w_l) < rw_units(w_l));
-            if (avail >= kPoolRound || (open == 0u && (avail >= kPoolMinPartial || (avail > 0 && (idle >= kPoolPatience || fronts <= 0))))) {
+            if (avail >= kPoolRound || (open == 0u && (avail >= kPoolMinPartial || (avail > 0 && idle >= kPoolPatience)))) {
                 base = hd; n = avail < kPoolRound ? avail : kPoolRound;
                 int seen = hd;
                 if (lane == 0) __hip_atomic_compare_exchange_strong(&pctl[0], &seen, hd + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
