@@ -545,6 +545,25 @@ __device__ __forceinline__ double poly_point_distance(const Lds &L, int sh, doub
     return dist - r;
 }
 
+// poly_point_distance(L, sh, r, px, py) <= lim, evaluated exactly behind a reject that no rounding can fool: a point outside one face plane by more
+// than r + lim + 1e-6 is farther than that from the hull (which lies behind every plane), and the distance's own error is ~1e-12.  The setup's
+// "origin inside the query radius" test runs on walls whose inflated bb holds the origin: on a map of slanted footprints (agh-map) that is often a
+// 20-edge hull many pixels away, and the full distance costs a divide and a square root per edge (10.5 k cycles of an agh-map front before this).
+__device__ __forceinline__ bool poly_point_within(const Lds &L, int sh, double r, double px, double py, double lim)
+{
+    const int fc = L.fc[sh], first = fc & 0xFFFF, count = fc >> 16;
+    const double far = r + lim + 1e-6;
+    bool out = false;
+    for (int i = 0; i < count; i++) {
+        const double *pl = L.planes + 8 * (first + i);
+        const double2 n = *reinterpret_cast<const double2 *>(pl);
+        const double2 v1 = *reinterpret_cast<const double2 *>(pl + 2);
+        out = out || (n.x * (px - v1.x) + n.y * (py - v1.y) > far);
+    }
+    if (out) return false;
+    return poly_point_distance(L, sh, r, px, py) <= lim;
+}
+
 // ------------------------------------------------------------------ ray fan -------------------
 // Broadphase = spatial hash (GridDesc): (cell of the agent, ray index) -> ascending candidate wall ids,
 // looked up in a table built once per map; the other agents' circles are added per ray from the cone
@@ -793,7 +812,7 @@ __device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, i
             const double *bb = L.bb + kBB * sh;
             const double m = r2 + 1e-6;
             if ((bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m))
-                near = poly_point_distance(L, sh, p.wall_r, ax, ay) <= r2;  // [CP cpShapeSegmentQuery] alpha = 0 rule
+                near = poly_point_within(L, sh, p.wall_r, ax, ay, r2);  // [CP cpShapeSegmentQuery] alpha = 0 rule
         }
         const unsigned long long m = __ballot(near);
         // ascending wall ids; more than two such walls cannot matter: the first visited wins at alpha 0
@@ -823,7 +842,7 @@ __device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, i
                 const double *bb = L.bb + kBB * sh;
                 const double m = r2 + 1e-6;
                 if ((bb[0] - m <= ax) && (ax <= bb[2] + m) && (bb[1] - m <= ay) && (ay <= bb[3] + m))
-                    near = poly_point_distance(L, sh, p.wall_r, ax, ay) <= r2;
+                    near = poly_point_within(L, sh, p.wall_r, ax, ay, r2);
             }
             unsigned long long m = __ballot(near);
             while (m) {
@@ -1388,10 +1407,16 @@ __device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, d
     const int fc = uni(L.fc[sh]), first = fc & 0xFFFF, count = fc >> 16;
     double sep = -INFINITY, dd = INFINITY, tt = 0.0, ppx = 0.0, ppy = 0.0;
     if (lane < count) {
+        const double *pl = L.planes + 8 * (first + lane);
+        sep = pl[0] * (cx - pl[2]) + pl[1] * (cy - pl[3]);
+    }
+    // a plane farther than rc + rp from the centre separates: no contact (hull lies behind every plane).  Checked before the per-edge closest
+    // points (a divide each): on a map of slanted footprints most bb overlaps end here
+    if (__ballot(sep > rc + rp + 1e-9) != 0ull) return 0;
+    if (lane < count) {
         const int i = lane;
         const double *pl = L.planes + 8 * (first + i);
         const double *pv = L.planes + 8 * (first + (i - 1 + count) % count);
-        sep = pl[0] * (cx - pl[2]) + pl[1] * (cy - pl[3]);
         // Minkowski points (poly vertex - circle centre); GJK's final ordering for a CCW hull: v0 = vert[i], v1 = vert[i-1]
         double ax_ = pl[2] - cx, ay_ = pl[3] - cy, bx_ = pv[2] - cx, by_ = pv[3] - cy;
         double dx = bx_ - ax_, dy = by_ - ay_;
@@ -1401,8 +1426,6 @@ __device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, d
         dd = ppx * ppx + ppy * ppy;
         tt = t;
     }
-    // a plane farther than rc + rp from the centre separates: no contact (hull lies behind every plane)
-    if (__ballot(sep > rc + rp + 1e-9) != 0ull) return 0;
     const bool inside = __ballot(sep > 0.0) == 0ull;
     int best = 0, sepi = 0;
     double bestd = INFINITY, maxsep = -INFINITY;
@@ -2385,6 +2408,17 @@ __global__ __launch_bounds__(kMaxWaves *kLanes) void step_kernel(const Params *_
     rollout_body<D, true>(pp0, la0);
 }
 
+#ifdef CAT_WB_COUNTS
+__device__ unsigned long long g_wb_counts[8];
+extern "C" int cat_debug_wb_counts(unsigned long long *out8, int reset)
+{
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wb_counts), sizeof h) != hipSuccess) return -1;
+    for (int i = 0; i < 8; i++) out8[i] = h[i];
+    if (reset) { memset(h, 0, sizeof h); if (hipMemcpyToSymbol(HIP_SYMBOL(g_wb_counts), h, sizeof h) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 // ------------------------------------------------------------------ pooled ray fan -----------
 template <class T> __device__ __forceinline__ T *slot_ptr(T *p0, int sl, int envb) { return (T *)((char *)const_cast<typename std::remove_const<T>::type *>(p0) + sl * envb); }
 // step_kernel_pooled / rollout_kernel_pooled (light maps whose rays fit the pool: wpb * A * R <= 4096).  In the unit form above a slot's
@@ -2725,6 +2759,9 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
             hint = slot;
             WSPREAD(2); SSPREAD(slot, 1);
         }
+#ifdef CAT_WB_COUNTS   // diagnostic build: how many slot ticks a wave completes at once (cat_debug_wb_counts)
+        if (wbm && lane0 == 0) { const int k_ = __popc(wbm); atomicAdd(&g_wb_counts[k_ > 7 ? 7 : k_], 1ull); }
+#endif
         while (wbm) {   // ---- this wave completed these slots' ticks: write them back; their next fronts are this wave's next job
             const int lane = opaque_v(lane0);
             const Params &p = *(const Params *)launder((ParamsK)pp0);
@@ -3685,6 +3722,12 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         const int g2 = kLanes * std::min(4, std::min(A, gsz) * cpa);
         const LdsSizes l2 = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, true, g2);
         if (cap <= 4096 && A <= 8 && cfg->n_rays <= 256 && wpb <= 16 && l2.total(wpb) + 16 + (size_t)cap * 8 <= 160 * 1024) { pool_cap = cap; grp_rays = g2; ls = l2; }
+    }
+    if (getenv("CAT_VERBOSE")) {   // contact-candidate rows (agent_setup): how many cells overflow the packed row of seven
+        size_t n = 0, n0 = 0, n7 = 0, n15 = 0; int mx = 0;
+        for (unsigned long long w : grid_host.crows) { const int c = (int)(w & 0xFF); n++; n0 += c > 0; n7 += c > 7; n15 += c > 15; if (c > mx) mx = c; }
+        fprintf(stderr, "[cat_sim] contact rows: %zu cells, %.3f with a candidate, %.4f with more than 7 (CSR walk), %.4f with more than 15; longest %d\n", n, n ? (double)n0 / n : 0.0,
+                n ? (double)n7 / n : 0.0, n ? (double)n15 / n : 0.0, mx);
     }
     if (getenv("CAT_VERBOSE")) fprintf(stderr, "[cat_sim] ray pool: %d entries (%s); rows without a candidate around the spawn points: %.3f\n", pool_cap, pool_cap ? "pooled fan kernels" : "unit form", empty_rows);
     // ---- work list: workgroups are map-homogeneous; env slots grouped by map, padded with -1
