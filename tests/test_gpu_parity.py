@@ -126,6 +126,36 @@ def test_pooled_and_unit_form_of_the_light_maps_fan(name, rays, cops, thieves, p
     gpu.close()
 
 
+@pytest.mark.parametrize("n_envs", [1, 5, 17])
+def test_pooled_fan_with_a_partly_filled_workgroup(n_envs, monkeypatch):
+    """The pooled kernels with fewer env slots than a workgroup has waves (slots without an env publish nothing and count nothing), and with a
+    second workgroup that holds a single env: one-tick launches, then a resident launch, against the oracle; the scheduler's watchdog flag stays clear."""
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.sim import CatSim
+    from oracle.cat_oracle import OracleSim
+    monkeypatch.setenv("CAT_POOL", "1")
+    m = compiled("labyrinth")
+    cfg = SimConfig(n_envs=n_envs, n_rays=64, max_step_count=25, seed=5)
+    stats = _run(cfg, [m], np.zeros(n_envs, np.int32), ticks=40, rng=np.random.default_rng(8), auto_reset=True)
+    assert stats["done"] >= n_envs
+    gpu, cpu = CatSim(cfg, [m], device="cuda:0"), OracleSim(cfg, [m])
+    assert gpu.one_tick_kernel == "step_kernel_pooled"
+    gpu.reset(); cpu.reset()
+    rows = to_np(gpu.rollout_fused(60, None, tick=0, auto_reset=True))
+    torch.cuda.synchronize()
+    for t in range(60):
+        c = cpu.step(cpu.random_actions(t))
+        flags = {k: c[k].copy() for k in ("reward", "terminated", "truncated", "winner")}
+        cpu.reset(mask=c["terminated"].copy())
+        got = {k: v[t] for k, v in rows.items()}
+        assert_outputs_equal(got, cpu.out, keys=("obs_distance", "obs_type", "shared_distance", "shared_type", "team_positions"), ctx=f"tick {t}")
+        assert_outputs_equal(got, flags, keys=tuple(flags), ctx=f"tick {t}")
+    assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx="resident launch")
+    assert gpu.device_errors() == 0
+    gpu.close()
+
+
 @pytest.mark.parametrize("switch,value", [("CAT_GRID_HULLS", "0"), ("CAT_GRID_OCCLUSION", "0"), ("CAT_GRID_CELL", "16"), ("CAT_GRID_CELL", "5"),
                                           ("CAT_GRID_FIELDS", "0"), ("CAT_FAN", "chunks")])
 @pytest.mark.parametrize("name", ["agh-map", "labyrinth"])
