@@ -2703,10 +2703,14 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
         const int lane = lane0;
         W = uni((int)(blockDim.x / kLanes));
         T = kOneTick ? 1 : la0.T;
+        WSPREAD(6);   // the parameter burst has arrived
         int *const ctrl = reinterpret_cast<int *>(smem + q.lds_map_bytes);
         BlockDesc bd0;
         prologue_env_desc(q, uniform, W, wave, env, bd0);
         const MapDesc &md0 = bd0.md;
+#ifdef CAT_WAVE_SPREAD
+        { int e_ = env, s_ = md0.S; asm volatile("" : "+s"(e_), "+v"(s_)); WSPREAD(7); }   // env id and descriptor have arrived
+#endif
         // control words of slot `wave`: claim word (epoch << 14 | units << 7 | next; the only claimable unit is Space.step), rays + units counted
         // in this tick, the tick its next front runs, env id
         if (lane < 4) ctrl[4 * wave + lane] = lane == 3 ? env : ((lane == 0 && env < 0) ? (int)kRwFinished : 0);
