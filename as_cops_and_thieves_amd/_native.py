@@ -91,6 +91,9 @@ def lib() -> C.CDLL:
     if hasattr(L, "cat_one_tick_kernel"):      # absent from diagnostic builds of earlier sources (CAT_SIM_LIB, tools/ab_*.sh)
         L.cat_one_tick_kernel.restype = C.c_char_p
         L.cat_one_tick_kernel.argtypes = [vp]
+    if hasattr(L, "cat_rollout_kernel"):
+        L.cat_rollout_kernel.restype = C.c_char_p
+        L.cat_rollout_kernel.argtypes = [vp]
     L.cat_create.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp]
     L.cat_destroy.argtypes = [vp]
     L.cat_reset.argtypes = [vp, vp, vp, vp, vp]
@@ -125,7 +128,7 @@ def lib() -> C.CDLL:
     return L
 
 
-EXPORTED_SYMBOLS = ("cat_abi_version", "cat_one_tick_kernel", "cat_last_error", "cat_create", "cat_destroy", "cat_reset",
+EXPORTED_SYMBOLS = ("cat_abi_version", "cat_one_tick_kernel", "cat_rollout_kernel", "cat_last_error", "cat_create", "cat_destroy", "cat_reset",
                     "cat_reset_done", "cat_step", "cat_step_fused", "cat_rollout_fused", "cat_get_state", "cat_set_state", "cat_random_actions",
                     "cat_set_seed", "cat_device_errors", "cat_arm_kernel_timing", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup",
                     "cat_grid_build_host", "cat_grid_lookup_host", "cat_grid_bytes_host", "cat_grid_free_host", "cat_map_wall_bb_depth_host")

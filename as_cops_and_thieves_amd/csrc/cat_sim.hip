@@ -2429,7 +2429,7 @@ template <class T> __device__ __forceinline__ T *slot_ptr(T *p0, int sl, int env
 // slot per lane).  The per-ray arithmetic is fan_group's, so the results are bit-identical.  A slot's tick is complete when its
 // A * R rays and its Space.step have been counted (ctrl word 1); the wave that counts the last writes it back.
 constexpr unsigned kPoolValid = 0x80000000u;
-constexpr double kPoolEmptyRows = 0.25;   // cat_create: the pooled kernels serve a sim whose candidate table has at least this share of empty rows
+constexpr double kPoolEmptyRows = 0.05;   // cat_create: the pooled one-tick kernel serves a sim whose candidate rows around the spawn points are empty at least this often
 #ifndef CAT_POOL_ROUND
 #define CAT_POOL_ROUND 60
 #endif
@@ -3400,19 +3400,22 @@ template <class D> static void kernels_of(int fan, KernelFn &reset, KernelFn &ro
     else { reset = reset_kernel<WithFan<D, 0>>; rollout = rollout_kernel<WithFan<D, 0>>; step = step_kernel<WithFan<D, 0>>; }
 }
 // fan: 0 = chunk by chunk, 1 = agent groups with compacted rays (cat_create decides from the maps; CAT_FAN=chunks forces 0)
-// pool: the sim's rays fit a workgroup ring (cat_create): the step / rollout entries run the pooled fan (instantiated for the headline roster and generically)
-static const char *select_kernels(int A, int R, int n_cops, int fan, bool pool, KernelFn &reset, KernelFn &rollout, KernelFn &step)
+// pool_roll / pool_step: the sim's rays fit a workgroup ring (cat_create) and the resident / the one-tick entry runs the pooled fan (instantiated for the
+// headline roster and generically)
+static const char *select_kernels(int A, int R, int n_cops, int fan, bool pool_roll, bool pool_step, KernelFn &reset, KernelFn &rollout, KernelFn &step)
 {
     const char *e = getenv("CAT_GENERIC_KERNEL");
     const bool generic = e && atoi(e) != 0;
-    if (pool && fan == 1) {
+    if ((pool_roll || pool_step) && fan == 1) {
         if (!generic && A == 3 && n_cops == 2 && R == 64) {
             kernels_of<FixDims<3, 64, 2>>(fan, reset, rollout, step);
-            rollout = rollout_kernel_pooled<WithFan<FixDims<3, 64, 2>, 1>>; step = step_kernel_pooled<WithFan<FixDims<3, 64, 2>, 1>>;
+            if (pool_roll) rollout = rollout_kernel_pooled<WithFan<FixDims<3, 64, 2>, 1>>;
+            if (pool_step) step = step_kernel_pooled<WithFan<FixDims<3, 64, 2>, 1>>;
             return "3 agents (2 cops), 64 rays, pooled fan";
         }
         kernels_of<DynDims>(fan, reset, rollout, step);
-        rollout = rollout_kernel_pooled<WithFan<DynDims, 1>>; step = step_kernel_pooled<WithFan<DynDims, 1>>;
+        if (pool_roll) rollout = rollout_kernel_pooled<WithFan<DynDims, 1>>;
+        if (pool_step) step = step_kernel_pooled<WithFan<DynDims, 1>>;
         return "generic, pooled fan";
     }
     if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(fan, reset, rollout, step); return "3 agents (2 cops), 64 rays"; }
@@ -3456,6 +3459,7 @@ struct cat_sim {
     int device;
     int n_blocks, wpb;
     Prologue pro;
+    bool pool_step = false;   // the one-tick entry runs the pooled kernel (the resident one does whenever the ring exists: p.pool_mask)
     KernelFn reset_fn = nullptr, rollout_fn = nullptr, step_fn = nullptr;   // the instantiations matching (agents, rays, cops): cat_reset*, cat_rollout_fused, cat_step*
     const char *kernel_variant = "";
     hipEvent_t t_start = nullptr, t_stop = nullptr;   // cat_arm_kernel_timing
@@ -3488,7 +3492,8 @@ static int dev_alloc(cat_sim *s, T **ptr, size_t count, const void *init)
 }
 
 extern "C" int cat_abi_version(void) { return CAT_ABI_VERSION; }
-extern "C" const char *cat_one_tick_kernel(const cat_sim *sim) { return sim ? (sim->p.pool_mask ? "step_kernel_pooled" : "step_kernel") : ""; }
+extern "C" const char *cat_one_tick_kernel(const cat_sim *sim) { return sim ? (sim->pool_step ? "step_kernel_pooled" : "step_kernel") : ""; }
+extern "C" const char *cat_rollout_kernel(const cat_sim *sim) { return sim ? (sim->p.pool_mask ? "rollout_kernel_pooled" : "rollout_kernel") : ""; }
 extern "C" const char *cat_last_error(const cat_sim *sim) { return sim ? sim->err : g_create_err; }
 extern "C" int cat_num_agents(const cat_sim *sim) { return sim ? sim->p.A : CAT_ERR_BAD_ARG; }
 extern "C" int cat_num_shapes(const cat_sim *sim, int m)
@@ -3687,9 +3692,11 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         }
     }
     // ---- the workgroup's ray pool (step_kernel_pooled / rollout_kernel_pooled): a ring of wpb * A * R eight-byte entries beside the env areas, where it fits
-    // The pooled kernels pay a sorting pass per slot and win where rounds of a slot's own rays run half empty: the share of (cell, ray)
-    // rows without any candidate decides (labyrinth 0.6: 29.0 against 31.0 us per tick at 4096 envs, 104 against 112 at 16384; lbirinth,
-    // whose rays all meet a wall: 48.5 against 46.0).  CAT_POOL=1 / 0 overrides.
+    // Where the ring fits, the RESIDENT launch always runs pooled (whole runs from the reset, tools/pool_soak.py, M env-steps/s unit -> pooled: labyrinth 201 -> 229,
+    // labyrinth-inside 148 -> 159, squarinth 156 -> 169, grandbyrinth 154 -> 169, lbirinth 123.0 -> 123.6).  The ONE-TICK launch pays the sorting pass in its serial
+    // chain and loses on a map whose rays all meet a wall (lbirinth 90.5 -> 87.0; labyrinth 132.5 -> 139.1, the others + 1 - 2 %): it runs pooled unless practically no
+    // (cell, ray) row sampled around the spawn points is empty (lbirinth 0.008; labyrinth-inside 0.06, squarinth 0.22, grandbyrinth 0.27, labyrinth 0.41).
+    // CAT_POOL=1 / 0 forces both / neither.
     int pool_cap = 0, grp_rays = 4 * kLanes;
     double empty_rows = 0.0;
     {   // ... sampled where episodes start: five points of every spawn region (the JSON start position of an agent without regions), every ray
@@ -3717,9 +3724,9 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         }
         empty_rows = n_rows ? (double)n_empty / (double)n_rows : 0.0;
     }
-    bool want_pool = empty_rows >= kPoolEmptyRows;
-    if (const char *e = getenv("CAT_POOL")) want_pool = atoi(e) != 0;
-    if (fan == 1 && want_pool) {
+    bool want_ring = true, pool_step = empty_rows >= kPoolEmptyRows;
+    if (const char *e = getenv("CAT_POOL")) want_ring = pool_step = atoi(e) != 0;
+    if (fan == 1 && want_ring) {
         int cap = 64;
         while (cap < wpb * A * cfg->n_rays) cap *= 2;
         const int cpa = (cfg->n_rays + 63) / 64, gsz = cpa <= 2 ? 2 : 1;   // group_agents(): what reset_kernel's fan_group holds at once
@@ -3733,7 +3740,10 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         fprintf(stderr, "[cat_sim] contact rows: %zu cells, %.3f with a candidate, %.4f with more than 7 (CSR walk), %.4f with more than 15; longest %d\n", n, n ? (double)n0 / n : 0.0,
                 n ? (double)n7 / n : 0.0, n ? (double)n15 / n : 0.0, mx);
     }
-    if (getenv("CAT_VERBOSE")) fprintf(stderr, "[cat_sim] ray pool: %d entries (%s); rows without a candidate around the spawn points: %.3f\n", pool_cap, pool_cap ? "pooled fan kernels" : "unit form", empty_rows);
+    if (!pool_cap) pool_step = false;
+    if (getenv("CAT_VERBOSE"))
+        fprintf(stderr, "[cat_sim] ray pool: %d entries (resident launch: %s, one-tick launch: %s); rows without a candidate around the spawn points: %.3f\n", pool_cap,
+                pool_cap ? "pooled" : "unit form", pool_step ? "pooled" : "unit form", empty_rows);
     // ---- work list: workgroups are map-homogeneous; env slots grouped by map, padded with -1
     std::vector<int> work, block_map;
     int helpers = 0;   // CAT_HELPERS (diagnostic): that many waves of every workgroup own no env slot and only take work units
@@ -3863,7 +3873,8 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     p.pool_mask = pool_cap ? pool_cap - 1 : 0;
     s->wpb = wpb;
     s->lds_bytes = pool_cap ? (size_t)p.lds_pool_off + (size_t)pool_cap * 8 : ls.total(wpb);
-    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, pool_cap != 0, s->reset_fn, s->rollout_fn, s->step_fn);
+    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, pool_cap != 0, pool_step, s->reset_fn, s->rollout_fn, s->step_fn);
+    s->pool_step = pool_step;
     if (s->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->step_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);

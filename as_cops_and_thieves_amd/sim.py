@@ -105,7 +105,9 @@ class CatSim:
     @property
     def rollout_kernel(self) -> str:
         """The kernel ``rollout_fused`` launches: "rollout_kernel", or "rollout_kernel_pooled" where cat_create chose the pooled ray fan."""
-        return "rollout_kernel_pooled" if self.one_tick_kernel.endswith("_pooled") else "rollout_kernel"
+        if hasattr(self._L, "cat_rollout_kernel"):
+            return self._L.cat_rollout_kernel(self._h).decode()
+        return "rollout_kernel"   # diagnostic builds of earlier sources
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream

@@ -190,9 +190,11 @@ int cat_arm_kernel_timing(cat_sim *sim, void *start_event, void *stop_event);
 
 /* Introspection */
 int cat_abi_version(void);
-/* Name of the kernel cat_step / cat_step_fused launch ("step_kernel": one tick through the resident rollout's scheduler): what a
-   profile of the one-launch-per-tick path lists.  No reference counterpart. */
+/* Names of the kernels cat_step / cat_step_fused and cat_rollout_fused launch ("step_kernel" / "rollout_kernel": one tick / T ticks through the resident
+   scheduler; "step_kernel_pooled" / "rollout_kernel_pooled" where cat_create chose the pooled ray fan for that entry): what a profile lists.  No reference
+   counterpart. */
 const char *cat_one_tick_kernel(const cat_sim *sim);
+const char *cat_rollout_kernel(const cat_sim *sim);
 int cat_num_agents(const cat_sim *sim);
 int cat_num_shapes(const cat_sim *sim, int map_index);
 /* Timing hook for bench.py: seconds spent in the last n recorded step launches are measured by

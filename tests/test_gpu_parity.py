@@ -109,7 +109,8 @@ def test_pooled_and_unit_form_of_the_light_maps_fan(name, rays, cops, thieves, p
     gpu = CatSim(cfg, [m], device="cuda:0")
     if (cops, thieves) != (2, 2):   # (the four-agent roster only gets the pooled kernels if its ring fits the LDS left beside its larger env areas)
         assert gpu.one_tick_kernel == ("step_kernel_pooled" if pool == "1" else "step_kernel")
-    print(name, rays, cops, thieves, gpu.one_tick_kernel)
+        assert gpu.rollout_kernel == ("rollout_kernel_pooled" if pool == "1" else "rollout_kernel")
+    print(name, rays, cops, thieves, gpu.one_tick_kernel, gpu.rollout_kernel)
     cpu = OracleSim(cfg, [m])
     gpu.reset(); cpu.reset()
     rows = to_np(gpu.rollout_fused(50, None, tick=0, auto_reset=True))
@@ -124,6 +125,21 @@ def test_pooled_and_unit_form_of_the_light_maps_fan(name, rays, cops, thieves, p
     assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"{name} resident launch")
     assert gpu.device_errors() == 0
     gpu.close()
+
+
+def test_default_choice_of_the_scheduler_per_entry():
+    """Where the ring fits, cat_create gives the resident launch the pooled kernel on every map and the one-tick launch the pooled kernel unless practically every
+    ray around the spawn points meets a wall (lbirinth); a roster whose ring does not fit (3v2 at 64 rays) keeps the unit form for both."""
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.maps import load_preset
+    from as_cops_and_thieves_amd.sim import CatSim
+    want = {("labyrinth", 2, 1): ("step_kernel_pooled", "rollout_kernel_pooled"), ("squarinth", 2, 1): ("step_kernel_pooled", "rollout_kernel_pooled"),
+            ("lbirinth", 2, 1): ("step_kernel", "rollout_kernel_pooled"), ("grandbyrinth", 3, 2): ("step_kernel", "rollout_kernel"),
+            ("agh-map", 2, 1): ("step_kernel", "rollout_kernel")}
+    for (name, c, t), kernels in want.items():
+        sim = CatSim(SimConfig(n_envs=64, n_cops=c, n_thieves=t, n_rays=64, seed=1), [load_preset(name, c, t).compile()], device="cuda:0")
+        assert (sim.one_tick_kernel, sim.rollout_kernel) == kernels, (name, sim.one_tick_kernel, sim.rollout_kernel)
+        sim.close()
 
 
 @pytest.mark.parametrize("n_envs", [1, 5, 17])
