@@ -3413,6 +3413,14 @@ static const char *select_kernels(int A, int R, int n_cops, int fan, bool pool_r
             if (pool_step) step = step_kernel_pooled<WithFan<FixDims<3, 64, 2>, 1>>;
             return "3 agents (2 cops), 64 rays, pooled fan";
         }
+#ifndef CAT_QUICK_BUILD
+        if (!generic && A == 2 && n_cops == 1 && R == 90) {   // the reference's own defaults: 1v1 (simple_env.py), 90 rays (entity.py:86)
+            kernels_of<FixDims<2, 90, 1>>(fan, reset, rollout, step);
+            if (pool_roll) rollout = rollout_kernel_pooled<WithFan<FixDims<2, 90, 1>, 1>>;
+            if (pool_step) step = step_kernel_pooled<WithFan<FixDims<2, 90, 1>, 1>>;
+            return "2 agents (1 cop), 90 rays, pooled fan";
+        }
+#endif
         kernels_of<DynDims>(fan, reset, rollout, step);
         if (pool_roll) rollout = rollout_kernel_pooled<WithFan<DynDims, 1>>;
         if (pool_step) step = step_kernel_pooled<WithFan<DynDims, 1>>;
@@ -3421,6 +3429,7 @@ static const char *select_kernels(int A, int R, int n_cops, int fan, bool pool_r
     if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(fan, reset, rollout, step); return "3 agents (2 cops), 64 rays"; }
 #ifndef CAT_QUICK_BUILD   // diagnostic builds (tools/build_variant.sh -DCAT_QUICK_BUILD): the headline instantiation + the generic one only
     if (!generic && A == 3 && n_cops == 2 && R == 90) { kernels_of<FixDims<3, 90, 2>>(fan, reset, rollout, step); return "3 agents (2 cops), 90 rays"; }
+    if (!generic && A == 2 && n_cops == 1 && R == 90) { kernels_of<FixDims<2, 90, 1>>(fan, reset, rollout, step); return "2 agents (1 cop), 90 rays"; }
     if (!generic && A == 5 && n_cops == 3 && R == 64) { kernels_of<FixDims<5, 64, 3>>(fan, reset, rollout, step); return "5 agents (3 cops), 64 rays"; }
 #endif
     kernels_of<DynDims>(fan, reset, rollout, step);

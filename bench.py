@@ -146,6 +146,7 @@ EXTRA_WORKLOADS = (   # the other BASELINE.json shapes, measured in the same run
     ("five maps mixed 2v1 x16384 (configs[4])", dict(map="mixed", cops=2, thieves=1, envs=16384)),
     ("labyrinth 2v1 x4096, every agent spawned inside the maze", dict(map="labyrinth-inside", cops=2, thieves=1, envs=4096)),
     ("labyrinth 2v1 x4096 with the reference's own 90-ray sensor (entity.py:86)", dict(map="labyrinth", cops=2, thieves=1, envs=4096, rays=90)),
+    ("squarinth 1v1 x4096, 90 rays: the reference's own default roster, map and sensor (configs[0], batched)", dict(map="squarinth", cops=1, thieves=1, envs=4096, rays=90)),
 )
 
 
