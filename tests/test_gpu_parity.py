@@ -127,6 +127,38 @@ def test_pooled_and_unit_form_of_the_light_maps_fan(name, rays, cops, thieves, p
     gpu.close()
 
 
+@pytest.mark.parametrize("name,N", [("labyrinth", 4096), ("squarinth", 2048), ("lbirinth", 1024)])
+def test_pooled_and_unit_schedulers_agree_at_batch_size(name, N, monkeypatch):
+    """Beyond the sizes the oracle reaches in seconds: two sims of the same seed, one per scheduler, through 300 one-tick launches and one 200-tick resident
+    launch each (400-tick episodes would not end: max_step_count 120, so every slot resets twice) -- every output of every tick's last row and the whole state, bit for bit."""
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.sim import CatSim
+    cfg = SimConfig(n_envs=N, n_rays=64, max_step_count=120, seed=29)
+    m = compiled(name)
+    sims = []
+    for pool in ("1", "0"):
+        monkeypatch.setenv("CAT_POOL", pool)
+        sims.append(CatSim(cfg, [m], device="cuda:0"))
+    assert sims[0].one_tick_kernel == "step_kernel_pooled" and sims[1].one_tick_kernel == "step_kernel"
+    outs = []
+    for sim in sims:
+        sim.reset()
+        for t in range(300):
+            o = sim.step_fused(None, tick=t, auto_reset=True)
+        a = {k: v.clone() for k, v in o.items()}
+        rows = sim.rollout_fused(200, None, tick=300, auto_reset=True)
+        b = {k: v[-1].clone() for k, v in rows.items()}
+        outs.append((a, b, {k: v.clone() for k, v in sim.get_state().items()}, sim.device_errors()))
+    for part in range(3):
+        for k in outs[0][part]:
+            assert torch.equal(outs[0][part][k], outs[1][part][k]), (name, part, k)
+    assert outs[0][3] == 0 and outs[1][3] == 0
+    assert int(outs[0][2]["reset_count"].min()) >= 4
+    for sim in sims:
+        sim.close()
+
+
 def test_default_choice_of_the_scheduler_per_entry():
     """Where the ring fits, cat_create gives the resident launch the pooled kernel on every map and the one-tick launch the pooled kernel unless practically every
     ray around the spawn points meets a wall (lbirinth); a roster whose ring does not fit (3v2 at 64 rays) keeps the unit form for both."""
