@@ -124,8 +124,10 @@ struct Params {
     // LDS carve (bytes)
     int lds_map_bytes, lds_env_bytes, lds_union_bytes;
     int wpb;                // waves per workgroup (= blockDim.x / 64)
-    int lds_pool_off, pool_mask;   // ray pool of the *_pool kernels: byte offset in LDS, capacity - 1 (a power of two >= wpb * A * R); 0: no pool
+    int lds_pool_off, pool_mask;   // ray pool of the *_pooled kernels: byte offset in LDS, capacity - 1 (capacity >= wpb * A * R, even); 0: no pool
     int grp_rays;           // rays the arow / alist / adyn arrays of a scratch union hold (fan_group)
+    unsigned pool_magic; int pool_shift;   // ring position of entry i: i & pool_mask where the capacity is a power of two (pool_shift < 0), else i - capacity * (i / capacity)
+                                           // with the quotient by multiply-high and shifts (unsigned division by an invariant, computed by cat_create)
 };
 
 // Problem dimensions as seen by the device code: either read from the parameter block (DynDims) or compile-time
@@ -166,7 +168,9 @@ template <class D> __device__ __forceinline__ int group_agents(const Params &p)
     // a 2v1 roster in ONE unit: 40.3 us against 37.9 on the labyrinth x4096, 32.4 against 31.6 with the round-3 candidate table -- and
     // 106.9 against 110.4 at 16384 envs, where the launch is several workgroup rounds long; one agent per unit: 42.0.)
     const int cpa = (D::R(p) + 63) / 64;
-    return cpa <= 2 ? 2 : 1;
+    int g = cpa <= 2 ? 2 : 1;
+    if (g * cpa * kLanes > p.grp_rays) g = p.grp_rays / (cpa * kLanes);   // (a sim whose ring leaves the scratch unions room for one agent's chunks only)
+    return g;
 }
 // ... and in the scheduler kernels (step_kernel, rollout_kernel), for rosters whose rays fill more than four chunks: as many agents as fill four (3v2 at 64 rays:
 // units of 4 + 1 agents instead of 2 + 2 + 1).  With T ticks per launch the slots of a workgroup run out of phase and a slot needs
@@ -175,7 +179,7 @@ template <class D> __device__ __forceinline__ int group_agents(const Params &p)
 template <class D> __device__ __forceinline__ int group_agents_resident(const Params &p)
 {
     const int cpa = (D::R(p) + 63) / 64, most = cpa <= 4 ? 4 / cpa : 1;
-    return D::A(p) * cpa > 4 && most > group_agents<D>(p) ? most : group_agents<D>(p);
+    return D::A(p) * cpa > 4 && most > group_agents<D>(p) && most * cpa * kLanes <= p.grp_rays ? most : group_agents<D>(p);
 }
 // ray-fan work units of an env slot (gsz: agents per unit of the group form)
 template <class D> __device__ __forceinline__ int fan_units(const Params &p, int gsz)
@@ -2446,9 +2450,20 @@ constexpr int kSpinLimit = 1 << 22;   // a ring entry that never arrives / a los
 __device__ __forceinline__ int *pool_ctl(char *smem, const Params &p, int W) { return reinterpret_cast<int *>(smem + p.lds_map_bytes + 16 * W + kWgConstBytes - 8); }   // head, tail
 static_assert(sizeof(BlockDesc) <= kWgConstBytes - 8, "the pool counters live behind the BlockDesc");
 
+// entry index (free-running 32-bit counter) -> position in the ring.  kExact: the capacity is not a power of two (a compile-time property of the
+// kernel instantiation: with both paths behind a run-time test the headline shape lost 1 %)
+template <bool kExact>
+__device__ __forceinline__ int ring_pos(const Params &p, unsigned i)
+{
+    if constexpr (!kExact) return (int)(i & (unsigned)p.pool_mask);
+    const unsigned t = __umulhi(p.pool_magic, i);
+    const unsigned q = (t + ((i - t) >> 1)) >> p.pool_shift;
+    return (int)(i - q * (unsigned)(p.pool_mask + 1));
+}
+
 // The rays of one slot (its front just ran agent_setup): EMPTY observations for the candidate-less ones, ring entries for the others.
 // Returns the number of rays resolved here.  env: the slot's row of the output buffers (hit_shape only).
-template <class D>
+template <class D, bool kExact>
 __device__ __forceinline__ int pool_sort(const Lds &L, const Params &p, const LaunchArgs &la, const GridDesc &gd, long long env, int slot, int lane,
                                          int *pctl, unsigned long long *pool)
 {
@@ -2458,7 +2473,6 @@ __device__ __forceinline__ int pool_sort(const Lds &L, const Params &p, const La
     const int cpa = (R + kLanes - 1) / kLanes, nch = A * cpa;
     const int my_cell = lane < A ? L.acell[lane] : -1;
     const int my_dk0 = lane < A * A ? L.dk0[lane] : 0, my_dcnt = lane < A * A ? L.dcnt[lane] : 0;
-    const int pmask = p.pool_mask;
     int n_res = 0;
     for (int c0 = 0; c0 < nch; c0 += 4) {   // four chunks at a time: their packed rows are requested together
         unsigned wrow[4] = {0u, 0u, 0u, 0u};
@@ -2496,7 +2510,7 @@ __device__ __forceinline__ int pool_sort(const Lds &L, const Params &p, const La
                 }
                 if (act) {
                     const unsigned meta = kPoolValid | ((unsigned)slot << 24) | ((unsigned)i << 16) | (dynmask << 8) | (unsigned)k;
-                    __hip_atomic_store(&pool[(base + __popcll(m & lt_mask)) & pmask], ((unsigned long long)meta << 32) | rowv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&pool[ring_pos<kExact>(p, (unsigned)(base + __popcll(m & lt_mask)))], ((unsigned long long)meta << 32) | rowv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else if (in) {   // nothing along this ray: its observation is final
                     const int o = i * R + k;
                     L.od[o] = (unsigned short)d_empty;
@@ -2512,7 +2526,7 @@ __device__ __forceinline__ int pool_sort(const Lds &L, const Params &p, const La
 
 // One round: entries [base, base + n) of the ring, n <= 64, lane = entry.  L0: slot 0's view with the calling wave's scratch union.
 // Returns the mask of the slots whose tick this round completed.
-template <class D>
+template <class D, bool kExact>
 __device__ __forceinline__ unsigned pool_round(const Lds &L0, const Params &p, const LaunchArgs &la, int S, float cmax, int base, int n, int lane, int *ctrl,
                                unsigned long long *pool, PhaseClock &pc)
 {
@@ -2527,7 +2541,7 @@ __device__ __forceinline__ unsigned pool_round(const Lds &L0, const Params &p, c
     bool on = lane < n;
     unsigned w0 = 0u, meta = 0u;
     if (on) {   // the entry may still be on its way from the front that reserved it
-        unsigned long long *e = &pool[(base + lane) & p.pool_mask];
+        unsigned long long *e = &pool[ring_pos<kExact>(p, (unsigned)(base + lane))];
         unsigned long long v = 0ull;
         int spins = 0;
         do { v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (!(v >> 63) && ++spins < kSpinLimit);
@@ -2684,7 +2698,7 @@ __device__ __forceinline__ unsigned pool_round(const Lds &L0, const Params &p, c
     return done;
 }
 
-template <class D, bool kOneTick>
+template <class D, bool kOneTick, bool kExact>
 __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0, const LaunchArgs &la0)
 {
     extern __shared__ __align__(16) char smem[];
@@ -2754,7 +2768,7 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
             lds_release();
             if (lane == 0) __hip_atomic_store((unsigned *)&ctrl[4 * slot], rw_make(t + 1, n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             PHASE(pc, 3);
-            const int n_res = pool_sort<D>(Ls, p, la, K->gd, (long long)t * p.N + e_s, slot, lane, pool_ctl(smem, p, W), reinterpret_cast<unsigned long long *>(smem + p.lds_pool_off));
+            const int n_res = pool_sort<D, kExact>(Ls, p, la, K->gd, (long long)t * p.N + e_s, slot, lane, pool_ctl(smem, p, W), reinterpret_cast<unsigned long long *>(smem + p.lds_pool_off));
             lds_release();
             const int add = n_res + (n2 == 0 ? 1 : 0);
             int old = 0;
@@ -2844,7 +2858,7 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
             const BlockDesc *const K = block_desc_lds(smem, p, W);
             if (n > 0) {
                 const Lds L0 = carve<D>(p, smem, K->md, 0, wave);
-                wbm |= pool_round<D>(L0, p, la, uni(K->md.S), K->md.cmax, base, n, lane, ctrl, reinterpret_cast<unsigned long long *>(smem + p.lds_pool_off), pc);
+                wbm |= pool_round<D, kExact>(L0, p, la, uni(K->md.S), K->md.cmax, base, n, lane, ctrl, reinterpret_cast<unsigned long long *>(smem + p.lds_pool_off), pc);
             } else {
                 const Lds Ls = carve<D>(p, smem, K->md, slot, wave);
                 SSPREAD(slot, 2);
@@ -2865,15 +2879,15 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
     pc.flush(lane0);
 }
 
-template <class D>
+template <class D, bool kExact = false>
 __global__ __launch_bounds__(kMaxWaves *kLanes) void rollout_kernel_pooled(const Params *__restrict__ pp0, const LaunchArgs la0, const Prologue)
 {
-    rollout_body_pool<D, false>(pp0, la0);
+    rollout_body_pool<D, false, kExact>(pp0, la0);
 }
-template <class D>
+template <class D, bool kExact = false>
 __global__ __launch_bounds__(kMaxWaves *kLanes) void step_kernel_pooled(const Params *__restrict__ pp0, const LaunchArgs la0, const Prologue)
 {
-    rollout_body_pool<D, true>(pp0, la0);
+    rollout_body_pool<D, true, kExact>(pp0, la0);
 }
 
 template <class D>
@@ -3400,30 +3414,38 @@ template <class D> static void kernels_of(int fan, KernelFn &reset, KernelFn &ro
     else { reset = reset_kernel<WithFan<D, 0>>; rollout = rollout_kernel<WithFan<D, 0>>; step = step_kernel<WithFan<D, 0>>; }
 }
 // fan: 0 = chunk by chunk, 1 = agent groups with compacted rays (cat_create decides from the maps; CAT_FAN=chunks forces 0)
-// pool_roll / pool_step: the sim's rays fit a workgroup ring (cat_create) and the resident / the one-tick entry runs the pooled fan (instantiated for the
-// headline roster and generically)
-static const char *select_kernels(int A, int R, int n_cops, int fan, bool pool_roll, bool pool_step, KernelFn &reset, KernelFn &rollout, KernelFn &step)
+// pool_roll / pool_step: the sim's rays fit a workgroup ring (cat_create) and the resident / the one-tick entry runs the pooled fan; exact: the ring's capacity is not a
+// power of two.  Instantiated for 2v1 / 64 and 1v1 / 90 (power-of-two rings), 2v1 / 90 (exact) and generically in both forms.
+template <class D, bool kExact> static void pooled_of(bool pool_roll, bool pool_step, KernelFn &rollout, KernelFn &step)
+{
+    if (pool_roll) rollout = rollout_kernel_pooled<WithFan<D, 1>, kExact>;
+    if (pool_step) step = step_kernel_pooled<WithFan<D, 1>, kExact>;
+}
+static const char *select_kernels(int A, int R, int n_cops, int fan, bool pool_roll, bool pool_step, bool exact, KernelFn &reset, KernelFn &rollout, KernelFn &step)
 {
     const char *e = getenv("CAT_GENERIC_KERNEL");
     const bool generic = e && atoi(e) != 0;
     if ((pool_roll || pool_step) && fan == 1) {
-        if (!generic && A == 3 && n_cops == 2 && R == 64) {
+        if (!generic && A == 3 && n_cops == 2 && R == 64 && !exact) {
             kernels_of<FixDims<3, 64, 2>>(fan, reset, rollout, step);
-            if (pool_roll) rollout = rollout_kernel_pooled<WithFan<FixDims<3, 64, 2>, 1>>;
-            if (pool_step) step = step_kernel_pooled<WithFan<FixDims<3, 64, 2>, 1>>;
+            pooled_of<FixDims<3, 64, 2>, false>(pool_roll, pool_step, rollout, step);
             return "3 agents (2 cops), 64 rays, pooled fan";
         }
 #ifndef CAT_QUICK_BUILD
-        if (!generic && A == 2 && n_cops == 1 && R == 90) {   // the reference's own defaults: 1v1 (simple_env.py), 90 rays (entity.py:86)
+        if (!generic && A == 3 && n_cops == 2 && R == 90 && exact) {
+            kernels_of<FixDims<3, 90, 2>>(fan, reset, rollout, step);
+            pooled_of<FixDims<3, 90, 2>, true>(pool_roll, pool_step, rollout, step);
+            return "3 agents (2 cops), 90 rays, pooled fan";
+        }
+        if (!generic && A == 2 && n_cops == 1 && R == 90 && !exact) {   // the reference's own defaults: 1v1 (simple_env.py), 90 rays (entity.py:86)
             kernels_of<FixDims<2, 90, 1>>(fan, reset, rollout, step);
-            if (pool_roll) rollout = rollout_kernel_pooled<WithFan<FixDims<2, 90, 1>, 1>>;
-            if (pool_step) step = step_kernel_pooled<WithFan<FixDims<2, 90, 1>, 1>>;
+            pooled_of<FixDims<2, 90, 1>, false>(pool_roll, pool_step, rollout, step);
             return "2 agents (1 cop), 90 rays, pooled fan";
         }
 #endif
         kernels_of<DynDims>(fan, reset, rollout, step);
-        if (pool_roll) rollout = rollout_kernel_pooled<WithFan<DynDims, 1>>;
-        if (pool_step) step = step_kernel_pooled<WithFan<DynDims, 1>>;
+        if (exact) pooled_of<DynDims, true>(pool_roll, pool_step, rollout, step);
+        else pooled_of<DynDims, false>(pool_roll, pool_step, rollout, step);
         return "generic, pooled fan";
     }
     if (!generic && A == 3 && n_cops == 2 && R == 64) { kernels_of<FixDims<3, 64, 2>>(fan, reset, rollout, step); return "3 agents (2 cops), 64 rays"; }
@@ -3736,12 +3758,19 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     bool want_ring = true, pool_step = empty_rows >= kPoolEmptyRows;
     if (const char *e = getenv("CAT_POOL")) want_ring = pool_step = atoi(e) != 0;
     if (fan == 1 && want_ring) {
-        int cap = 64;
-        while (cap < wpb * A * cfg->n_rays) cap *= 2;
-        const int cpa = (cfg->n_rays + 63) / 64, gsz = cpa <= 2 ? 2 : 1;   // group_agents(): what reset_kernel's fan_group holds at once
-        const int g2 = kLanes * std::min(4, std::min(A, gsz) * cpa);
-        const LdsSizes l2 = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, true, g2);
-        if (cap <= 4096 && A <= 8 && cfg->n_rays <= 256 && wpb <= 16 && l2.total(wpb) + 16 + (size_t)cap * 8 <= 160 * 1024) { pool_cap = cap; grp_rays = g2; ls = l2; }
+        // capacity: the next power of two (ring position by a mask), else wpb * A * R + 64 entries exactly (position by an invariant division); group
+        // arrays of the scratch unions: what group_agents() holds at once (two agents up to 128 rays each), else one agent's chunks
+        int cap2 = 64;
+        while (cap2 < wpb * A * cfg->n_rays) cap2 *= 2;
+        const int cap_x = (wpb * A * cfg->n_rays + 64 + 1) / 2 * 2;
+        const int cpa = (cfg->n_rays + 63) / 64, gsz = cpa <= 2 ? 2 : 1;
+        const int g_full = kLanes * std::min(4, std::min(A, gsz) * cpa), g_one = kLanes * std::min(4, cpa);
+        const bool ok_dims = A <= 8 && cfg->n_rays <= 256 && wpb <= 16 && cpa <= 4;
+        for (int attempt = 0; ok_dims && attempt < 3 && !pool_cap; attempt++) {
+            const int cap = attempt == 0 ? cap2 : cap_x, g2 = attempt < 2 ? g_full : g_one;
+            const LdsSizes l2 = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, true, g2);
+            if (l2.total(wpb) + 16 + (size_t)cap * 8 <= 160 * 1024) { pool_cap = cap; grp_rays = g2; ls = l2; }
+        }
     }
     if (getenv("CAT_VERBOSE")) {   // contact-candidate rows (agent_setup): how many cells overflow the packed row of seven
         size_t n = 0, n0 = 0, n7 = 0, n15 = 0; int mx = 0;
@@ -3751,8 +3780,8 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     }
     if (!pool_cap) pool_step = false;
     if (getenv("CAT_VERBOSE"))
-        fprintf(stderr, "[cat_sim] ray pool: %d entries (resident launch: %s, one-tick launch: %s); rows without a candidate around the spawn points: %.3f\n", pool_cap,
-                pool_cap ? "pooled" : "unit form", pool_step ? "pooled" : "unit form", empty_rows);
+        fprintf(stderr, "[cat_sim] ray pool: %d entries, group arrays for %d rays (resident launch: %s, one-tick launch: %s); rows without a candidate around the spawn points: %.3f\n", pool_cap,
+                grp_rays, pool_cap ? "pooled" : "unit form", pool_step ? "pooled" : "unit form", empty_rows);
     // ---- work list: workgroups are map-homogeneous; env slots grouped by map, padded with -1
     std::vector<int> work, block_map;
     int helpers = 0;   // CAT_HELPERS (diagnostic): that many waves of every workgroup own no env slot and only take work units
@@ -3880,9 +3909,16 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     p.grp_rays = grp_rays;
     p.lds_pool_off = pool_cap ? (int)((ls.total(wpb) + 15) / 16 * 16) : 0;
     p.pool_mask = pool_cap ? pool_cap - 1 : 0;
+    p.pool_magic = 0u; p.pool_shift = -1;
+    if (pool_cap && (pool_cap & (pool_cap - 1))) {   // not a power of two: floor(i / cap) = (t + ((i - t) >> 1)) >> shift with t = mulhi(magic, i)  [Granlund & Montgomery]
+        int l = 0;
+        while ((1u << l) < (unsigned)pool_cap) l++;
+        p.pool_magic = (unsigned)((((unsigned long long)1 << 32) * ((1ull << l) - (unsigned long long)pool_cap)) / (unsigned long long)pool_cap + 1ull);
+        p.pool_shift = l - 1;
+    }
     s->wpb = wpb;
     s->lds_bytes = pool_cap ? (size_t)p.lds_pool_off + (size_t)pool_cap * 8 : ls.total(wpb);
-    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, pool_cap != 0, pool_step, s->reset_fn, s->rollout_fn, s->step_fn);
+    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, pool_cap != 0, pool_step, p.pool_shift >= 0, s->reset_fn, s->rollout_fn, s->step_fn);
     s->pool_step = pool_step;
     if (s->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->step_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);

@@ -89,7 +89,8 @@ def test_chunk_form_of_the_ray_fan_on_the_light_maps(name, rays, monkeypatch):
 
 
 @pytest.mark.parametrize("name,rays,cops,thieves,pool", [("labyrinth", 64, 2, 1, "0"), ("lbirinth", 64, 2, 1, "1"), ("squarinth", 64, 2, 1, "1"),
-                                                         ("squarinth", 90, 1, 1, "1"), ("grandbyrinth", 48, 2, 2, "1")])
+                                                         ("squarinth", 90, 1, 1, "1"), ("grandbyrinth", 48, 2, 2, "1"), ("labyrinth", 90, 2, 1, "0"),
+                                                         ("lbirinth", 90, 2, 1, "1")])
 def test_pooled_and_unit_form_of_the_light_maps_fan(name, rays, cops, thieves, pool, monkeypatch):
     """Where the rays of a workgroup fit an LDS ring (wpb * A * R <= 4096) cat_create picks between two schedulers of the group form: fan
     units of a slot's own rays (step_kernel / rollout_kernel), or one pool of the active rays of ALL slots from which any wave takes rounds
@@ -167,9 +168,12 @@ def test_default_choice_of_the_scheduler_per_entry():
     from as_cops_and_thieves_amd.sim import CatSim
     want = {("labyrinth", 2, 1): ("step_kernel_pooled", "rollout_kernel_pooled"), ("squarinth", 2, 1): ("step_kernel_pooled", "rollout_kernel_pooled"),
             ("lbirinth", 2, 1): ("step_kernel", "rollout_kernel_pooled"), ("grandbyrinth", 3, 2): ("step_kernel", "rollout_kernel"),
+            ("labyrinth", 2, 1, 90): ("step_kernel_pooled", "rollout_kernel_pooled"),   # a ring of exactly wpb * A * R + 64 entries (no power of two fits)
             ("agh-map", 2, 1): ("step_kernel", "rollout_kernel")}
-    for (name, c, t), kernels in want.items():
-        sim = CatSim(SimConfig(n_envs=64, n_cops=c, n_thieves=t, n_rays=64, seed=1), [load_preset(name, c, t).compile()], device="cuda:0")
+    for key, kernels in want.items():
+        name, c, t = key[:3]
+        rays = key[3] if len(key) > 3 else 64
+        sim = CatSim(SimConfig(n_envs=64, n_cops=c, n_thieves=t, n_rays=rays, seed=1), [load_preset(name, c, t).compile()], device="cuda:0")
         assert (sim.one_tick_kernel, sim.rollout_kernel) == kernels, (name, sim.one_tick_kernel, sim.rollout_kernel)
         sim.close()
 
