@@ -34,6 +34,7 @@
 #include <thread>
 #include <type_traits>
 #include <sched.h>
+#include <string>
 #include <vector>
 
 #include "cat_sim.h"
@@ -140,7 +141,6 @@ struct DynDims {
     static __device__ __forceinline__ int R(const Params &p) { return p.R; }
     static __device__ __forceinline__ int n_cops(const Params &p) { return p.n_cops; }
     static __device__ __forceinline__ int NP(const Params &p) { return p.NP; }
-    static __device__ __forceinline__ int maxc(const Params &p) { return p.maxc; }
     static __device__ __forceinline__ int rec_bytes(const Params &p) { return p.rec_bytes; }
     static __device__ __forceinline__ int hot_bytes(const Params &p) { return p.hot_bytes; }
 };
@@ -152,7 +152,6 @@ template <int TA, int TR, int TC> struct FixDims {
     static __device__ __forceinline__ constexpr int R(const Params &) { return TR; }
     static __device__ __forceinline__ constexpr int n_cops(const Params &) { return TC; }
     static __device__ __forceinline__ constexpr int NP(const Params &) { return kNP; }
-    static __device__ __forceinline__ constexpr int maxc(const Params &) { return TA * CAT_WALL_CACHE + kNP; }
     static __device__ __forceinline__ constexpr int rec_bytes(const Params &) { return kHotBytes + kColdBytes; }
     static __device__ __forceinline__ constexpr int hot_bytes(const Params &) { return kHotBytes; }
 };
@@ -390,8 +389,7 @@ struct Lds {
     char *rec;      // the env's state record (same layout as in HBM)
     unsigned short *sd;  // [2R] team-shared distance (staged for wide stores)
     unsigned char *st;   // [2R] team-shared type
-    double *conf;   // [maxc][12]
-    int *coni;      // [maxc][4]
+    double *conf;   // [maxc] contact records of kConD doubles: 12 doubles, then four ints (physics_env)
     const double *rayd;  // [R][2]  ray offsets (workgroup-shared)
     int *acell, *anear;     // [A], [A][2]  grid cell and "origin inside" wall ids per agent
     int *dk0, *dcnt;        // [A*A]  ray cone (start, count | near << 16) of agent j seen from agent i
@@ -1482,8 +1480,11 @@ __device__ int circle_poly_contact(const Lds &L, int sh, double rp, double cx, d
     return 1;
 }
 
-// contact record in LDS: conf[q*12 + ..] = nx ny r1x r1y r2x r2y nMass bias jBias jnAcc bounce -
-//                        coni[q*4 + ..] = a b first cache_index (wall: i*K+slot, pair: 1<<20 | pi)
+// contact record q in LDS, kConD doubles at conf + kConD * q: nx ny r1x r1y r2x r2y nMass bias jBias jnAcc bounce - | (ints) a b first cache_index
+// (wall: i*K+slot, pair: 1<<20 | pi).  One record per contact, so the carve needs no contact count; Params::maxc (what cat_create proves possible for
+// the sim's maps: agents x the deepest overlap of wall bbs an agent's bb can reach, + agent pairs) sizes the array, and a contact beyond it -- never
+// on a map cat_create accepted -- is dropped and flagged (CAT_DEVERR_CONTACT_DROPPED) instead of written.
+constexpr int kConD = 14;
 // [CP cpSpaceStep] for one env.  Executed wave-uniformly (every lane computes the same values and
 // stores them to the same LDS words) except the bb-overlap test, where lanes stride the walls.
 template <class D>
@@ -1546,6 +1547,7 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
                 m &= m - 1;
                 double nx, ny, p1x, p1y, p2x, p2y;
                 if (!circle_poly_contact(L, sh, p.wall_r, cx, cy, rc, lane, nx, ny, p1x, p1y, p2x, p2y)) continue;
+                if (nc >= p.maxc) { if (lane == 0) atomicOr(p.err_word, CAT_DEVERR_CONTACT_DROPPED); continue; }   // (the contact array is full: see kConD)
                 // arbiter cache lookup [CP cpSpaceCollideShapes / cpArbiterUpdate]: lanes = the agent's slots
                 const bool mine = lane >= i * kK && lane < (i + 1) * kK;
                 const int cur = mine ? L.wsh[lane] : -2;
@@ -1570,8 +1572,8 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
                     L.wsh[i * kK + slot] = sh; L.wjn[i * kK + slot] = 0.0; L.wag[i * kK + slot] = 0;
                 }
                 seen_w |= 1ull << (i * kK + slot);
-                double *cf = L.conf + 12 * nc;
-                int *ci = L.coni + 4 * nc;
+                double *cf = L.conf + kConD * nc;
+                int *ci = reinterpret_cast<int *>(cf + 12);
                 cf[0] = nx; cf[1] = ny;
                 cf[2] = p1x - L.pos[2 * i]; cf[3] = p1y - L.pos[2 * i + 1];
                 cf[4] = p2x - 0.0; cf[5] = p2y - 0.0;
@@ -1603,6 +1605,7 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
             double dx = L.tc[2 * j] - L.tc[2 * i], dy = L.tc[2 * j + 1] - L.tc[2 * i + 1];
             double distsq = dx * dx + dy * dy;
             if (!(distsq < mindist * mindist)) continue;
+            if (nc >= p.maxc) { if (lane == 0) atomicOr(p.err_word, CAT_DEVERR_CONTACT_DROPPED); continue; }
             double dist = sqrt(distsq);
             double nx = 1.0, ny = 0.0;
             if (dist != 0.0) { double inv = 1.0 / dist; nx = dx * inv; ny = dy * inv; }
@@ -1611,8 +1614,8 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
             if (page < 0) { first = 1; L.pjn[pi] = 0.0; }
             else first = page > 0;
             L.pag[pi] = 0; seen_p |= 1u << pi;
-            double *cf = L.conf + 12 * nc;
-            int *ci = L.coni + 4 * nc;
+            double *cf = L.conf + kConD * nc;
+            int *ci = reinterpret_cast<int *>(cf + 12);
             double p1x = L.tc[2 * i] + nx * rc, p1y = L.tc[2 * i + 1] + ny * rc;
             double p2x = L.tc[2 * j] + nx * (-rc), p2y = L.tc[2 * j + 1] + ny * (-rc);
             cf[0] = nx; cf[1] = ny;
@@ -1656,8 +1659,8 @@ __device__ void physics_env(const Lds &L, const Params &p, int S, int lane, Phas
     int ca = 0, cb = -1, cfirst = 1, cidx = 0;
     double nx = 0, ny = 0, nMass = 0, bias = 0, jBiasAcc = 0.0, jnAcc = 0, bounce = 0;
     if (own) {   // [CP cpArbiterPreStep]
-        const double *cf = L.conf + 12 * q;
-        const int *ci = L.coni + 4 * q;
+        const double *cf = L.conf + kConD * q;
+        const int *ci = reinterpret_cast<const int *>(cf + 12);
         ca = ci[0]; cb = ci[1]; cfirst = ci[2]; cidx = ci[3];
         nx = cf[0]; ny = cf[1]; jnAcc = cf[9];
         const double mib = (cb < 0) ? 0.0 : m_inv;
@@ -1758,7 +1761,6 @@ __device__ __forceinline__ Lds carve(const Params &p, char *smem, const MapDesc 
     // union: contact arrays (physics) / ray-fan scratch
     char *u = smem + p.lds_map_bytes + ctrl_bytes(W) + W * p.lds_env_bytes + wave * p.lds_union_bytes;
     L.conf = reinterpret_cast<double *>(u);
-    L.coni = reinterpret_cast<int *>(L.conf + 12 * D::maxc(p));
     L.itbb = reinterpret_cast<double *>(u);
     L.ialpha = L.itbb + kItemCap;
     L.itm = reinterpret_cast<unsigned short *>(L.ialpha + kItemCap);
@@ -2000,7 +2002,7 @@ __device__ __forceinline__ Params prologue_params(PrologueK pk, int &uniform)
     q.cop_lut = pk->cop_lut; q.thief_lut = pk->thief_lut;
     // ONE pin for all of them: the loads above are issued together and waited for once
     asm volatile("" : "+s"(q.lds_map_bytes), "+s"(q.lds_env_bytes), "+s"(q.lds_union_bytes), "+s"(q.wpb), "+s"(q.A), "+s"(q.R), "+s"(q.NP),
-                      "+s"(q.maxc), "+s"(q.n_cops), "+s"(q.rec_bytes), "+s"(q.hot_bytes), "+s"(q.N), "+s"(uniform), "+s"(q.lds_pool_off), "+s"(q.pool_mask), "+s"(q.grp_rays), "+s"(q.work_env), "+s"(q.block_desc), "+s"(q.state),
+                      "+s"(q.n_cops), "+s"(q.rec_bytes), "+s"(q.hot_bytes), "+s"(q.N), "+s"(uniform), "+s"(q.lds_pool_off), "+s"(q.pool_mask), "+s"(q.grp_rays), "+s"(q.work_env), "+s"(q.block_desc), "+s"(q.state),
                       "+s"(q.geo_f64), "+s"(q.geo_i32), "+s"(q.ray_dx), "+s"(q.ray_dy), "+s"(q.cop_lut), "+s"(q.thief_lut));
     return q;
 }
@@ -2446,7 +2448,11 @@ constexpr double kPoolEmptyRows = 0.05;   // cat_create: the pooled one-tick ker
 constexpr int kPoolRound = CAT_POOL_ROUND;            // rays of a full round
 constexpr int kPoolMinPartial = CAT_POOL_MIN_PARTIAL; // a wave with nothing else to do takes fewer than a full round only from this many on ...
 constexpr int kPoolPatience = CAT_POOL_PATIENCE;      // ... or after this many idle looks (fronts under way will add to the ring; the end of a launch drains it)
+#ifdef CAT_FAULT_INJECT
+constexpr int kSpinLimit = 1 << 14;   // the fault-injection build reaches its limits quickly
+#else
 constexpr int kSpinLimit = 1 << 22;   // a ring entry that never arrives / a lost wake-up: leave with CAT_DEVERR_SCHEDULER instead of hanging the device
+#endif
 __device__ __forceinline__ int *pool_ctl(char *smem, const Params &p, int W) { return reinterpret_cast<int *>(smem + p.lds_map_bytes + 16 * W + kWgConstBytes - 8); }   // head, tail
 static_assert(sizeof(BlockDesc) <= kWgConstBytes - 8, "the pool counters live behind the BlockDesc");
 
@@ -2500,7 +2506,7 @@ __device__ __forceinline__ int pool_sort(const Lds &L, const Params &p, const La
                         int rel = k - dk; if (rel < 0) rel += R;
                         if (rel < dc) dynmask |= 1u << j;
                     }
-                const bool act = rowv != 0u || dynmask != 0u;
+                bool act = rowv != 0u || dynmask != 0u;
                 const unsigned long long m = __ballot(act);
                 const int n = __popcll(m);
                 int base = 0;
@@ -2508,16 +2514,25 @@ __device__ __forceinline__ int pool_sort(const Lds &L, const Params &p, const La
                     if (lane == 0) base = __hip_atomic_fetch_add(&pctl[1], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     base = uni(base);
                 }
+                unsigned long long *const e = &pool[act ? ring_pos<kExact>(p, (unsigned)(base + __popcll(m & lt_mask))) : 0];
+#ifdef CAT_FAULT_INJECT   // diagnostic build only (tests/test_gpu_fault_injection.py): the first entry of slot 0 is reserved and never written
+                if (slot == 0 && c0 + q == 0 && n && lane == (int)__builtin_ctzll(m)) act = false;
+#endif
+                // The ring holds at most wpb * A * R entries that are not yet counted, but an entry counts as read only once the wave that claimed its
+                // round has loaded it: the position must read 0 (cleared by that reader) before a new entry goes there.  True at the first look in every
+                // run observed; the wait makes it an invariant instead of a matter of timing (bounded like every wait of the scheduler).
+                for (int spins = 0; __ballot(act && __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0ull) != 0ull;)
+                    if (++spins >= kSpinLimit) { if (lane == 0) atomicOr(p.err_word, CAT_DEVERR_SCHEDULER); break; }
                 if (act) {
                     const unsigned meta = kPoolValid | ((unsigned)slot << 24) | ((unsigned)i << 16) | (dynmask << 8) | (unsigned)k;
-                    __hip_atomic_store(&pool[ring_pos<kExact>(p, (unsigned)(base + __popcll(m & lt_mask)))], ((unsigned long long)meta << 32) | rowv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else if (in) {   // nothing along this ray: its observation is final
+                    __hip_atomic_store(e, ((unsigned long long)meta << 32) | rowv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (in && (rowv == 0u && dynmask == 0u)) {   // nothing along this ray: its observation is final
                     const int o = i * R + k;
                     L.od[o] = (unsigned short)d_empty;
                     L.ot[o] = (unsigned char)CAT_EMPTY;
                     if (la.out.hit_shape) la.out.hit_shape[(size_t)env * A * R + o] = -1;  // parity/debug only
                 }
-                n_res += __popcll(__ballot(in && !act));
+                n_res += __popcll(__ballot(in && (rowv == 0u && dynmask == 0u)));
             }
         }
     }
@@ -2749,6 +2764,10 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
     unsigned todo = env >= 0 ? 1u << wave : 0u;   // slots whose next front this wave is to run (their tick: ctrl word 2)
     unsigned wbm = 0u;                             // slots whose tick this wave completed: it writes them back
     int hint = wave, idle = 0;
+    // watchdog of the idle loop: looks in a row during which NOTHING in the workgroup moved (ring head and tail, every slot's claim word).  A resident
+    // launch may legitimately run for seconds (T up to 65536); a wave with nothing to take is stuck only if nobody else makes progress either.
+    int stall = 0, moved_sig = 0;
+    unsigned w_seen = 0u;
     for (;;) {
         while (todo) {   // ---- the serial front of a slot, its rays into the ring, its Space.step published
             const int lane = opaque_v(lane0);
@@ -2773,8 +2792,8 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
             const int add = n_res + (n2 == 0 ? 1 : 0);
             int old = 0;
             if (lane == 0) old = __hip_atomic_fetch_add(&ctrl[4 * slot + 1], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (uni(old) + add == D::A(p) * D::R(p) + 1) wbm |= 1u << slot;
-            hint = slot;
+            if (add > 0 && uni(old) + add == D::A(p) * D::R(p) + 1) wbm |= 1u << slot;   // only a party that counted something can complete the tick (add == 0: the
+            hint = slot;                                                                     // wave that counted the last ray or the Space.step has seen the total already)
             WSPREAD(2); SSPREAD(slot, 1);
         }
 #ifdef CAT_WB_COUNTS   // diagnostic build: how many slot ticks a wave completes at once (cat_debug_wb_counts)
@@ -2841,7 +2860,13 @@ __device__ __forceinline__ void rollout_body_pool(const Params *__restrict__ pp0
                 // nothing to take: leave when nothing can come any more -- every slot has finished its T ticks; with one tick per launch, when
                 // every slot HAS published (its rays are in rounds under way on other waves, which write it back)
                 if (avail == 0 && __ballot(kOneTick ? (w_l == 0u) : (w_l != kRwFinished)) == 0ull) break;   // (a remainder below kPoolMinPartial is taken after kPoolPatience looks)
-                if (++idle > kSpinLimit) { if (lane == 0) atomicOr(p.err_word, CAT_DEVERR_SCHEDULER); break; }   // never in a correct run
+                ++idle;
+                {
+                    const bool moved = __ballot(w_l != w_seen) != 0ull || hd + tl != moved_sig;   // head and tail only grow: their sum changes with either
+                    w_seen = w_l; moved_sig = hd + tl;
+                    stall = moved ? 0 : stall + 1;
+                }
+                if (stall > kSpinLimit) { if (lane == 0) atomicOr(p.err_word, CAT_DEVERR_SCHEDULER); break; }   // never in a correct run
                 __builtin_amdgcn_s_sleep(4);
                 PHASE(pc, 21);
                 continue;
@@ -3437,6 +3462,11 @@ static const char *select_kernels(int A, int R, int n_cops, int fan, bool pool_r
             pooled_of<FixDims<3, 90, 2>, true>(pool_roll, pool_step, rollout, step);
             return "3 agents (2 cops), 90 rays, pooled fan";
         }
+        if (!generic && A == 5 && n_cops == 3 && R == 64 && exact) {    // BASELINE configs[3]: the ring fits since the contact arrays are sized by the map
+            kernels_of<FixDims<5, 64, 3>>(fan, reset, rollout, step);
+            pooled_of<FixDims<5, 64, 3>, true>(pool_roll, pool_step, rollout, step);
+            return "5 agents (3 cops), 64 rays, pooled fan";
+        }
         if (!generic && A == 2 && n_cops == 1 && R == 90 && !exact) {   // the reference's own defaults: 1v1 (simple_env.py), 90 rays (entity.py:86)
             kernels_of<FixDims<2, 90, 1>>(fan, reset, rollout, step);
             pooled_of<FixDims<2, 90, 1>, false>(pool_roll, pool_step, rollout, step);
@@ -3463,14 +3493,14 @@ struct LdsSizes {
     int map, env, uni;
     size_t total(int wpb) const { return (size_t)map + (size_t)ctrl_bytes(wpb) + (size_t)wpb * ((size_t)env + (size_t)uni); }
 };
-static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool group_fan, int grp_rays = 4 * 64)
+static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool group_fan, int maxc, int grp_rays = 4 * 64)
 {
     auto up = [](int x, int a) { return (x + a - 1) / a * a; };
-    const int NP = A * (A - 1) / 2, NPs = NP > 0 ? NP : 1, maxc = A * kK + NP;
+    const int NP = A * (A - 1) / 2, NPs = NP > 0 ? NP : 1;
     LdsSizes z;
     const int rest = CAT_EDGE_PAIRS ? 8 * maxP + (kPairF / 2) * maxPP : kGeoPerPlane * maxP;
     z.map = up((kBB * maxS + rest) * 8 + 2 * maxS * 4, 16) + 16 * R;
-    const int phys_bytes = 12 * maxc * 8 + 4 * maxc * 4;
+    const int phys_bytes = kConD * 8 * maxc;   // contact records (physics_env)
     const int cpa = (R + 63) / 64;
     const int fan_bytes = kFanBytes + (group_fan ? grp_rays * (4 + 1 + 1) : 0);   // the rays of an agent group (four chunks unless the ray pool needs the LDS): arow, alist, adyn
     (void)cpa;
@@ -3483,22 +3513,49 @@ static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool grou
     return z;
 }
 
-struct cat_sim {
-    GridHost grid;
+// The env slots of a sim whose maps take one form of the ray fan: their candidate tables, parameter block, LDS carve, work list and kernels -- one
+// dispatch per entry.  A sim has one part, or two when its maps want both forms (cat_create).
+struct Part {
+    GridHost grid;                 // grid.desc[k] belongs to map map_ids[k] of the sim
+    std::vector<int> map_ids;
     Params p;
-    Params *dev_p;
-    int device;
-    int n_blocks, wpb;
+    Params *dev_p = nullptr;
     Prologue pro;
+    int n_blocks = 0, wpb = 0, n_envs = 0;
+    size_t lds_bytes = 0;
     bool pool_step = false;   // the one-tick entry runs the pooled kernel (the resident one does whenever the ring exists: p.pool_mask)
     KernelFn reset_fn = nullptr, rollout_fn = nullptr, step_fn = nullptr;   // the instantiations matching (agents, rays, cops): cat_reset*, cat_rollout_fused, cat_step*
     const char *kernel_variant = "";
+};
+
+struct cat_sim {
+    std::vector<Part> parts;
+    int device;
+    hipStream_t side = nullptr;                       // two parts: the second one's stream ...
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // ... forked from and joined to the caller's
     hipEvent_t t_start = nullptr, t_stop = nullptr;   // cat_arm_kernel_timing
-    size_t lds_bytes;
     std::vector<MapDesc> maps;
     std::vector<void *> allocs;
+    std::string one_tick_name, rollout_name;
     char err[256];
 };
+
+// the tables of one map (a GridHost of its own, as build_grids leaves it) appended to a part's
+static void append_grid(GridHost &g, const GridHost &m)
+{
+    GridDesc d = m.desc[0];
+    d.off_base = (int)g.off.size(); d.ent_base = (int)g.ent.size();
+    d.coff_base = (int)g.coff.size(); d.cent_base = (int)g.cent.size();
+    d.crow_base = (int)g.crows.size();
+    g.off.insert(g.off.end(), m.off.begin(), m.off.end());
+    g.ent.insert(g.ent.end(), m.ent.begin(), m.ent.end());
+    g.coff.insert(g.coff.end(), m.coff.begin(), m.coff.end());
+    g.cent.insert(g.cent.end(), m.cent.begin(), m.cent.end());
+    g.crows.insert(g.crows.end(), m.crows.begin(), m.crows.end());
+    g.desc.push_back(d);
+    g.rows_of.push_back(m.rows_of[0]);
+    if (m.max_row > g.max_row) g.max_row = m.max_row;
+}
 
 #define HIP_TRY(sim, expr)                                                                     \
     do {                                                                                       \
@@ -3523,10 +3580,11 @@ static int dev_alloc(cat_sim *s, T **ptr, size_t count, const void *init)
 }
 
 extern "C" int cat_abi_version(void) { return CAT_ABI_VERSION; }
-extern "C" const char *cat_one_tick_kernel(const cat_sim *sim) { return sim ? (sim->pool_step ? "step_kernel_pooled" : "step_kernel") : ""; }
-extern "C" const char *cat_rollout_kernel(const cat_sim *sim) { return sim ? (sim->p.pool_mask ? "rollout_kernel_pooled" : "rollout_kernel") : ""; }
+// (a sim of two parts: both names, "+"-joined, the group-form part first)
+extern "C" const char *cat_one_tick_kernel(const cat_sim *sim) { return sim ? sim->one_tick_name.c_str() : ""; }
+extern "C" const char *cat_rollout_kernel(const cat_sim *sim) { return sim ? sim->rollout_name.c_str() : ""; }
 extern "C" const char *cat_last_error(const cat_sim *sim) { return sim ? sim->err : g_create_err; }
-extern "C" int cat_num_agents(const cat_sim *sim) { return sim ? sim->p.A : CAT_ERR_BAD_ARG; }
+extern "C" int cat_num_agents(const cat_sim *sim) { return sim ? sim->parts[0].p.A : CAT_ERR_BAD_ARG; }
 extern "C" int cat_num_shapes(const cat_sim *sim, int m)
 {
     if (!sim || m < 0 || m >= (int)sim->maps.size()) return CAT_ERR_BAD_ARG;
@@ -3554,9 +3612,9 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
     }
     // ---- parse blobs into one packed geometry buffer
     std::vector<MapDesc> descs((size_t)n_maps);
+    std::vector<int> wall_depth((size_t)n_maps, 0);   // per map: the most wall bbs one agent's bb can overlap at once (max_wall_bb_depth)
     std::vector<double> geo_f;
     std::vector<int> geo_i;
-    int maxS = 0, maxP = 0, maxPP = 0;
     for (int m = 0; m < n_maps; m++) {
         const unsigned char *b = static_cast<const unsigned char *>(blobs[m]);
         int32_t h[16];
@@ -3584,6 +3642,7 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
             // bb overlap is a loose bound on simultaneous CONTACTS (slanted or star-shaped walls overlap boxes without touching):
             // CAT_ALLOW_DEEP_WALL_OVERLAP=1 accepts such a map, with CAT_DEVERR_CONTACT_DROPPED as the run-time check
             const int depth = max_wall_bb_depth(f.data() + 2, d.S, cfg->agent_radius);
+            wall_depth[(size_t)m] = depth;
             const char *allow = getenv("CAT_ALLOW_DEEP_WALL_OVERLAP");
             if (depth > CAT_WALL_CACHE && !(allow && atoi(allow) != 0)) {
                 snprintf(g_create_err, sizeof g_create_err, "map blob %d: an agent can touch the bounding boxes of %d walls at once; the state record "
@@ -3639,9 +3698,6 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
         geo_i.insert(geo_i.end(), first_pair.begin(), first_pair.end());   // [first S][count S][region_off A+1][first pair S]
         if (geo_f.size() & 1) geo_f.push_back(0.0);  // keep 16-byte alignment of each map's base
         descs[m] = d;
-        maxS = d.S > maxS ? d.S : maxS;
-        maxP = d.P > maxP ? d.P : maxP;
-        maxPP = d.PP > maxPP ? d.PP : maxPP;
     }
     const int N = cfg->n_envs;
     std::vector<int> slot((size_t)N, 0);
@@ -3652,8 +3708,9 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
             return CAT_ERR_BAD_SLOT_MAP;
         }
     }
-    // ---- spatial-hash grids per map (cell size: CAT_GRID_CELL px, default 8); their longest candidate list picks the ray fan
-    GridHost grid_host;
+    // ---- spatial-hash grids, one GridHost per map first (cell size: CAT_GRID_CELL px, default 4 ... while the table fits); a map's longest candidate
+    //      list decides which form of the ray fan can serve it
+    std::vector<GridHost> map_grid((size_t)n_maps);
     {
         // Cell size: the smaller the cell, the tighter the three listing rules (agh-map, entries per ray: 16 px 2.1, 8 px 1.56, 4 px 1.35,
         // 2 px: kernel 64.6 -> 63.2 us for four times the table) and the larger the table (rows of 4 - 8 B per cell and ray: labyrinth
@@ -3677,277 +3734,340 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
                 }
             }
             build_grids(geo_f.data() + descs[m].f64_off, descs[m].S, cfg->n_rays, tab->ray_dx, tab->ray_dy, reach, cfg->bbtree_gate != 0,
-                        cfg->ray_radius + 2e-6, cell, grid_host, geo_i.data() + descs[m].i32_off, geo_i.data() + descs[m].i32_off + descs[m].S,
+                        cfg->ray_radius + 2e-6, cell, map_grid[(size_t)m], geo_i.data() + descs[m].i32_off, geo_i.data() + descs[m].i32_off + descs[m].S,
                         cfg->wall_radius + cfg->ray_radius, cfg->ray_radius);
         }
     }
-    // Rays that meet few walls (every list fits a four-byte row -- the labyrinth's six walls of 5 bits --; ids and agents fit 6 bits; an agent's rays fit four chunks):
-    // the group form of the ray fan, which compacts the rays that have any candidate across the agents of a group.  Else chunk by chunk.
-    int id_bits = 1;   // bits of a wall id + 1
-    while ((1 << id_bits) <= maxS) id_bits++;
-    int fan = (grid_host.max_row <= 7 && grid_host.max_row * id_bits <= 32 && maxS + A <= 63 && cfg->n_rays <= kGroupRays) ? 1 : 0;
-    if (const char *e = getenv("CAT_FAN")) { if (!strcmp(e, "chunks")) fan = 0; }
-    // the group form reads four-byte rows; the chunk form eight-byte rows of the same fields where the longest list fits
-    // (agh-map: 9 walls of 7 bits), else byte rows of 8 / 16 / 32 bytes with the CSR continuation (CAT_GRID_FIELDS=0 forces those)
-    bool wide = fan == 0 && grid_host.max_row * id_bits <= 64;
-    if (const char *e = getenv("CAT_GRID_FIELDS")) { if (atoi(e) == 0) wide = false; }
-    finalize_rows(grid_host, (fan == 1 || wide) ? id_bits : 0, wide);
-    if (getenv("CAT_VERBOSE"))
-        fprintf(stderr, "[cat_sim] ray fan: %s form; longest candidate list %d; rows of %d bytes (%s); table %.1f MB\n", fan ? "group" : "chunk",
-                grid_host.max_row, fan ? 4 : 8 * grid_host.row_words, (fan || wide) ? "fields of wall id + 1" : "count byte + id bytes, CSR beyond",
-                grid_host.rows.size() * 8 / 1e6);
-    // ---- LDS carve sizes (must match carve()) and the workgroup size
-    LdsSizes ls = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, fan == 1);
-    int wpb = 0;
-    {   // waves (= env slots) per workgroup.  Most resident waves per CU first (cap 16 = 4 per SIMD at <= 128 VGPRs);
-        // among equals a launch of at most two rounds takes the LARGEST workgroup (its waves share ray chunks, which
-        // removes the lone-wave tail of a single round), a longer launch the SMALLEST (workgroups of a CU overlap
-        // each other's drain).  CAT_WAVES_PER_BLOCK overrides (tuning).
-        const int cu = 256;
-        int forced = 0;
-        if (const char *e = getenv("CAT_WAVES_PER_BLOCK")) forced = atoi(e);
-        int best_score = -1, best_w = 0;
-        if (forced >= 1 && forced <= kMaxWaves && ls.total(forced) <= 160 * 1024) wpb = forced;   // any size, also not a power of two
-        for (int w = 1; w <= kMaxWaves && wpb == 0; w *= 2) {
-            const size_t bytes = ls.total(w);
-            if (bytes > 160 * 1024) continue;
-            int resident = (int)((160 * 1024) / bytes) * w;
-            if (resident > 16) resident = 16;
-            const bool small_launch = (long long)N <= 2LL * 16 * cu;
-            if (resident > best_score || (resident == best_score && small_launch)) { best_score = resident; best_w = w; }
+    // ---- parts: the maps whose rays meet few walls (every candidate list fits a four-byte row -- the labyrinth's six walls of 5 bits --; shape ids and agents
+    //      fit 6 bits; an agent's rays fit four chunks) take the GROUP form of the ray fan (and its pooled kernels where the ring fits the LDS), every other map
+    //      the CHUNK form.  A sim whose maps want both runs in ONE part on the chunk form by default; CAT_SPLIT=1 cuts it in two parts -- each with its own
+    //      candidate tables, LDS carve, workgroup size, work list and kernels -- that every entry launches side by side on two streams.  Measured (round 5, five
+    //      maps x16384, us per tick one part -> two parts): one launch per tick 167.8 -> 185.6 (the two kernels do overlap -- 130 and 170 us inside a 182 us period by
+    //      the trace -- but a mixed batch costs the SUM of its workgroups' times either way, the pooled one-tick kernel gains + 1 - 2 % on three of the four box maps and
+    //      loses 4 % on lbirinth, and the fork / join events add 14 us between launches); resident T = 64 128.7 -> 127.8.  So the split is kept as a tested option, not
+    //      the default.  CAT_FAN=chunks forces the chunk form everywhere.
+    std::vector<std::vector<int>> part_maps;
+    std::vector<int> part_fan;
+    {
+        bool chunks_only = false, split = false;
+        if (const char *e = getenv("CAT_FAN")) chunks_only = !strcmp(e, "chunks");
+        if (const char *e = getenv("CAT_SPLIT")) split = atoi(e) != 0;
+        std::vector<int> light, dense;
+        for (int m = 0; m < n_maps; m++) (map_grid[(size_t)m].max_row <= 7 && cfg->n_rays <= kGroupRays && !chunks_only ? light : dense).push_back(m);
+        if (!light.empty()) {   // the four-byte row must hold the longest list of the part in fields of the part's id width
+            int S_l = 0, row_l = 0, idb = 1;
+            for (int m : light) { S_l = std::max(S_l, descs[m].S); row_l = std::max(row_l, map_grid[(size_t)m].max_row); }
+            while ((1 << idb) <= S_l) idb++;
+            if (!(row_l * idb <= 32 && S_l + A <= 63)) { dense.insert(dense.end(), light.begin(), light.end()); light.clear(); }
         }
-        if (wpb == 0) wpb = best_w;
-        if (wpb == 0) {
-            snprintf(g_create_err, sizeof g_create_err, "LDS budget exceeded: %zu bytes for one env slot", ls.total(1));
-            return CAT_ERR_BAD_CONFIG;
-        }
-    }
-    // ---- the workgroup's ray pool (step_kernel_pooled / rollout_kernel_pooled): a ring of wpb * A * R eight-byte entries beside the env areas, where it fits
-    // Where the ring fits, the RESIDENT launch always runs pooled (whole runs from the reset, tools/pool_soak.py, M env-steps/s unit -> pooled: labyrinth 201 -> 229,
-    // labyrinth-inside 148 -> 159, squarinth 156 -> 169, grandbyrinth 154 -> 169, lbirinth 123.0 -> 123.6).  The ONE-TICK launch pays the sorting pass in its serial
-    // chain and loses on a map whose rays all meet a wall (lbirinth 90.5 -> 87.0; labyrinth 132.5 -> 139.1, the others + 1 - 2 %): it runs pooled unless practically no
-    // (cell, ray) row sampled around the spawn points is empty (lbirinth 0.008; labyrinth-inside 0.06, squarinth 0.22, grandbyrinth 0.27, labyrinth 0.41).
-    // CAT_POOL=1 / 0 forces both / neither.
-    int pool_cap = 0, grp_rays = 4 * kLanes;
-    double empty_rows = 0.0;
-    {   // ... sampled where episodes start: five points of every spawn region (the JSON start position of an agent without regions), every ray
-        size_t n_rows = 0, n_empty = 0;
-        for (size_t m = 0; m < grid_host.desc.size(); m++) {
-            const MapDesc &md = descs[m];
-            const GridDesc &gd = grid_host.desc[m];
-            const double *start = geo_f.data() + md.f64_off + 4 * md.S + geo_rest_doubles(md), *regions = start + 2 * md.A;
-            const int *region_off = geo_i.data() + md.i32_off + 2 * md.S;
-            auto sample = [&](double x, double y) {
-                const int cx = (int)floor((x - gd.x0) * gd.inv_cell), cy = (int)floor((y - gd.y0) * gd.inv_cell);
-                if (cx < 0 || cy < 0 || cx >= gd.nx || cy >= gd.ny) return;
-                const size_t r0 = (size_t)gd.off_base + ((size_t)cy * gd.nx + cx) * cfg->n_rays;
-                for (int k = 0; k < cfg->n_rays; k++) { n_rows++; n_empty += grid_host.off[r0 + k + 1] == grid_host.off[r0 + k]; }
-            };
-            for (int i = 0; i < md.A; i++) {
-                const int r0 = region_off[i], nr = region_off[i + 1] - r0;
-                if (nr <= 0) { sample(start[2 * i], start[2 * i + 1]); continue; }
-                for (int q = 0; q < nr; q++) {
-                    const double *rg = regions + 4 * (r0 + q);
-                    sample(rg[0] + rg[2] / 2, rg[1] + rg[3] / 2);
-                    for (int c = 0; c < 4; c++) sample(rg[0] + rg[2] * ((c & 1) ? 0.75 : 0.25), rg[1] + rg[3] * ((c & 2) ? 0.75 : 0.25));
-                }
-            }
-        }
-        empty_rows = n_rows ? (double)n_empty / (double)n_rows : 0.0;
-    }
-    bool want_ring = true, pool_step = empty_rows >= kPoolEmptyRows;
-    if (const char *e = getenv("CAT_POOL")) want_ring = pool_step = atoi(e) != 0;
-    if (fan == 1 && want_ring) {
-        // capacity: the next power of two (ring position by a mask), else wpb * A * R + 64 entries exactly (position by an invariant division); group
-        // arrays of the scratch unions: what group_agents() holds at once (two agents up to 128 rays each), else one agent's chunks
-        int cap2 = 64;
-        while (cap2 < wpb * A * cfg->n_rays) cap2 *= 2;
-        const int cap_x = (wpb * A * cfg->n_rays + 64 + 1) / 2 * 2;
-        const int cpa = (cfg->n_rays + 63) / 64, gsz = cpa <= 2 ? 2 : 1;
-        const int g_full = kLanes * std::min(4, std::min(A, gsz) * cpa), g_one = kLanes * std::min(4, cpa);
-        const bool ok_dims = A <= 8 && cfg->n_rays <= 256 && wpb <= 16 && cpa <= 4;
-        for (int attempt = 0; ok_dims && attempt < 3 && !pool_cap; attempt++) {
-            const int cap = attempt == 0 ? cap2 : cap_x, g2 = attempt < 2 ? g_full : g_one;
-            const LdsSizes l2 = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, true, g2);
-            if (l2.total(wpb) + 16 + (size_t)cap * 8 <= 160 * 1024) { pool_cap = cap; grp_rays = g2; ls = l2; }
-        }
-    }
-    if (getenv("CAT_VERBOSE")) {   // contact-candidate rows (agent_setup): how many cells overflow the packed row of seven
-        size_t n = 0, n0 = 0, n7 = 0, n15 = 0; int mx = 0;
-        for (unsigned long long w : grid_host.crows) { const int c = (int)(w & 0xFF); n++; n0 += c > 0; n7 += c > 7; n15 += c > 15; if (c > mx) mx = c; }
-        fprintf(stderr, "[cat_sim] contact rows: %zu cells, %.3f with a candidate, %.4f with more than 7 (CSR walk), %.4f with more than 15; longest %d\n", n, n ? (double)n0 / n : 0.0,
-                n ? (double)n7 / n : 0.0, n ? (double)n15 / n : 0.0, mx);
-    }
-    if (!pool_cap) pool_step = false;
-    if (getenv("CAT_VERBOSE"))
-        fprintf(stderr, "[cat_sim] ray pool: %d entries, group arrays for %d rays (resident launch: %s, one-tick launch: %s); rows without a candidate around the spawn points: %.3f\n", pool_cap,
-                grp_rays, pool_cap ? "pooled" : "unit form", pool_step ? "pooled" : "unit form", empty_rows);
-    // ---- work list: workgroups are map-homogeneous; env slots grouped by map, padded with -1
-    std::vector<int> work, block_map;
-    int helpers = 0;   // CAT_HELPERS (diagnostic): that many waves of every workgroup own no env slot and only take work units
-    if (const char *e = getenv("CAT_HELPERS")) { helpers = atoi(e); if (helpers < 0 || helpers >= wpb) helpers = 0; }
-    const int epb = wpb - helpers;
-    for (int m = 0; m < n_maps; m++) {
-        int cnt = 0;
-        for (int e = 0; e < N; e++)
-            if (slot[e] == m) {
-                if (cnt % wpb == 0) block_map.push_back(m);
-                work.push_back(e);
-                cnt++;
-                if (cnt % wpb == epb) for (int h = 0; h < helpers; h++) { work.push_back(-1); cnt++; }
-            }
-        while (cnt % wpb) { work.push_back(-1); cnt++; }
+        if (!light.empty() && !dense.empty() && !split) { dense.insert(dense.end(), light.begin(), light.end()); light.clear(); }
+        std::sort(dense.begin(), dense.end());
+        if (!light.empty()) { part_maps.push_back(light); part_fan.push_back(1); }
+        if (!dense.empty()) { part_maps.push_back(dense); part_fan.push_back(0); }
     }
 
     cat_sim *s = new cat_sim();
     s->err[0] = 0;
     s->device = device;
     s->maps = descs;
-    s->n_blocks = (int)block_map.size();
     if (hipSetDevice(device) != hipSuccess) {
         snprintf(g_create_err, sizeof g_create_err, "hipSetDevice(%d) failed", device);
         delete s;
         return CAT_ERR_NO_DEVICE;
     }
-    Params &p = s->p;
-    memset(&p, 0, sizeof p);
-    p.N = N; p.A = A; p.n_cops = cfg->n_cops; p.R = cfg->n_rays; p.max_step = cfg->max_step_count;
-    p.iterations = cfg->iterations; p.persistence = cfg->persistence; p.gate = cfg->bbtree_gate;
-    p.NP = A * (A - 1) / 2; p.maxc = A * kK + p.NP;
-    p.env_id_offset = cfg->env_id_offset; p.seed = cfg->seed;
-    p.dt = cfg->dt; p.bias_coef = cfg->bias_coef; p.slop = cfg->slop; p.ray_length = cfg->ray_length;
-    p.ray_radius = cfg->ray_radius; p.rc = cfg->agent_radius; p.mass = cfg->agent_mass; p.impulse = cfg->impulse;
-    p.max_speed = cfg->max_speed; p.term_radius = cfg->termination_radius; p.wall_r = cfg->wall_radius;
-
     int rc = CAT_OK;
     auto fail = [&](int code) { strncpy(g_create_err, s->err, sizeof g_create_err - 1); cat_destroy(s); return code; };
-    // ---- env state records (layout documented at Params::state)
-    const int NPs_rec = p.NP > 0 ? p.NP : 1;
-    p.hot_bytes = 96 * A + 16;
-    p.rec_bytes = p.hot_bytes + ((A * kK + NPs_rec) * 8 + (2 * A * kK + NPs_rec) * 4 + 15) / 16 * 16;
-    if (p.hot_bytes > kLanes * 16) {   // StateRegs
-        snprintf(s->err, sizeof s->err, "state record of %d bytes exceeds the kernels' register staging", p.hot_bytes);
+#define TRY_ALLOC(call) do { rc = (call); if (rc != CAT_OK) return fail(rc); } while (0)
+    // ---- what every part shares: the configuration, the ray table and reward LUTs, the geometry of all maps, the env state records, the error word
+    Params base;
+    memset(&base, 0, sizeof base);
+    base.N = N; base.A = A; base.n_cops = cfg->n_cops; base.R = cfg->n_rays; base.max_step = cfg->max_step_count;
+    base.iterations = cfg->iterations; base.persistence = cfg->persistence; base.gate = cfg->bbtree_gate;
+    base.NP = A * (A - 1) / 2;
+    base.env_id_offset = cfg->env_id_offset; base.seed = cfg->seed;
+    base.dt = cfg->dt; base.bias_coef = cfg->bias_coef; base.slop = cfg->slop; base.ray_length = cfg->ray_length;
+    base.ray_radius = cfg->ray_radius; base.rc = cfg->agent_radius; base.mass = cfg->agent_mass; base.impulse = cfg->impulse;
+    base.max_speed = cfg->max_speed; base.term_radius = cfg->termination_radius; base.wall_r = cfg->wall_radius;
+    const int NPs_rec = base.NP > 0 ? base.NP : 1;
+    base.hot_bytes = 96 * A + 16;
+    base.rec_bytes = base.hot_bytes + ((A * kK + NPs_rec) * 8 + (2 * A * kK + NPs_rec) * 4 + 15) / 16 * 16;
+    if (base.hot_bytes > kLanes * 16) {   // StateRegs
+        snprintf(s->err, sizeof s->err, "state record of %d bytes exceeds the kernels' register staging", base.hot_bytes);
         return fail(CAT_ERR_BAD_CONFIG);
     }
-    std::vector<char> rec0((size_t)N * p.rec_bytes, 0);
-    for (int e = 0; e < N; e++) {
-        const MapDesc &d = descs[slot[e]];
-        const double *start = geo_f.data() + d.f64_off + 4 * d.S + geo_rest_doubles(d);
-        double *rd = reinterpret_cast<double *>(rec0.data() + (size_t)e * p.rec_bytes);
-        int *ri = reinterpret_cast<int *>(rec0.data() + (size_t)e * p.rec_bytes + p.hot_bytes + (A * kK + NPs_rec) * 8);   // cold ints
-        for (int i = 0; i < A; i++) {
-            // Entity.__init__ + space.add: caches and BBTree leaf at the start position, v = 0
-            const double x = start[2 * i], y = start[2 * i + 1], r = cfg->agent_radius;
-            rd[2 * i] = x; rd[2 * i + 1] = y;                       // pos
-            rd[6 * A + 2 * i] = x; rd[6 * A + 2 * i + 1] = y;       // tc
-            const double l = x - r, b = y - r, rr = x + r, t = y + r;
-            const double mx = (rr - l) * 0.1, my = (t - b) * 0.1;
-            double *lf = rd + 8 * A + 4 * i;
-            lf[0] = l + (-mx < 0.0 ? -mx : 0.0); lf[1] = b + (-my < 0.0 ? -my : 0.0);
-            lf[2] = rr + (mx > 0.0 ? mx : 0.0); lf[3] = t + (my > 0.0 ? my : 0.0);
+    {   // env state records (layout documented at Params::state)
+        std::vector<char> rec0((size_t)N * base.rec_bytes, 0);
+        for (int e = 0; e < N; e++) {
+            const MapDesc &d = descs[slot[e]];
+            const double *start = geo_f.data() + d.f64_off + 4 * d.S + geo_rest_doubles(d);
+            double *rd = reinterpret_cast<double *>(rec0.data() + (size_t)e * base.rec_bytes);
+            int *ri = reinterpret_cast<int *>(rec0.data() + (size_t)e * base.rec_bytes + base.hot_bytes + (A * kK + NPs_rec) * 8);   // cold ints
+            for (int i = 0; i < A; i++) {
+                // Entity.__init__ + space.add: caches and BBTree leaf at the start position, v = 0
+                const double x = start[2 * i], y = start[2 * i + 1], r = cfg->agent_radius;
+                rd[2 * i] = x; rd[2 * i + 1] = y;                       // pos
+                rd[6 * A + 2 * i] = x; rd[6 * A + 2 * i + 1] = y;       // tc
+                const double l = x - r, b = y - r, rr = x + r, t = y + r;
+                const double mx = (rr - l) * 0.1, my = (t - b) * 0.1;
+                double *lf = rd + 8 * A + 4 * i;
+                lf[0] = l + (-mx < 0.0 ? -mx : 0.0); lf[1] = b + (-my < 0.0 ? -my : 0.0);
+                lf[2] = rr + (mx > 0.0 ? mx : 0.0); lf[3] = t + (my > 0.0 ? my : 0.0);
+            }
+            for (int q = 0; q < A * kK; q++) ri[q] = -1;                // wall_shape: free slots
+            for (int q = 0; q < NPs_rec; q++) ri[2 * A * kK + q] = -1;  // pair_age: none
         }
-        for (int q = 0; q < A * kK; q++) ri[q] = -1;                // wall_shape: free slots
-        for (int q = 0; q < NPs_rec; q++) ri[2 * A * kK + q] = -1;  // pair_age: none
+        TRY_ALLOC(dev_alloc(s, &base.state, rec0.size(), rec0.data()));
     }
-#define TRY_ALLOC(call) do { rc = (call); if (rc != CAT_OK) return fail(rc); } while (0)
-    TRY_ALLOC(dev_alloc(s, const_cast<double **>(&p.ray_dx), (size_t)p.R, tab->ray_dx));
-    TRY_ALLOC(dev_alloc(s, const_cast<double **>(&p.ray_dy), (size_t)p.R, tab->ray_dy));
-    TRY_ALLOC(dev_alloc(s, const_cast<float **>(&p.cop_lut), 32768, tab->cop_reward_lut));
-    TRY_ALLOC(dev_alloc(s, const_cast<float **>(&p.thief_lut), 32768, tab->thief_reward_lut));
-    TRY_ALLOC(dev_alloc(s, const_cast<MapDesc **>(&p.maps), descs.size(), descs.data()));
-    TRY_ALLOC(dev_alloc(s, const_cast<double **>(&p.geo_f64), geo_f.size(), geo_f.data()));
-    TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.geo_i32), geo_i.size(), geo_i.data()));
-    {
-        s->grid = std::move(grid_host);
-        p.row_words = s->grid.row_words;
-        p.row_id_bits = s->grid.id_bits;
-        if (p.row_id_bits) {
-            p.row_cnt_mul = (65536 + p.row_id_bits - 1) / p.row_id_bits;
-            for (int b = 0; b < 64; b++)
-                if (((b * p.row_cnt_mul) >> 16) != b / p.row_id_bits) { snprintf(g_create_err, sizeof g_create_err, "row field divider"); return CAT_ERR_BAD_CONFIG; }
-        }
-        TRY_ALLOC(dev_alloc(s, const_cast<GridDesc **>(&p.grids), s->grid.desc.size(), s->grid.desc.data()));
-        TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.grid_rows), s->grid.rows.size(), s->grid.rows.data()));
-        // the CSR arrays of the ray grid are only read for lists beyond a row's capacity: not uploaded when no list is that long
-        const bool csr = !s->grid.id_bits && s->grid.max_row > 8 * s->grid.row_words - 1;
-        TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.grid_off), csr ? s->grid.off.size() : 1, csr ? s->grid.off.data() : nullptr));
-        TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.grid_ent), csr ? s->grid.ent.size() : 1, csr ? s->grid.ent.data() : nullptr));
-        TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.cgrid_off), s->grid.coff.size(), s->grid.coff.data()));
-        TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.cgrid_ent), s->grid.cent.size(), s->grid.cent.data()));
-        TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.cgrid_rows), s->grid.crows.size(), s->grid.crows.data()));
-    }
-    TRY_ALLOC(dev_alloc(s, &p.err_word, 1, nullptr));
-    TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.work_env), work.size(), work.data()));
-    TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.block_map), block_map.size(), block_map.data()));
-    {
-        std::vector<BlockDesc> bd(block_map.size());
-        for (size_t b = 0; b < block_map.size(); b++) {
-            bd[b].md = descs[block_map[b]];
-            bd[b].gd = s->grid.desc.empty() ? GridDesc{} : s->grid.desc[block_map[b]];
-        }
-        TRY_ALLOC(dev_alloc(s, const_cast<BlockDesc **>(&p.block_desc), bd.size(), bd.data()));
-    }
-    TRY_ALLOC(dev_alloc(s, &p.state, rec0.size(), rec0.data()));
-#undef TRY_ALLOC
-    // ---- ray-direction cone parameters: valid when the table is a uniform full circle
-    {
+    TRY_ALLOC(dev_alloc(s, const_cast<double **>(&base.ray_dx), (size_t)base.R, tab->ray_dx));
+    TRY_ALLOC(dev_alloc(s, const_cast<double **>(&base.ray_dy), (size_t)base.R, tab->ray_dy));
+    TRY_ALLOC(dev_alloc(s, const_cast<float **>(&base.cop_lut), 32768, tab->cop_reward_lut));
+    TRY_ALLOC(dev_alloc(s, const_cast<float **>(&base.thief_lut), 32768, tab->thief_reward_lut));
+    TRY_ALLOC(dev_alloc(s, const_cast<MapDesc **>(&base.maps), descs.size(), descs.data()));
+    TRY_ALLOC(dev_alloc(s, const_cast<double **>(&base.geo_f64), geo_f.size(), geo_f.data()));
+    TRY_ALLOC(dev_alloc(s, const_cast<int **>(&base.geo_i32), geo_i.size(), geo_i.data()));
+    TRY_ALLOC(dev_alloc(s, &base.err_word, 1, nullptr));
+    {   // ray-direction cone parameters: valid when the table is a uniform full circle
         const double two_pi = 6.283185307179586;
         const double a0 = atan2(tab->ray_dy[0], tab->ray_dx[0]);
-        const double step = two_pi / p.R;
-        bool ok = p.R >= 4;
-        for (int k = 0; k < p.R && ok; k++) {
+        const double step = two_pi / base.R;
+        bool ok = base.R >= 4;
+        for (int k = 0; k < base.R && ok; k++) {
             double d = atan2(tab->ray_dy[k], tab->ray_dx[k]) - (a0 + k * step);
             d -= two_pi * floor(d / two_pi + 0.5);
             if (fabs(d) > 1e-6) ok = false;
         }
-        p.ang_ok = ok ? 1 : 0;  // otherwise every shape is paired with every ray (still exact)
-        p.ang0 = (float)a0;
-        p.inv_step = (float)(1.0 / step);
+        base.ang_ok = ok ? 1 : 0;  // otherwise every shape is paired with every ray (still exact)
+        base.ang0 = (float)a0;
+        base.inv_step = (float)(1.0 / step);
     }
-    p.maxE = maxS + A;
-    p.lds_map_bytes = ls.map; p.lds_env_bytes = ls.env; p.lds_union_bytes = ls.uni; p.wpb = wpb;
-    p.grp_rays = grp_rays;
-    p.lds_pool_off = pool_cap ? (int)((ls.total(wpb) + 15) / 16 * 16) : 0;
-    p.pool_mask = pool_cap ? pool_cap - 1 : 0;
-    p.pool_magic = 0u; p.pool_shift = -1;
-    if (pool_cap && (pool_cap & (pool_cap - 1))) {   // not a power of two: floor(i / cap) = (t + ((i - t) >> 1)) >> shift with t = mulhi(magic, i)  [Granlund & Montgomery]
-        int l = 0;
-        while ((1u << l) < (unsigned)pool_cap) l++;
-        p.pool_magic = (unsigned)((((unsigned long long)1 << 32) * ((1ull << l) - (unsigned long long)pool_cap)) / (unsigned long long)pool_cap + 1ull);
-        p.pool_shift = l - 1;
+
+    s->parts.resize(part_maps.size());
+    for (size_t pi = 0; pi < part_maps.size(); pi++) {
+        Part &pt = s->parts[pi];
+        pt.map_ids = part_maps[pi];
+        const int fan = part_fan[pi];
+        int maxS = 0, maxP = 0, maxPP = 0, depth = 0, n_part_envs = 0;
+        std::vector<int> local_of((size_t)n_maps, -1);   // map -> its index among the part's grids
+        for (size_t k = 0; k < pt.map_ids.size(); k++) {
+            const int m = pt.map_ids[k];
+            local_of[(size_t)m] = (int)k;
+            maxS = std::max(maxS, descs[m].S); maxP = std::max(maxP, descs[m].P); maxPP = std::max(maxPP, descs[m].PP);
+            depth = std::max(depth, wall_depth[(size_t)m]);
+            append_grid(pt.grid, map_grid[(size_t)m]);
+            map_grid[(size_t)m] = GridHost();   // the part owns the tables now
+        }
+        for (int e = 0; e < N; e++) n_part_envs += local_of[(size_t)slot[e]] >= 0;
+        pt.n_envs = n_part_envs;
+        GridHost &grid_host = pt.grid;
+        int id_bits = 1;   // bits of a wall id + 1
+        while ((1 << id_bits) <= maxS) id_bits++;
+        // the group form reads four-byte rows; the chunk form eight-byte rows of the same fields where the longest list fits
+        // (agh-map: 9 walls of 7 bits), else byte rows of 8 / 16 / 32 bytes with the CSR continuation (CAT_GRID_FIELDS=0 forces those)
+        bool wide = fan == 0 && grid_host.max_row * id_bits <= 64;
+        if (const char *e = getenv("CAT_GRID_FIELDS")) { if (atoi(e) == 0) wide = false; }
+        finalize_rows(grid_host, (fan == 1 || wide) ? id_bits : 0, wide);
+        if (getenv("CAT_VERBOSE"))
+            fprintf(stderr, "[cat_sim] part %zu of %zu: %zu map(s), %d env slots; ray fan: %s form; longest candidate list %d; rows of %d bytes (%s); table %.1f MB\n", pi + 1, part_maps.size(),
+                    pt.map_ids.size(), n_part_envs, fan ? "group" : "chunk", grid_host.max_row, fan ? 4 : 8 * grid_host.row_words,
+                    (fan || wide) ? "fields of wall id + 1" : "count byte + id bytes, CSR beyond", grid_host.rows.size() * 8 / 1e6);
+        // the contact array of a scratch union: what the part's maps make possible (an agent's bb overlaps at most `depth` wall bbs at once -- 2 on the box
+        // maps, 5 on agh-map -- and holds at most CAT_WALL_CACHE arbiters), + every agent pair; lane q solves contact q, so never more than a wave's lanes
+        const int maxc = std::min(kLanes, A * std::min(depth, kK) + base.NP);
+        // ---- LDS carve sizes (must match carve()) and the workgroup size
+        LdsSizes ls = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, fan == 1, maxc);
+        int wpb = 0;
+        {   // waves (= env slots) per workgroup.  Most resident waves per CU first (cap 16 = 4 per SIMD at <= 128 VGPRs);
+            // among equals a launch of at most two rounds takes the LARGEST workgroup (its waves share ray chunks, which
+            // removes the lone-wave tail of a single round), a longer launch the SMALLEST (workgroups of a CU overlap
+            // each other's drain).  CAT_WAVES_PER_BLOCK overrides (tuning).
+            const int cu = 256;
+            int forced = 0;
+            if (const char *e = getenv("CAT_WAVES_PER_BLOCK")) forced = atoi(e);
+            int best_score = -1, best_w = 0;
+            if (forced >= 1 && forced <= kMaxWaves && ls.total(forced) <= 160 * 1024) wpb = forced;   // any size, also not a power of two
+            for (int w = 1; w <= kMaxWaves && wpb == 0; w *= 2) {
+                const size_t bytes = ls.total(w);
+                if (bytes > 160 * 1024) continue;
+                int resident = (int)((160 * 1024) / bytes) * w;
+                if (resident > 16) resident = 16;
+                const bool small_launch = (long long)N <= 2LL * 16 * cu;
+                if (resident > best_score || (resident == best_score && small_launch)) { best_score = resident; best_w = w; }
+            }
+            if (wpb == 0) wpb = best_w;
+            if (wpb == 0) {
+                snprintf(s->err, sizeof s->err, "LDS budget exceeded: %zu bytes for one env slot", ls.total(1));
+                return fail(CAT_ERR_BAD_CONFIG);
+            }
+        }
+        // ---- the workgroup's ray pool (step_kernel_pooled / rollout_kernel_pooled): a ring of wpb * A * R eight-byte entries beside the env areas, where it fits
+        // Where the ring fits, the RESIDENT launch always runs pooled (whole runs from the reset, tools/pool_soak.py, M env-steps/s unit -> pooled: labyrinth 201 -> 229,
+        // labyrinth-inside 148 -> 159, squarinth 156 -> 169, grandbyrinth 154 -> 169, lbirinth 123.0 -> 123.6).  The ONE-TICK launch pays the sorting pass in its serial
+        // chain and loses on a map whose rays all meet a wall (lbirinth 90.5 -> 87.0; labyrinth 132.5 -> 139.1, the others + 1 - 2 %): it runs pooled unless practically no
+        // (cell, ray) row sampled around the spawn points is empty (lbirinth 0.008; labyrinth-inside 0.06, squarinth 0.22, grandbyrinth 0.27, labyrinth 0.41).
+        // CAT_POOL=1 / 0 forces both / neither.
+        int pool_cap = 0, grp_rays = 4 * kLanes;
+        double empty_rows = 0.0;
+        {   // ... sampled where episodes start: five points of every spawn region (the JSON start position of an agent without regions), every ray
+            size_t n_rows = 0, n_empty = 0;
+            for (size_t k = 0; k < grid_host.desc.size(); k++) {
+                const MapDesc &md = descs[pt.map_ids[k]];
+                const GridDesc &gd = grid_host.desc[k];
+                const double *start = geo_f.data() + md.f64_off + 4 * md.S + geo_rest_doubles(md), *regions = start + 2 * md.A;
+                const int *region_off = geo_i.data() + md.i32_off + 2 * md.S;
+                auto sample = [&](double x, double y) {
+                    const int cx = (int)floor((x - gd.x0) * gd.inv_cell), cy = (int)floor((y - gd.y0) * gd.inv_cell);
+                    if (cx < 0 || cy < 0 || cx >= gd.nx || cy >= gd.ny) return;
+                    const size_t r0 = (size_t)gd.off_base + ((size_t)cy * gd.nx + cx) * cfg->n_rays;
+                    for (int k2 = 0; k2 < cfg->n_rays; k2++) { n_rows++; n_empty += grid_host.off[r0 + k2 + 1] == grid_host.off[r0 + k2]; }
+                };
+                for (int i = 0; i < md.A; i++) {
+                    const int r0 = region_off[i], nr = region_off[i + 1] - r0;
+                    if (nr <= 0) { sample(start[2 * i], start[2 * i + 1]); continue; }
+                    for (int q = 0; q < nr; q++) {
+                        const double *rg = regions + 4 * (r0 + q);
+                        sample(rg[0] + rg[2] / 2, rg[1] + rg[3] / 2);
+                        for (int c = 0; c < 4; c++) sample(rg[0] + rg[2] * ((c & 1) ? 0.75 : 0.25), rg[1] + rg[3] * ((c & 2) ? 0.75 : 0.25));
+                    }
+                }
+            }
+            empty_rows = n_rows ? (double)n_empty / (double)n_rows : 0.0;
+        }
+        // ... and on rosters of at most four agents: the pooled one-tick launch keeps the whole sorting pass in the slot's serial front, which grows with the roster
+        // (3v2 at 64 rays x8192, round 5: 97.4 us unit form, 99.0 pooled; resident 77.6 -> 74.8 us per tick: the resident launch takes the ring whenever it exists)
+        bool want_ring = true, pool_step = empty_rows >= kPoolEmptyRows && A <= 4;
+        if (const char *e = getenv("CAT_POOL")) want_ring = pool_step = atoi(e) != 0;
+        if (fan == 1 && want_ring) {
+            // capacity: the next power of two (ring position by a mask), else wpb * A * R + 64 entries exactly (position by an invariant division); group
+            // arrays of the scratch unions: what group_agents() holds at once (two agents up to 128 rays each), else one agent's chunks
+            int cap2 = 64;
+            while (cap2 < wpb * A * cfg->n_rays) cap2 *= 2;
+            const int cap_x = (wpb * A * cfg->n_rays + 64 + 1) / 2 * 2;
+            const int cpa = (cfg->n_rays + 63) / 64, gsz = cpa <= 2 ? 2 : 1;
+            const int g_full = kLanes * std::min(4, std::min(A, gsz) * cpa), g_one = kLanes * std::min(4, cpa);
+            const bool ok_dims = A <= 8 && cfg->n_rays <= 256 && wpb <= 16 && cpa <= 4;
+            for (int attempt = 0; ok_dims && attempt < 3 && !pool_cap; attempt++) {
+                const int cap = attempt == 0 ? cap2 : cap_x, g2 = attempt < 2 ? g_full : g_one;
+                const LdsSizes l2 = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, true, maxc, g2);
+                if (l2.total(wpb) + 16 + (size_t)cap * 8 <= 160 * 1024) { pool_cap = cap; grp_rays = g2; ls = l2; }
+            }
+        }
+        if (getenv("CAT_VERBOSE")) {   // contact-candidate rows (agent_setup): how many cells overflow the packed row of seven
+            size_t n = 0, n0 = 0, n7 = 0, n15 = 0; int mx = 0;
+            for (unsigned long long w : grid_host.crows) { const int c = (int)(w & 0xFF); n++; n0 += c > 0; n7 += c > 7; n15 += c > 15; if (c > mx) mx = c; }
+            fprintf(stderr, "[cat_sim] contact rows: %zu cells, %.3f with a candidate, %.4f with more than 7 (CSR walk), %.4f with more than 15; longest %d; contact array of %d (wall bb depth %d)\n", n,
+                    n ? (double)n0 / n : 0.0, n ? (double)n7 / n : 0.0, n ? (double)n15 / n : 0.0, mx, maxc, depth);
+        }
+        if (!pool_cap) pool_step = false;
+        if (getenv("CAT_VERBOSE"))
+            fprintf(stderr, "[cat_sim] ray pool: %d entries, group arrays for %d rays (resident launch: %s, one-tick launch: %s); rows without a candidate around the spawn points: %.3f; "
+                    "LDS %zu bytes per workgroup of %d waves\n", pool_cap, grp_rays, pool_cap ? "pooled" : "unit form", pool_step ? "pooled" : "unit form", empty_rows,
+                    ls.total(wpb) + (pool_cap ? 16 + (size_t)pool_cap * 8 : 0), wpb);
+        // ---- work list: workgroups are map-homogeneous; env slots grouped by map, padded with -1
+        std::vector<int> work, block_map;
+        int helpers = 0;   // CAT_HELPERS (diagnostic): that many waves of every workgroup own no env slot and only take work units
+        if (const char *e = getenv("CAT_HELPERS")) { helpers = atoi(e); if (helpers < 0 || helpers >= wpb) helpers = 0; }
+        const int epb = wpb - helpers;
+        for (int m : pt.map_ids) {
+            int cnt = 0;
+            for (int e = 0; e < N; e++)
+                if (slot[e] == m) {
+                    if (cnt % wpb == 0) block_map.push_back(m);
+                    work.push_back(e);
+                    cnt++;
+                    if (cnt % wpb == epb) for (int h = 0; h < helpers; h++) { work.push_back(-1); cnt++; }
+                }
+            while (cnt % wpb) { work.push_back(-1); cnt++; }
+        }
+        pt.n_blocks = (int)block_map.size();
+        Params &p = pt.p;
+        p = base;
+        p.maxc = maxc;
+        {
+            p.row_words = grid_host.row_words;
+            p.row_id_bits = grid_host.id_bits;
+            if (p.row_id_bits) {
+                p.row_cnt_mul = (65536 + p.row_id_bits - 1) / p.row_id_bits;
+                for (int b = 0; b < 64; b++)
+                    if (((b * p.row_cnt_mul) >> 16) != b / p.row_id_bits) { snprintf(s->err, sizeof s->err, "row field divider"); return fail(CAT_ERR_BAD_CONFIG); }
+            }
+            TRY_ALLOC(dev_alloc(s, const_cast<GridDesc **>(&p.grids), grid_host.desc.size(), grid_host.desc.data()));
+            TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.grid_rows), grid_host.rows.size(), grid_host.rows.data()));
+            // the CSR arrays of the ray grid are only read for lists beyond a row's capacity: not uploaded when no list is that long
+            const bool csr = !grid_host.id_bits && grid_host.max_row > 8 * grid_host.row_words - 1;
+            TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.grid_off), csr ? grid_host.off.size() : 1, csr ? grid_host.off.data() : nullptr));
+            TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.grid_ent), csr ? grid_host.ent.size() : 1, csr ? grid_host.ent.data() : nullptr));
+            TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.cgrid_off), grid_host.coff.size(), grid_host.coff.data()));
+            TRY_ALLOC(dev_alloc(s, const_cast<unsigned char **>(&p.cgrid_ent), grid_host.cent.size(), grid_host.cent.data()));
+            TRY_ALLOC(dev_alloc(s, const_cast<unsigned long long **>(&p.cgrid_rows), grid_host.crows.size(), grid_host.crows.data()));
+        }
+        TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.work_env), work.size(), work.data()));
+        TRY_ALLOC(dev_alloc(s, const_cast<int **>(&p.block_map), block_map.size(), block_map.data()));
+        {
+            std::vector<BlockDesc> bd(block_map.size());
+            for (size_t b = 0; b < block_map.size(); b++) {
+                bd[b].md = descs[block_map[b]];
+                bd[b].gd = grid_host.desc[(size_t)local_of[(size_t)block_map[b]]];
+            }
+            TRY_ALLOC(dev_alloc(s, const_cast<BlockDesc **>(&p.block_desc), bd.size(), bd.data()));
+        }
+        p.maxE = maxS + A;
+        p.lds_map_bytes = ls.map; p.lds_env_bytes = ls.env; p.lds_union_bytes = ls.uni; p.wpb = wpb;
+        p.grp_rays = grp_rays;
+        p.lds_pool_off = pool_cap ? (int)((ls.total(wpb) + 15) / 16 * 16) : 0;
+        p.pool_mask = pool_cap ? pool_cap - 1 : 0;
+        p.pool_magic = 0u; p.pool_shift = -1;
+        if (pool_cap && (pool_cap & (pool_cap - 1))) {   // not a power of two: floor(i / cap) = (t + ((i - t) >> 1)) >> shift with t = mulhi(magic, i)  [Granlund & Montgomery]
+            int l = 0;
+            while ((1u << l) < (unsigned)pool_cap) l++;
+            p.pool_magic = (unsigned)((((unsigned long long)1 << 32) * ((1ull << l) - (unsigned long long)pool_cap)) / (unsigned long long)pool_cap + 1ull);
+            p.pool_shift = l - 1;
+        }
+        pt.wpb = wpb;
+        pt.lds_bytes = pool_cap ? (size_t)p.lds_pool_off + (size_t)pool_cap * 8 : ls.total(wpb);
+        pt.kernel_variant = select_kernels(A, p.R, p.n_cops, fan, pool_cap != 0, pool_step, p.pool_shift >= 0, pt.reset_fn, pt.rollout_fn, pt.step_fn);
+        pt.pool_step = pool_step;
+        if (pt.lds_bytes > 64 * 1024) {
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(pt.step_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt.lds_bytes);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(pt.reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt.lds_bytes);
+            hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(pt.rollout_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt.lds_bytes);
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+                snprintf(s->err, sizeof s->err, "cannot raise dynamic LDS limit to %zu", pt.lds_bytes);
+                return fail(CAT_ERR_HIP);
+            }
+        }
+        {
+            Params *dp = nullptr;
+            rc = dev_alloc(s, &dp, 1, &p);
+            if (rc != CAT_OK) return fail(rc);
+            pt.dev_p = dp;
+        }
+        {   // the prologue's copy (third kernel argument)
+            Prologue &q = pt.pro;
+            memset(&q, 0, sizeof q);
+            q.lds_map_bytes = p.lds_map_bytes; q.lds_env_bytes = p.lds_env_bytes; q.lds_union_bytes = p.lds_union_bytes; q.wpb = p.wpb;
+            q.A = p.A; q.R = p.R; q.NP = p.NP; q.maxc = p.maxc; q.n_cops = p.n_cops; q.rec_bytes = p.rec_bytes; q.hot_bytes = p.hot_bytes; q.N = p.N;
+            q.lds_pool_off = p.lds_pool_off; q.pool_mask = p.pool_mask; q.grp_rays = p.grp_rays;
+            q.work_env = p.work_env; q.block_desc = p.block_desc; q.state = p.state; q.geo_f64 = p.geo_f64; q.geo_i32 = p.geo_i32;
+            q.ray_dx = p.ray_dx; q.ray_dy = p.ray_dy; q.cop_lut = p.cop_lut; q.thief_lut = p.thief_lut;
+            bool ident = n_maps == 1 && (int)work.size() == pt.n_blocks * wpb;
+            for (size_t k = 0; ident && k < work.size(); k++) ident = work[k] == ((int)k < N ? (int)k : -1);
+            q.uniform = ident ? 1 : 0;
+            q.bd.md = descs[block_map[0]];
+            q.bd.gd = grid_host.desc[(size_t)local_of[(size_t)block_map[0]]];
+        }
     }
-    s->wpb = wpb;
-    s->lds_bytes = pool_cap ? (size_t)p.lds_pool_off + (size_t)pool_cap * 8 : ls.total(wpb);
-    s->kernel_variant = select_kernels(A, p.R, p.n_cops, fan, pool_cap != 0, pool_step, p.pool_shift >= 0, s->reset_fn, s->rollout_fn, s->step_fn);
-    s->pool_step = pool_step;
-    if (s->lds_bytes > 64 * 1024) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->step_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->reset_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
-        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void *>(s->rollout_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-            snprintf(s->err, sizeof s->err, "cannot raise dynamic LDS limit to %zu", s->lds_bytes);
+#undef TRY_ALLOC
+    if (s->parts.size() > 1) {   // the second part's launches run on a stream of the handle, forked from and joined to the caller's (launch_parts)
+        if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+            snprintf(s->err, sizeof s->err, "cannot create the second part's stream / events");
             return fail(CAT_ERR_HIP);
         }
     }
-    {
-        Params *dp = nullptr;
-        rc = dev_alloc(s, &dp, 1, &p);
-        if (rc != CAT_OK) return fail(rc);
-        s->dev_p = dp;
-    }
-    {   // the prologue's copy (third kernel argument)
-        Prologue &q = s->pro;
-        memset(&q, 0, sizeof q);
-        q.lds_map_bytes = p.lds_map_bytes; q.lds_env_bytes = p.lds_env_bytes; q.lds_union_bytes = p.lds_union_bytes; q.wpb = p.wpb;
-        q.A = p.A; q.R = p.R; q.NP = p.NP; q.maxc = p.maxc; q.n_cops = p.n_cops; q.rec_bytes = p.rec_bytes; q.hot_bytes = p.hot_bytes; q.N = p.N;
-        q.lds_pool_off = p.lds_pool_off; q.pool_mask = p.pool_mask; q.grp_rays = p.grp_rays;
-        q.work_env = p.work_env; q.block_desc = p.block_desc; q.state = p.state; q.geo_f64 = p.geo_f64; q.geo_i32 = p.geo_i32;
-        q.ray_dx = p.ray_dx; q.ray_dy = p.ray_dy; q.cop_lut = p.cop_lut; q.thief_lut = p.thief_lut;
-        bool ident = n_maps == 1 && (int)work.size() == s->n_blocks * wpb;
-        for (size_t k = 0; ident && k < work.size(); k++) ident = work[k] == ((int)k < N ? (int)k : -1);
-        q.uniform = ident ? 1 : 0;
-        q.bd.md = descs[block_map[0]];
-        q.bd.gd = s->grid.desc.empty() ? GridDesc{} : s->grid.desc[block_map[0]];
+    for (size_t pi = 0; pi < s->parts.size(); pi++) {
+        const Part &pt = s->parts[pi];
+        s->one_tick_name += (pi ? "+" : "") + std::string(pt.pool_step ? "step_kernel_pooled" : "step_kernel");
+        s->rollout_name += (pi ? "+" : "") + std::string(pt.p.pool_mask ? "rollout_kernel_pooled" : "rollout_kernel");
     }
     *out = s;
     return CAT_OK;
@@ -3957,8 +4077,39 @@ extern "C" int cat_destroy(cat_sim *s)
 {
     if (!s) return CAT_ERR_BAD_ARG;
     (void)hipSetDevice(s->device);
+    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     for (void *d : s->allocs) (void)hipFree(d);
     delete s;
+    return CAT_OK;
+}
+
+// One dispatch per part.  A sim of two parts launches the second on the handle's own stream, forked from the caller's stream by an event and joined back
+// to it by another: for the caller the entry stays one stream-ordered operation, and the two kernels share the device.  An armed pair of timing events
+// (cat_arm_kernel_timing) is attached to the dispatch itself when there is one, else recorded on the caller's stream around the fork and the join.
+enum { kFnReset, kFnStep, kFnRollout };
+static int launch_parts(cat_sim *s, const LaunchArgs &la, void *stream, int which)
+{
+    hipStream_t user = static_cast<hipStream_t>(stream);
+    const bool two = s->parts.size() > 1;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (which != kFnReset && s->t_start && s->t_stop) { t0 = s->t_start; t1 = s->t_stop; s->t_start = s->t_stop = nullptr; }
+    auto launch = [&](const Part &pt, hipStream_t st, bool events) {
+        const KernelFn fn = which == kFnReset ? pt.reset_fn : (which == kFnStep ? pt.step_fn : pt.rollout_fn);
+        const dim3 grid(pt.n_blocks), block(pt.wpb * kLanes);
+        if (events) hipExtLaunchKernelGGL(fn, grid, block, pt.lds_bytes, st, t0, t1, 0, pt.dev_p, la, pt.pro);
+        else hipLaunchKernelGGL(fn, grid, block, pt.lds_bytes, st, pt.dev_p, la, pt.pro);
+    };
+    if (!two) { launch(s->parts[0], user, t0 != nullptr); return CAT_OK; }
+    if (t0) HIP_TRY(s, hipEventRecord(t0, user));
+    HIP_TRY(s, hipEventRecord(s->ev_fork, user));
+    HIP_TRY(s, hipStreamWaitEvent(s->side, s->ev_fork, 0));
+    launch(s->parts[1], s->side, false);   // the chunk-form part first: its workgroups are the long ones
+    HIP_TRY(s, hipEventRecord(s->ev_join, s->side));
+    launch(s->parts[0], user, false);
+    HIP_TRY(s, hipStreamWaitEvent(user, s->ev_join, 0));
+    if (t1) HIP_TRY(s, hipEventRecord(t1, user));
     return CAT_OK;
 }
 
@@ -3971,8 +4122,8 @@ static int launch_reset(cat_sim *s, const uint8_t *mask, const double *positions
     memset(&la, 0, sizeof la);
     if (out) la.out = *out;
     la.mask = mask; la.positions = positions; la.use_done_mask = use_done;
-    hipLaunchKernelGGL(s->reset_fn, dim3(s->n_blocks), dim3(s->wpb * kLanes), s->lds_bytes,
-                       static_cast<hipStream_t>(stream), s->dev_p, la, s->pro);
+    const int rc = launch_parts(s, la, stream, kFnReset);
+    if (rc != CAT_OK) return rc;
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -3985,21 +4136,6 @@ extern "C" int cat_reset(cat_sim *s, const uint8_t *mask, const double *position
 extern "C" int cat_reset_done(cat_sim *s, const cat_outputs *out, void *stream)
 {
     return launch_reset(s, nullptr, nullptr, out, 1, stream);
-}
-
-// step_kernel / rollout_kernel launch; when cat_arm_kernel_timing armed a pair of HIP events they are attached to THIS dispatch
-// (recorded at the kernel's own begin and end, not at the surrounding stream positions), one shot.
-static void launch_tick(cat_sim *s, const LaunchArgs &la, void *stream, KernelFn fn = nullptr)
-{
-    const dim3 grid(s->n_blocks), block(s->wpb * kLanes);
-    if (!fn) fn = s->step_fn;
-    if (s->t_start && s->t_stop) {
-        hipExtLaunchKernelGGL(fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->t_start, s->t_stop, 0,
-                              s->dev_p, la, s->pro);
-        s->t_start = s->t_stop = nullptr;
-    } else {
-        hipLaunchKernelGGL(fn, grid, block, s->lds_bytes, static_cast<hipStream_t>(stream), s->dev_p, la, s->pro);
-    }
 }
 
 extern "C" int cat_arm_kernel_timing(cat_sim *s, void *start_event, void *stop_event)
@@ -4017,7 +4153,8 @@ extern "C" int cat_step(cat_sim *s, const int32_t *actions, const cat_outputs *o
     memset(&la, 0, sizeof la);
     if (out) la.out = *out;
     la.actions = actions;
-    launch_tick(s, la, stream);
+    const int rc = launch_parts(s, la, stream, kFnStep);
+    if (rc != CAT_OK) return rc;
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -4032,7 +4169,8 @@ extern "C" int cat_step_fused(cat_sim *s, const int32_t *actions, uint64_t synth
     if (out) la.out = *out;
     la.actions = actions; la.synth_tick = synth_tick;
     la.auto_reset = auto_reset ? 1 : 0;   // finished episodes are reset inside the same launch (no second kernel)
-    launch_tick(s, la, stream);
+    const int rc = launch_parts(s, la, stream, kFnStep);
+    if (rc != CAT_OK) return rc;
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -4048,7 +4186,8 @@ extern "C" int cat_rollout_fused(cat_sim *s, int T, const int32_t *actions, uint
     if (out) la.out = *out;
     la.actions = actions; la.synth_tick = synth_tick0; la.T = T;
     la.auto_reset = auto_reset ? 1 : 0;
-    launch_tick(s, la, stream, s->rollout_fn);
+    const int rc = launch_parts(s, la, stream, kFnRollout);
+    if (rc != CAT_OK) return rc;
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -4057,9 +4196,9 @@ extern "C" int cat_random_actions(cat_sim *s, uint64_t tick, int32_t *actions, v
 {
     if (!s || !actions) return CAT_ERR_BAD_ARG;
     HIP_TRY(s, hipSetDevice(s->device));
-    const int n = s->p.N * s->p.A;
+    const int n = s->parts[0].p.N * s->parts[0].p.A;
     hipLaunchKernelGGL(random_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       s->dev_p, (unsigned long long)tick, actions);
+                       s->parts[0].dev_p, (unsigned long long)tick, actions);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -4069,12 +4208,13 @@ extern "C" int cat_device_errors(cat_sim *s, uint32_t *flags, int clear, void *s
     if (!s || !flags) return CAT_ERR_BAD_ARG;
     HIP_TRY(s, hipSetDevice(s->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(s, hipMemcpyAsync(flags, s->p.err_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    if (clear) HIP_TRY(s, hipMemsetAsync(s->p.err_word, 0, sizeof(uint32_t), st));
+    HIP_TRY(s, hipMemcpyAsync(flags, s->parts[0].p.err_word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (clear) HIP_TRY(s, hipMemsetAsync(s->parts[0].p.err_word, 0, sizeof(uint32_t), st));
     HIP_TRY(s, hipStreamSynchronize(st));
-    if (*flags) snprintf(s->err, sizeof s->err, "device-side error flags 0x%x:%s%s", *flags,
+    if (*flags) snprintf(s->err, sizeof s->err, "device-side error flags 0x%x:%s%s%s", *flags,
                          (*flags & CAT_DEVERR_BAD_ACTION) ? " an action outside 0..3 (applied as no impulse)" : "",
-                         (*flags & CAT_DEVERR_CONTACT_DROPPED) ? " a wall contact was dropped (more than CAT_WALL_CACHE simultaneous wall contacts of one agent)" : "");
+                         (*flags & CAT_DEVERR_CONTACT_DROPPED) ? " a contact was dropped (more simultaneous contacts than the cache / contact array holds)" : "",
+                         (*flags & CAT_DEVERR_SCHEDULER) ? " a work item of the pooled ray fan never arrived (results of that launch are invalid)" : "");
     return CAT_OK;
 }
 
@@ -4082,10 +4222,11 @@ extern "C" int cat_set_seed(cat_sim *s, uint64_t seed, void *stream)
 {
     if (!s) return CAT_ERR_BAD_ARG;
     HIP_TRY(s, hipSetDevice(s->device));
-    s->p.seed = seed;
-    // the 8-byte source lives in the handle, which outlives the async copy
-    HIP_TRY(s, hipMemcpyAsync(&s->dev_p->seed, &s->p.seed, sizeof(s->p.seed), hipMemcpyHostToDevice,
-                              static_cast<hipStream_t>(stream)));
+    for (Part &pt : s->parts) {
+        pt.p.seed = seed;
+        // the 8-byte source lives in the handle, which outlives the async copy
+        HIP_TRY(s, hipMemcpyAsync(&pt.dev_p->seed, &pt.p.seed, sizeof(pt.p.seed), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    }
     return CAT_OK;
 }
 
@@ -4093,7 +4234,7 @@ static int copy_state(cat_sim *s, const cat_state *v, bool get, void *stream)
 {
     if (!s || !v) return CAT_ERR_BAD_ARG;
     HIP_TRY(s, hipSetDevice(s->device));
-    const Params &p = s->p;
+    const Params &p = s->parts[0].p;   // (the record layout and the state pointer are the same in every part)
     const int A = p.A, NPs = p.NP > 0 ? p.NP : 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // field <-> strided slice of the per-env records
@@ -4107,7 +4248,7 @@ static int copy_state(cat_sim *s, const cat_state *v, bool get, void *stream)
     const bool cold_touched = v->wall_jn || v->pair_jn || v->wall_shape || v->wall_age || v->pair_age;
     // a slot whose cache_live flag is 0 keeps STALE bytes in the cold part of its record: make them say "empty" before
     // they are read out, and raise the flag of every slot after cold fields were written from outside
-    if (get) hipLaunchKernelGGL(cold_fixup_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, s->dev_p, 0);
+    if (get) hipLaunchKernelGGL(cold_fixup_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, s->parts[0].dev_p, 0);
     HIP_TRY(s, cp(v->pos, 0, 2 * A * D));
     HIP_TRY(s, cp(v->vel, 2 * A * D, 2 * A * D));
     HIP_TRY(s, cp(v->vbias, 4 * A * D, 2 * A * D));
@@ -4120,7 +4261,7 @@ static int copy_state(cat_sim *s, const cat_state *v, bool get, void *stream)
     HIP_TRY(s, cp(v->wall_shape, ci, (size_t)A * kK * I));
     HIP_TRY(s, cp(v->wall_age, ci + (size_t)A * kK * I, (size_t)A * kK * I));
     if (p.NP > 0) HIP_TRY(s, cp(v->pair_age, ci + 2 * (size_t)A * kK * I, (size_t)p.NP * I));
-    if (!get && cold_touched) hipLaunchKernelGGL(cold_fixup_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, s->dev_p, 1);
+    if (!get && cold_touched) hipLaunchKernelGGL(cold_fixup_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, s->parts[0].dev_p, 1);
     HIP_TRY(s, hipGetLastError());
     return CAT_OK;
 }
@@ -4209,8 +4350,11 @@ extern "C" void cat_grid_free_host(cat_grid_host *gh) { delete gh; }
 // candidates (k < 0) for an origin at (x, y) on map `map_index`.  Returns the count (ids in out).
 extern "C" int cat_debug_grid_lookup(const cat_sim *s, int map_index, double x, double y, int k, int *out, int max_out)
 {
-    if (!s || map_index < 0 || map_index >= (int)s->grid.desc.size() || k >= s->p.R) return CAT_ERR_BAD_ARG;
-    return grid_lookup(s->grid, map_index, s->p.R, x, y, k, out, max_out);
+    if (!s || map_index < 0 || map_index >= (int)s->maps.size() || k >= s->parts[0].p.R) return CAT_ERR_BAD_ARG;
+    for (const Part &pt : s->parts)
+        for (size_t q = 0; q < pt.map_ids.size(); q++)
+            if (pt.map_ids[q] == map_index) return grid_lookup(pt.grid, (int)q, pt.p.R, x, y, k, out, max_out);
+    return CAT_ERR_BAD_ARG;
 }
 
 extern "C" int cat_selftest_arith(int op, const double *a, const double *b, double *out, int n, int device, void *stream)

@@ -404,7 +404,9 @@ class VecCopsEnv:
             n = min(cap, ticks - 1 - done)
             self._sim.rollout_fused(n, None, tick=tick0 + done, auto_reset=self.auto_reset, out={})
             done += n
-        return self._sim.step_fused(None, tick=tick0 + ticks - 1, auto_reset=self.auto_reset)
+        out = self._sim.step_fused(None, tick=tick0 + ticks - 1, auto_reset=self.auto_reset)
+        self._sim.check_errors()   # thousands of ticks went by inside one launch: a flag raised by any of them ends the run here, not never
+        return out
 
     def check_errors(self) -> None:
         """The step launches are asynchronous and cannot raise; this synchronises and raises ``ValueError`` if any

@@ -79,6 +79,7 @@ class TrainerConfig:
                                            # optimiser steps over W times the data (the update's cost is dominated by
                                            # its kernel COUNT, which does not grow with W)
     compute_bf16: bool = True              # bf16 compute copy of the weights on a GPU (fp32 master + fp32 Adam)
+    check_device_errors: bool = True       # read the env core's device error word once per update (raises on any flag)
     graph_rollout: bool = True             # capture the T-tick rollout (env ticks + all networks) in one HIP graph
     graph_update: bool = True              # capture the minibatch step (forward, losses, backward / clip, Adam)
     reference_q11: bool = False            # True: every critic sees the alphabetically first agent's channels (quirk Q11)
@@ -600,6 +601,13 @@ class MAPPOTrainer:
         """PPO update of every learner (or of the learner keys in ``only``) from the rollout just collected."""
         N = self.N
         todo = {k: rl for k, rl in self.roles.items() if only is None or k in only}
+        if self.tcfg.check_device_errors:
+            # the env ticks of the rollout were asynchronous launches that cannot raise: read the device error word once per update (one stream
+            # synchronisation, where the rollout has to be complete anyway) -- a bad action, a dropped contact or a scheduler fault stops training
+            # here, as the reference's exceptions would (entity.py:126-134)
+            check = getattr(self.env, "check_errors", None)   # (the CPU test doubles of the env have no device)
+            if check is not None:
+                check()
         with torch.no_grad():
             state = self.env.state()
             keep = (~self._starts).view(1, N)

@@ -214,6 +214,26 @@ def timed_rollout(sim, T: int, fence, hip: "HipEvents", first_tick: int, reps: i
     return elapsed, sum(hip.elapsed_ms(a, b) for a, b in ev) / (reps * T), reps
 
 
+def source_sha16() -> str:
+    """sha256 of the shipped env-core source, first 16 hex digits: what a committed profile must have been collected on to describe this build."""
+    import hashlib
+    return hashlib.sha256((ROOT / "as_cops_and_thieves_amd" / "csrc" / "cat_sim.hip").read_bytes()).hexdigest()[:16]
+
+
+def compute_block(valu):
+    """The compute-side roofline of a replayed profile (the path is bound by VALU issue, not by HBM): the share of the SIMDs' vector issue
+    slots in use x the share of lanes active in an issued instruction = the fraction of lane-issue slots doing work."""
+    if not valu:
+        return None
+    busy, util = valu.get("valu_issue_busy_frac"), valu.get("lane_utilisation")
+    return {"bound": "valu_issue", "valu_issue_busy": busy, "lane_utilisation": util,
+            "frac": (busy * util) if busy is not None and util is not None else None,
+            "valu_per_env_step": valu.get("valu_insts_per_wave"), "salu_per_env_step": valu.get("salu_insts_per_wave"),
+            "lds_per_env_step": valu.get("lds_insts_per_wave"), "lds_bank_conflict_per_active_cycle": valu.get("lds_bank_conflict_per_active_cycle"),
+            "what": "frac = valu_issue_busy x lane_utilisation: 1.0 = every SIMD issues a 64-lane vector instruction in every issue slot (FP64 geometry and "
+                    "integer bookkeeping alike); instruction counts are wave-instructions per env-step"}
+
+
 def find_profile(wl: dict, kernel: str):
     """The newest committed PMC profile (profiles/r*_traffic*.json) of this workload and kernel, or None.  PMC counters need
     rocprofv3 passes of their own, so the bench line REPLAYS them and says so."""
@@ -222,6 +242,7 @@ def find_profile(wl: dict, kernel: str):
         prof = json.loads(tfile.read_text())
         if prof.get("workload_key", default_key) == wl and prof.get("kernel", "tick_kernel") == kernel:
             prof["_file"] = tfile.name
+            prof["_stale"] = prof.get("source_sha16") != source_sha16()   # collected on another cat_sim.hip than the one shipped (or before r05: unrecorded)
             return prof
     return None
 
@@ -235,9 +256,12 @@ def replay_profile(entry: dict, wl: dict, kernel: str, ticks_per_launch: int = 1
     entry["traffic"] = prof["hbm_bytes_per_launch"] / prof.get("ticks_per_launch", 1)
     entry["traffic_source"] = f"profiles/{prof['_file']} (committed rocprofv3 --pmc passes; replayed, not measured in this run)"
     entry["traffic_over_algorithmic"] = entry["traffic"] / (algorithmic_bytes_per_env_step(wl["cops"] + wl["thieves"], wl["rays"]) * wl["envs"])
+    entry["profile_stale"] = prof["_stale"]
+    entry["profile_git_head"] = prof.get("git_head")
     if prof.get("valu"):
         entry["lane_utilisation"] = prof["valu"].get("lane_utilisation")
         entry["valu"] = prof["valu"]
+        entry["compute"] = compute_block(prof["valu"])
 
 
 def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16, rank: int = 0, world: int = 1, reduce_device=None) -> dict:
@@ -276,6 +300,8 @@ def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16,
         env.close()
         return out
     except Exception as exc:   # noqa: BLE001
+        if world > 1:   # the other ranks are inside the trainer's collectives: a swallowed error here would leave them waiting until the RCCL
+            raise       # timeout -- let torchrun tear the group down instead
         return {"value": None, "error": repr(exc)[:200]}
 
 
@@ -385,6 +411,7 @@ def main() -> None:
         r_el = max_over_ranks(r_el, device=None if rehearse else dev)
         roll = (r_el, r_kms, r_n)
     episodes = int(sim.get_state()["reset_count"].sum().item())
+    dev_errors = {"headline": sim.device_errors()}   # CAT_DEVERR_* raised by any launch of the burn-in, the timed region or the resident leg (0 = none)
     one_tick_kernel = sim.one_tick_kernel      # "step_kernel" / "step_kernel_pooled": one tick through the resident rollout scheduler (rounds 1 - 3: "tick_kernel")
     rollout_kernel = sim.rollout_kernel        # the resident launch of the same sim
     sim.close()
@@ -415,6 +442,7 @@ def main() -> None:
         r_el, r_kms, r_n = timed_rollout(s2, TR, fence, hip, first_tick=100 + k_steps)
         r_el = max_over_ranks(r_el, device=None if rehearse else dev)
         kern2, roll2 = s2.one_tick_kernel, s2.rollout_kernel
+        dev_errors[w["map"] + (f" {w['rays']} rays" if "rays" in w else "")] = s2.device_errors()
         s2.close()
         key = {"map": w["map"], "envs": w["envs"], "rays": w.get("rays", args.rays), "cops": w["cops"], "thieves": w["thieves"]}
         ent = {"value": world * c2.n_envs * k_steps / e2, "unit": "env-steps/s", "steps": k_steps,
@@ -469,6 +497,7 @@ def main() -> None:
             replay_profile(res, wl, rollout_kernel)
             extra = dict(extra or {})
             extra[f"{args.map} {args.cops}v{args.thieves} x{cfg.n_envs}, T={TR} resident rollout"] = res
+        stale = bool(prof["_stale"]) if prof is not None else None
         line = {
             "metric": "env-steps/sec (whole node) at 4096 parallel envs, 2v1 agents, 64-ray sensors",
             "value": world * cfg.n_envs * args.steps / elapsed,
@@ -488,6 +517,8 @@ def main() -> None:
                          "traffic_from_reset": traffic_from_reset, "traffic_source": traffic_source,
                          "kernel": one_tick_kernel, "kernel_ms": tick_ms, "kernel_launches_timed": n_timed, "kernel_ms_method": tick_method,
                          "algorithmic_bytes_per_launch": bytes_launch, "valu": valu, "valu_source": traffic_source,
+                         "compute": compute_block(valu), "profile_stale": stale, "profile_source_sha16": prof.get("source_sha16") if prof else None,
+                         "profile_git_head": prof.get("git_head") if prof else None, "shipped_source_sha16": source_sha16(),
                          "hbm_stream_copy_GBs": copy_gbs,
                          "frac_of_stream_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "note": "path is FP64-VALU/LDS bound, not HBM bound (SURVEY 8d); fraction reported as contracted"},
@@ -499,10 +530,28 @@ def main() -> None:
             line["extra"] = extra
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(cfg, cmap)
+    # device-side error words of every sim of every rank (the reference raises at once on a bad call, entity.py:126-134; the launches here are
+    # asynchronous, so the kernels flag and the host reads the word after each leg): the line carries the OR over ranks and legs, and a run that
+    # raised any flag exits non-zero after printing it
+    err_or = 0
+    for v in dev_errors.values():
+        err_or |= int(v)
+    if world > 1:
+        flags = [None] * world
+        dist.all_gather_object(flags, err_or)
+        err_or = 0
+        for v in flags:
+            err_or |= int(v)
+    if rank == 0:
+        line["device_errors"] = err_or
+        if err_or:
+            line["device_errors_by_leg"] = dev_errors
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if err_or:
+        sys.exit(f"bench.py: device-side error flags 0x{err_or:x} were raised (CAT_DEVERR_*: 1 bad action, 2 contact dropped, 4 scheduler): results invalid")
 
 
 if __name__ == "__main__":

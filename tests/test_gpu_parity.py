@@ -90,7 +90,7 @@ def test_chunk_form_of_the_ray_fan_on_the_light_maps(name, rays, monkeypatch):
 
 @pytest.mark.parametrize("name,rays,cops,thieves,pool", [("labyrinth", 64, 2, 1, "0"), ("lbirinth", 64, 2, 1, "1"), ("squarinth", 64, 2, 1, "1"),
                                                          ("squarinth", 90, 1, 1, "1"), ("grandbyrinth", 48, 2, 2, "1"), ("labyrinth", 90, 2, 1, "0"),
-                                                         ("lbirinth", 90, 2, 1, "1")])
+                                                         ("lbirinth", 90, 2, 1, "1"), ("grandbyrinth", 64, 3, 2, "1"), ("grandbyrinth", 64, 3, 2, "0")])
 def test_pooled_and_unit_form_of_the_light_maps_fan(name, rays, cops, thieves, pool, monkeypatch):
     """Where the rays of a workgroup fit an LDS ring (wpb * A * R <= 4096) cat_create picks between two schedulers of the group form: fan
     units of a slot's own rays (step_kernel / rollout_kernel), or one pool of the active rays of ALL slots from which any wave takes rounds
@@ -162,12 +162,14 @@ def test_pooled_and_unit_schedulers_agree_at_batch_size(name, N, monkeypatch):
 
 def test_default_choice_of_the_scheduler_per_entry():
     """Where the ring fits, cat_create gives the resident launch the pooled kernel on every map and the one-tick launch the pooled kernel unless practically every
-    ray around the spawn points meets a wall (lbirinth); a roster whose ring does not fit (3v2 at 64 rays) keeps the unit form for both."""
+    ray around the spawn points meets a wall (lbirinth) or the roster has more than four agents.  3v2 at 64 rays (BASELINE configs[3]) has its ring since the
+    contact arrays of the scratch unions are sized by what the map makes possible (round 4: 5 KB short): resident launch pooled, one-tick launch unit form
+    (measured: 97.4 against 99.0 us); the dense map keeps the chunk form."""
     from as_cops_and_thieves_amd.config import SimConfig
     from as_cops_and_thieves_amd.maps import load_preset
     from as_cops_and_thieves_amd.sim import CatSim
     want = {("labyrinth", 2, 1): ("step_kernel_pooled", "rollout_kernel_pooled"), ("squarinth", 2, 1): ("step_kernel_pooled", "rollout_kernel_pooled"),
-            ("lbirinth", 2, 1): ("step_kernel", "rollout_kernel_pooled"), ("grandbyrinth", 3, 2): ("step_kernel", "rollout_kernel"),
+            ("lbirinth", 2, 1): ("step_kernel", "rollout_kernel_pooled"), ("grandbyrinth", 3, 2): ("step_kernel", "rollout_kernel_pooled"),
             ("labyrinth", 2, 1, 90): ("step_kernel_pooled", "rollout_kernel_pooled"),   # a ring of exactly wpb * A * R + 64 entries (no power of two fits)
             ("agh-map", 2, 1): ("step_kernel", "rollout_kernel")}
     for key, kernels in want.items():
@@ -289,6 +291,60 @@ def test_mixed_map_batch_ragged():
     cfg = SimConfig(n_envs=N, n_rays=64, max_step_count=30, seed=21)
     stats = _run(cfg, maps, slot, ticks=45, rng=rng, auto_reset=True)
     assert stats["done"] >= N
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
+@pytest.mark.parametrize("pool", [None, "1", "0"])
+def test_mixed_map_batch_in_two_parts_and_in_one(split, pool, monkeypatch):
+    """A sim whose maps want both forms of the ray fan (BASELINE configs[4]: the agh-map needs the chunk form, the four box maps take the group form and its
+    pooled kernels) runs in one part on the chunk form, or (CAT_SPLIT=1) cut into two parts, each with its own tables, LDS carve and kernels, launched side
+    by side on two streams of the handle (cat_sim.hip cat_create / launch_parts).  Both ways, with the pooled / unit choice left to cat_create and forced
+    either way: one-tick launches with separate resets, then cat_step_fused, then one resident launch, every slot against the oracle."""
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.sim import CatSim
+    from oracle.cat_oracle import OracleSim
+    monkeypatch.setenv("CAT_SPLIT", split)
+    if pool is not None:
+        monkeypatch.setenv("CAT_POOL", pool)
+    maps = [compiled(n) for n in ("agh-map", "grandbyrinth", "labyrinth", "lbirinth", "squarinth")]
+    N = 5 * 19 + 3
+    slot = (np.arange(N) % 5).astype(np.int32)
+    cfg = SimConfig(n_envs=N, n_rays=64, max_step_count=30, seed=22)
+    stats = _run(cfg, maps, slot, ticks=45, rng=np.random.default_rng(8), auto_reset=True)
+    assert stats["done"] >= N
+    gpu, cpu = CatSim(cfg, maps, slot, device="cuda:0"), OracleSim(cfg, maps, slot)
+    if split == "1":
+        light = "_pooled" if pool != "0" else ""
+        assert gpu.rollout_kernel == f"rollout_kernel{light}+rollout_kernel", gpu.rollout_kernel
+        assert gpu.one_tick_kernel == f"step_kernel{light}+step_kernel", gpu.one_tick_kernel
+    else:
+        assert (gpu.one_tick_kernel, gpu.rollout_kernel) == ("step_kernel", "rollout_kernel")
+    gpu.reset(); cpu.reset()
+    keys = ("obs_distance", "obs_type", "shared_distance", "shared_type", "team_positions")
+    flag_keys = ("reward", "terminated", "truncated", "winner")
+    for t in range(35):
+        gpu.step_fused(None, tick=t, auto_reset=True)
+        c = cpu.step(cpu.random_actions(t))
+        flags = {k: c[k].copy() for k in flag_keys}
+        cpu.reset(mask=c["terminated"].copy())
+        if t % 5 == 0 or t >= 29:
+            torch.cuda.synchronize()
+            assert_outputs_equal(to_np(gpu.out), cpu.out, keys=keys, ctx=f"fused tick {t}")
+            assert_outputs_equal(to_np(gpu.out), flags, keys=flag_keys, ctx=f"fused tick {t}")
+            assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx=f"fused tick {t}")
+    rows = to_np(gpu.rollout_fused(50, None, tick=35, auto_reset=True))
+    torch.cuda.synchronize()
+    for t in range(50):
+        c = cpu.step(cpu.random_actions(35 + t))
+        flags = {k: c[k].copy() for k in flag_keys}
+        cpu.reset(mask=c["terminated"].copy())
+        got = {k: v[t] for k, v in rows.items()}
+        assert_outputs_equal(got, cpu.out, keys=keys, ctx=f"resident tick {t}")
+        assert_outputs_equal(got, flags, keys=flag_keys, ctx=f"resident tick {t}")
+    assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx="resident launch")
+    assert gpu.device_errors() == 0
+    gpu.close()
 
 
 def test_gate_off_parity():

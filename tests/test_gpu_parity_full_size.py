@@ -64,6 +64,53 @@ def test_every_slot_matches_the_oracle(label, names, cops, thieves, N, ticks, ma
         cat_oracle.lib().cato_set_threads(1)
 
 
+def test_configs2_at_its_stated_size_and_a_shard_at_its_real_offset():
+    """BASELINE configs[2] as stated: agh-map 2v1, 32768 envs.  (i) all of them in ONE batch on one GPU, 60 ticks of 25-tick episodes, every slot against the
+    oracle; (ii) the shard rank 7 of an 8-GPU job owns -- 4096 slots at env_id_offset 28672, which key their Philox streams with the GLOBAL env ids -- run as
+    its own sim and compared with slots 28672 ... of that batch (outputs and state), i.e. with what one big batch simulates for the same envs."""
+    import torch
+    from dataclasses import replace
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.sim import CatSim
+    from oracle import cat_oracle
+    from oracle.cat_oracle import OracleSim
+    N, n_shard, off, ticks = 32768, 4096, 28672, 60
+    m = compiled("agh-map", 2, 1)
+    cfg = SimConfig(n_envs=N, n_cops=2, n_thieves=1, n_rays=64, max_step_count=25, seed=20261005)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    cat_oracle.lib().cato_set_threads(threads)
+    try:
+        gpu = CatSim(cfg, [m], device="cuda:0", debug_hit_shape=True)
+        shard = CatSim(replace(cfg, n_envs=n_shard, env_id_offset=off), [m], device="cuda:0", debug_hit_shape=True)
+        cpu = OracleSim(cfg, [m])
+        g, c = gpu.reset(), cpu.reset()
+        shard.reset()
+        torch.cuda.synchronize()
+        assert_outputs_equal(to_np(g), c, keys=OBS_KEYS, ctx="configs[2] x32768: reset")
+        flag_keys = ("reward", "terminated", "truncated", "winner")
+        for t in range(ticks):
+            gpu.step_fused(None, tick=t, auto_reset=True)
+            shard.step_fused(None, tick=t, auto_reset=True)
+            c = cpu.step(cpu.random_actions(t))
+            flags = {k: c[k].copy() for k in flag_keys}
+            cpu.reset(mask=c["terminated"].copy())
+            if t % 10 == 0 or t == ticks - 1:
+                torch.cuda.synchronize()
+                got = to_np(gpu.out)
+                assert_outputs_equal(got, cpu.out, keys=OBS_KEYS, ctx=f"configs[2] x32768: tick {t}")
+                assert_outputs_equal(got, flags, keys=flag_keys, ctx=f"configs[2] x32768: tick {t}")
+                st = to_np(gpu.get_state())
+                assert_state_equal(st, cpu.get_state(), ctx=f"configs[2] x32768: tick {t}")
+                sh_out, sh_st = to_np(shard.out), to_np(shard.get_state())
+                assert_outputs_equal(sh_out, {k: v[off:off + n_shard] for k, v in got.items()}, ctx=f"shard at offset {off}: tick {t}")
+                assert_state_equal(sh_st, {k: v[off:off + n_shard] for k, v in st.items()}, ctx=f"shard at offset {off}: tick {t}")
+        assert int(cpu.get_state()["reset_count"].min()) >= 2
+        assert gpu.device_errors() == 0 and shard.device_errors() == 0
+        gpu.close(); shard.close()
+    finally:
+        cat_oracle.lib().cato_set_threads(1)
+
+
 def _full_pair(names, cops, thieves, N, rays, max_steps, seed=0):
     from as_cops_and_thieves_amd.config import SimConfig
     from as_cops_and_thieves_amd.sim import CatSim

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Diagnostic builds of cat_sim.hip for A/B runs (tools/ab_kernel.sh, tools/ab_parity.sh): build/var/NAME.so from extra -D flags.
-# Prints the register / spill figures of tick_kernel<WithFan<FixDims<3,64,2>, F>> as the compiler reports them.
+# Diagnostic builds of cat_sim.hip for A/B runs (tools/ab_kernel.sh, tools/ab_parity.sh): build/var/NAME.so from extra -D flags, the compiler's
+# resource report in build/var/NAME.log (tools/regs.sh NAME prints the register / spill figures of every kernel instantiation).
 # usage: tools/build_variant.sh NAME [-DFLAG ...] [--src FILE]
 set -e
 name=$1; shift
@@ -12,6 +12,4 @@ done
 mkdir -p build/var
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -Iinclude "${flags[@]}" -Rpass-analysis=kernel-resource-usage \
   -o build/var/$name.so $src 2> build/var/$name.log || { tail -30 build/var/$name.log; exit 1; }
-for fan in 1 0; do
-  grep -A12 "Function Name: .*tick_kernelINS_7WithFanINS_7FixDimsILi3ELi64ELi2EEELi${fan}E" build/var/$name.log | grep -E "VGPRs:|SGPRs Spill|VGPRs Spill|ScratchSize|Occupancy" | sed 's/.*remark: [^ ]* *//' | tr '\n' ';'; echo " <- $name fan form $fan (1 = groups, 0 = chunks)"
-done
+$(dirname $0)/regs.sh $name 'step_kernel.*FixDimsILi3ELi64ELi2' | sed 's/ScratchSize : /scr /; s/SGPRs Spill: /sS /; s/VGPRs Spill: /vS /; s/VGPRs: /V /' | tr -s '\t ' ' '

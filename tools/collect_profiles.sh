@@ -6,7 +6,7 @@
 #   <tag>_traffic_<shape>.json       tick_kernel, last 25 launches                  <tag>_traffic_<shape>_rollout.json   rollout_kernel, last 4
 # The headline shape (labyrinth 2v1 x4096) also keeps the names of the earlier rounds (<tag>_final_*, <tag>_traffic.json) and gets
 # the HBM counters a second time straight from the reset (--burn-in 0).  rocprofv3 is given `python3 bench.py ...` directly.
-# usage: tools/collect_profiles.sh r04 [shape ...]      shapes: lab agh 3v2 mixed r90 (default: all)
+# usage: tools/collect_profiles.sh r05 [shape ...]      shapes: lab agh 3v2 mixed r90 (default: all); run tools/stamp_head.sh HERE first (git head for the JSON files)
 set -e
 tag=${1:-r04}; shift || true
 shapes=${@:-lab agh 3v2 mixed r90}
@@ -38,7 +38,7 @@ for sh in $shapes; do
   bi=$(python3 -c "import json; print(json.load(open('profiles/${tag}_${sh}_bench_under_rocprof.json'))['config']['burn_in_steps'])")   # what the run used
   k1=$(python3 -c "import json; print(json.load(open('profiles/${tag}_${sh}_bench_under_rocprof.json'))['roofline']['kernel'])")   # tick_kernel or step_kernel
   python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel $k1 --burn-in $bi > /dev/null
-  k2=rollout_kernel; case $k1 in *_pooled) k2=rollout_kernel_pooled;; esac   # the resident launch of the same sim
+  k2=$(python3 -c "import json; e=json.load(open('profiles/${tag}_${sh}_bench_under_rocprof.json'))['extra']; print([v['kernel'] for k, v in e.items() if 'resident rollout' in k][0])")   # the resident launch of the same sim
   python3 tools/make_traffic_json.py $tag --shape $sh --key "${KEY[$sh]}" --kernel $k2 --ticks-per-launch 64 --burn-in $bi > /dev/null
   if [ $sh = lab ]; then
     for c in "FETCH_SIZE" "WRITE_SIZE"; do

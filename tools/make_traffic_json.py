@@ -6,8 +6,10 @@ these files into its JSON line (matched by `workload_key` and `kernel`), labelle
 usage: make_traffic_json.py TAG [--shape NAME --key JSON --kernel tick_kernel|rollout_kernel --ticks-per-launch T --burn-in B
                                  --summary FILE --from-reset FILE --out FILE]        (defaults: the headline workload, tick_kernel)"""
 import argparse
+import hashlib
 import json
 import re
+import subprocess
 from pathlib import Path
 
 root = Path(__file__).resolve().parents[1]
@@ -30,13 +32,35 @@ reset_file = Path(a.from_reset) if a.from_reset else root / "profiles" / f"{tag}
 out_file = Path(a.out) if a.out else root / "profiles" / f"{tag}_traffic{suffix}.json"
 
 
-def counters(path, kernel):
+def git_head():
+    """The commit the profile is collected on: build/GIT_HEAD (tools/stamp_head.sh, written before the gpurun call -- the GPU box gets no .git), else git itself."""
+    f = root / "build" / "GIT_HEAD"
+    if f.exists():
+        return f.read_text().strip()
+    try:
+        return subprocess.run(["git", "rev-parse", "HEAD"], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def counters_one(path, kernel):
     txt = path.read_text()
-    sec = txt[re.search(r"^" + re.escape(kernel), txt, re.M).start():]
+    m = re.search(r"^" + re.escape(kernel) + r"<", txt, re.M) or re.search(r"^" + re.escape(kernel), txt, re.M)   # "step_kernel<", not "step_kernel_pooled<"
+    sec = txt[m.start():]
     body = sec[sec.index("\n") + 1:]
     nxt = re.search(r"^\S", body, re.M)                      # the next kernel's header, if any
     sec = body if nxt is None else body[:nxt.start()]
     return {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+mean\s+([0-9.eE+-]+)", sec, re.M)}
+
+
+def counters(path, kernel):
+    """Counter means of one kernel; "a+b" (a sim of two parts: one dispatch each per entry, side by side): the SUM over both -- every figure
+    derived below is a ratio of such sums, or a count per tick."""
+    out = {}
+    for k in kernel.split("+"):
+        for c, v in counters_one(path, k).items():
+            out[c] = out.get(c, 0.0) + v
+    return out
 
 
 val = counters(summary, a.kernel)
@@ -52,6 +76,8 @@ out = {
     "workload_key": key,
     "kernel": a.kernel,
     "ticks_per_launch": T,
+    "source_sha16": hashlib.sha256((root / "as_cops_and_thieves_amd" / "csrc" / "cat_sim.hip").read_bytes()).hexdigest()[:16],   # bench.py: profile_stale
+    "git_head": git_head(),
     "regime": regime,
     "burn_in": a.burn_in,
     "FETCH_SIZE_KB_per_launch": val["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": val["WRITE_SIZE"],

@@ -43,3 +43,12 @@ for i in sorted(names, key=lambda k: list(names).index(k)):
     if buf[i]:
         print(f"{names[i]:46s} {buf[i] / steps:10.0f} cycles/env-step  {100.0 * buf[i] / tot:5.1f}%")
 print(f"{'total':46s} {tot / steps:10.0f} cycles/env-step;  {e0.elapsed_time(e1) * 1e3 / (reps * T):.2f} us/tick in this (instrumented) build")
+cnt = (C.c_ulonglong * 8)()
+if hasattr(L, "cat_debug_counts"):
+    L.cat_debug_counts(cnt)
+if any(cnt):   # a -DCAT_EVENT_COUNTS build (its cycle marks are distorted by the counting)
+    c = [x / steps for x in cnt]
+    print("per env-step: shape-query rounds %.2f (items %.1f, %.1f lanes per round); classification iterations %.2f (lanes %.1f = %.1f per iteration);"
+          % (c[0], c[1], c[1] / max(c[0], 1e-9), c[2], c[3], c[3] / max(c[2], 1e-9)))
+    print("              exact face iterations %.2f (tests %.1f = %.1f lanes each, %.2f per item); exact corner iterations %.2f (tests %.1f = %.1f lanes each, %.2f per item)"
+          % (c[4], c[5], c[5] / max(c[4], 1e-9), c[5] / max(c[1], 1e-9), c[6], c[7], c[7] / max(c[6], 1e-9), c[7] / max(c[1], 1e-9)))
