@@ -225,6 +225,9 @@ class RoleLearner:
         self.native = self.device.type == "cuda" and compute_dtype == torch.bfloat16   # libcat_learn.so loss kernel
         W, S = self.W, self.W * N
         B = S // cfg.mini_batches
+        if B < 1:
+            raise ValueError(f"{S} training sequences ({W} BPTT windows x {N} envs on this rank) cannot fill {cfg.mini_batches} minibatches: "
+                             "more envs per rank, a longer horizon or fewer minibatches")
         self.B = B
         self.idx = torch.zeros(B, dtype=torch.long, device=device)
         in_dt = dict(dtype=compute_dtype if self.native else torch.float32, device=device)   # the networks cast to it anyway

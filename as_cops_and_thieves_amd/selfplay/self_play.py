@@ -196,9 +196,16 @@ def run_self_play(map_name: str, num_envs: int, out_dir: Path, iterations: Optio
     rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
     chief = rank == 0
 
-    def sync():   # file hand-over between rank 0 and the others
+    def sync(ok: bool = True, what: str = ""):
+        """File hand-over between rank 0 and the others: a MIN all-reduce of an ok flag instead of a bare barrier, so that a failure
+        of rank 0 while it evaluates or writes reaches every rank at once (they raise too) instead of leaving them in a collective
+        until the backend's watchdog fires.  The group is opened with a generous timeout (``init_ranks``): rank 0's evaluation
+        (2000-tick episodes against several archived opponents) runs while the others wait here."""
         if multi:
-            dist.barrier()
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and ok:
+                raise RuntimeError(f"self-play: rank 0 failed {what or 'in its rank-0-only section'}; this rank ({rank}) stops with it")
     tc = training or TrainingConfig()
     iterations = tc.num_self_play_iterations if iterations is None else iterations
     # TrainerConfig's 128-tick rollouts: with 16-tick rollouts the cops' win rate against random thieves stays at its untrained
@@ -216,6 +223,15 @@ def run_self_play(map_name: str, num_envs: int, out_dir: Path, iterations: Optio
         env_factory = lambda n, s, off=0: VecCopsEnv(preset, n, num_rays=num_rays, max_step_count=max_step_count, seed=s, device=device,
                                                      env_id_offset=off)
     n_local, offset = shard_envs(num_envs, rank, world)
+    if multi:
+        # checked on EVERY rank from the same numbers, so that all of them refuse together (a rank that raised alone would leave the others in the
+        # trainer's first all-reduce): the smallest shard must still fill every role's minibatches
+        smallest = min(shard_envs(num_envs, r, world)[0] for r in range(world))
+        windows = max(1, trainer_cfg.horizon // min(trainer_cfg.bptt, trainer_cfg.horizon))
+        need = max(c.mini_batches for c in (role_cfg or {"cop": CFG_AGENT, "thief": CFG_AGENT}).values())
+        if smallest * windows < need:
+            raise ValueError(f"{num_envs} envs over {world} ranks leave a rank {smallest} env(s) = {smallest * windows} training sequences per update, "
+                             f"fewer than the {need} minibatches of the role configuration")
     takes_offset = len(inspect.signature(env_factory).parameters) >= 3
     if multi and not takes_offset:
         raise TypeError("a data-parallel run needs env_factory(num_envs, seed, env_id_offset): the ranks must simulate different envs")
@@ -244,19 +260,27 @@ def run_self_play(map_name: str, num_envs: int, out_dir: Path, iterations: Optio
         stats = trainer.train(trainer_cfg.timesteps)
         cop, thief = tc.cop_role_prefix, tc.thief_role_prefix
         ev = {cop: {}, thief: {}}
+        chief_error = None
         if chief:
-            # ---- 3. evaluation against archived opponents (:199-228)
-            ev = {cop: evaluate_agent(eval_env, evaluator, trainer, cop, thief, arch[thief], tc, rng, log),
-                  thief: evaluate_agent(eval_env, evaluator, trainer, thief, cop, arch[cop], tc, rng, log)}
-            # ---- 4. joint checkpoint into both archives (orchestration.py:225-245)
-            ck = out_dir / f"joint_iter_{it}_full_agent.pt"
-            torch.save(trainer.state_dict(), ck)
-            if it % tc.archive_save_interval == 0 or it == start + iterations - 1:
-                for role in arch:
-                    archive.add_policy_to_archive(str(ck), arch[role], it, role)
-            log(f"[self-play] iteration {it}: saved {ck.name}; evaluated {len(ev[cop])} thief and {len(ev[thief])} cop opponents"
-                + (f"; {world} ranks x {n_local} envs" if multi else ""))
-        sync()                                     # the other ranks read this iteration's archive entries in step 1 of the next
+            try:
+                # ---- 3. evaluation against archived opponents (:199-228)
+                ev = {cop: evaluate_agent(eval_env, evaluator, trainer, cop, thief, arch[thief], tc, rng, log),
+                      thief: evaluate_agent(eval_env, evaluator, trainer, thief, cop, arch[cop], tc, rng, log)}
+                # ---- 4. joint checkpoint into both archives (orchestration.py:225-245)
+                ck = out_dir / f"joint_iter_{it}_full_agent.pt"
+                torch.save(trainer.state_dict(), ck)
+                if it % tc.archive_save_interval == 0 or it == start + iterations - 1:
+                    for role in arch:
+                        archive.add_policy_to_archive(str(ck), arch[role], it, role)
+                log(f"[self-play] iteration {it}: saved {ck.name}; evaluated {len(ev[cop])} thief and {len(ev[thief])} cop opponents"
+                    + (f"; {world} ranks x {n_local} envs" if multi else ""))
+            except Exception as exc:   # noqa: BLE001 -- handed to the other ranks below, then re-raised here
+                if not multi:
+                    raise
+                chief_error = exc
+        sync(ok=chief_error is None, what=f"while evaluating / saving iteration {it}")   # the other ranks read this iteration's archive entries in step 1 of the next
+        if chief_error is not None:
+            raise chief_error
         history.append({"iteration": it, "evaluations": ev, "stats": stats})
     digest = trainer.param_digest()
     env.close()
@@ -282,6 +306,14 @@ def launch_ranks(n: int, argv) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def group_timeout():
+    """Collective timeout of the job's process group: the non-chief ranks wait in ``sync`` while rank 0 evaluates (2000-tick episodes
+    against ``num_opponents_to_evaluate`` archived opponents per role) and writes checkpoints -- well beyond the backends' default of
+    10 minutes on a slow disk or a long evaluation.  ``CAT_SELFPLAY_TIMEOUT_S`` (default two hours)."""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("CAT_SELFPLAY_TIMEOUT_S", "7200")))
+
+
 def init_ranks(gpus: int) -> str:
     """Inside a rank process (WORLD_SIZE set by the launcher): one GPU per rank and the RCCL group (``nccl`` IS RCCL on ROCm).
     ``CAT_SELFPLAY_REHEARSE=1``: the flow on a box with fewer GPUs than ranks -- ranks share devices, gloo carries the all-reduce
@@ -293,10 +325,10 @@ def init_ranks(gpus: int) -> str:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if os.environ.get("CAT_SELFPLAY_REHEARSE") == "1":
         torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=group_timeout())
         return "gloo (CAT_SELFPLAY_REHEARSE=1: ranks share devices)"
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=group_timeout())
     probe = torch.ones(1, device=torch.device("cuda", local))
     dist.all_reduce(probe)
     if int(probe.item()) != world:

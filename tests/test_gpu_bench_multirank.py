@@ -69,3 +69,26 @@ def test_a_rank_count_that_contradicts_the_launcher_is_refused():
     res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
                          env=dict(os.environ, WORLD_SIZE="4", RANK="0"), capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "rank count must equal --gpus" in (res.stderr + res.stdout)
+
+
+def test_four_rank_bench_rehearsal():
+    """More ranks than the two of the tests above, as far as one GPU box goes: a box admits six processes on its card, so with the test runner itself on the
+    GPU four rank processes is the most this suite starts (the eight-rank flow itself -- shard arithmetic, rank-0-only IO, identical replicas, clean exits --
+    runs on CPU: tests/test_self_play_two_ranks_cpu.py::test_eight_ranks_share_one_self_play_job, tests/test_sharding_gloo.py).  The plain command starts
+    its own four ranks; each takes its own env shard; ONE line comes back whose value is the whole-job aggregate over the slowest rank's time.  No scaling
+    curve is measured here or anywhere in this repo until the driver's SCALE run executes on a multi-GPU node."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CAT_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    envs, steps = 256, 40
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", str(steps), "--warmup", "5", "--envs", str(envs), "--no-extras"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["steps"] == steps and d["scaling"] == "weak" and d["device_errors"] == 0
+    assert d["config"]["env_id_offsets"] == [0, envs, 2 * envs, 3 * envs]
+    assert d["config"]["rccl_ranks"] is None and "gloo" in d["config"]["timing_reductions"]
+    assert d["value"] == pytest.approx(4 * envs * steps / (d["ms_per_step"] * 1e-3 * steps), rel=1e-9)
+    # four ranks time-share ONE GPU here: the aggregate stays in the range of what the card does alone on this many envs (N = 1-consistent), no more
+    assert 1e6 < d["value"] < 4e8

@@ -30,3 +30,22 @@ def test_self_play_command_with_two_ranks(tmp_path):
     for role, d in (("cop", "cops"), ("thief", "thieves")):
         assert sorted(p.name for p in (tmp_path / "arch" / d).glob("*.pt")) == [f"{role}_iter_{i}.pt" for i in range(2)]
     assert "2 ranks x 256 envs" in res.stdout
+
+
+def test_self_play_command_with_four_ranks(tmp_path):
+    """Four ranks on the one GPU (the most a box admits beside the test runner: six processes on the card): identical parameter digests on all four, disjoint
+    shards, rank 0 alone wrote; the process group is opened with the long timeout of `group_timeout()` and a failure of rank 0 would reach the others through
+    the ok-flag all-reduce of `run_self_play.sync` (exercised on CPU)."""
+    env = dict(os.environ, CAT_SELFPLAY_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=str(ROOT))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "as_cops_and_thieves_amd.selfplay.self_play", "--gpus", "4", "--map", "squarinth", "--envs", "512",
+           "--iterations", "1", "--timesteps", "64", "--horizon", "16", "--max-step-count", "60", "--random-timesteps", "16",
+           "--learning-starts", "32", "--freeze-duration", "32", "--out", str(tmp_path / "arch")]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
+    rows = re.findall(r"rank (\d)/4: (\d+) envs from global id (\d+), all-reduce over (.*?), parameters ([0-9a-f]{16})", res.stdout)
+    assert sorted((int(r), int(n), int(o)) for r, n, o, _, _ in rows) == [(0, 128, 0), (1, 128, 128), (2, 128, 256), (3, 128, 384)], res.stdout[-2000:]
+    assert len({r[4] for r in rows}) == 1                             # bit-identical replicas on all four ranks
+    for role, d in (("cop", "cops"), ("thief", "thieves")):
+        assert sorted(p.name for p in (tmp_path / "arch" / d).glob("*.pt")) == [f"{role}_iter_0.pt"]

@@ -42,8 +42,9 @@ def _worker(rank, world, port, out_dir, q):
     tc = TrainerConfig(horizon=4, timesteps=16, policy_freeze_duration=8, opponent_freeze_duration=8)
     kw = dict(training=self_play.TrainingConfig(n_trial_episodes=3, num_opponents_to_evaluate=2), trainer_cfg=tc,
               role_cfg={"cop": rc, "thief": rc}, env_factory=factory, log=lambda *a: None)
-    res = self_play.run_self_play("squarinth", 10, out_dir, iterations=3, **kw)
-    res2 = self_play.run_self_play("squarinth", 10, out_dir, iterations=1, **kw)        # resumes after iteration 2
+    total = 10 if world <= 4 else 20          # every rank needs two training sequences for the two minibatches of `rc`
+    res = self_play.run_self_play("squarinth", total, out_dir, iterations=3, **kw)
+    res2 = self_play.run_self_play("squarinth", total, out_dir, iterations=1, **kw)        # resumes after iteration 2
     q.put((rank, res["param_digest"], res["envs_local"], res["env_id_offset"], [h["iteration"] for h in res["iterations"]],
            [h["iteration"] for h in res2["iterations"]], res2["param_digest"], seen[0],
            sum(len(v) for h in res["iterations"] for v in h["evaluations"].values())))
@@ -51,21 +52,24 @@ def _worker(rank, world, port, out_dir, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_share_one_self_play_job(tmp_path):
-    world = 2
+def _run_job(world, out_dir):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tmp_path, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out_dir, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted(q.get(timeout=300) for _ in range(world))
+    got = sorted(q.get(timeout=600) for _ in range(world))
     for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    r0, r1 = got
+        p.join(timeout=120)
+        assert p.exitcode == 0                                         # every rank ended by itself: no process left behind
+    return got
+
+
+def test_two_ranks_share_one_self_play_job(tmp_path):
+    r0, r1 = _run_job(2, tmp_path)
     assert r0[1] == r1[1] and r0[6] == r1[6] and r0[1] != r0[6]       # identical replicas after each call; training moved them
     assert (r0[2], r0[3]) == (5, 0) and (r1[2], r1[3]) == (5, 5)      # 10 envs: two disjoint contiguous shards
     assert r0[7] == (5, 0, 0) and r1[7] == (5, 0, 5)                  # env_factory(n_local, seed, env_id_offset)
@@ -75,3 +79,52 @@ def test_two_ranks_share_one_self_play_job(tmp_path):
         assert sorted(p.name for p in (tmp_path / d).glob("*.pt")) == [f"{role}_iter_{i}.pt" for i in range(4)]
     assert sorted(p.name for p in tmp_path.glob("joint_iter_*")) == [f"joint_iter_{i}_full_agent.pt" for i in range(4)]
     assert (tmp_path / "thieves" / "win_rates.json").exists()
+
+
+def test_eight_ranks_share_one_self_play_job(tmp_path):
+    """The rank count of the 8-GPU node (BASELINE configs[2]), on CPU: 20 envs over eight gloo ranks = ragged shards (3, 3, 3, 3, 2, 2, 2, 2) at disjoint
+    contiguous offsets; every optimiser step all-reduces the gradient | KL buffer over all eight, so all eight end with bit-identical parameters after
+    each call; rank 0 alone evaluated and wrote; every rank resumed from rank 0's files; all eight processes exit by themselves."""
+    got = _run_job(8, tmp_path)
+    assert len(got) == 8 and [g[0] for g in got] == list(range(8))
+    assert len({g[1] for g in got}) == 1 and len({g[6] for g in got}) == 1 and got[0][1] != got[0][6]
+    assert [(g[2], g[3]) for g in got] == [(3, 0), (3, 3), (3, 6), (3, 9), (2, 12), (2, 14), (2, 16), (2, 18)]
+    assert all(g[7] == (g[2], 0, g[3]) for g in got)
+    assert all(g[4] == [0, 1, 2] and g[5] == [3] for g in got)
+    assert got[0][8] > 0 and all(g[8] == 0 for g in got[1:])
+    for role, d in (("cop", "cops"), ("thief", "thieves")):
+        assert sorted(p.name for p in (tmp_path / d).glob("*.pt")) == [f"{role}_iter_{i}.pt" for i in range(4)]
+
+
+def _refusing_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from as_cops_and_thieves_amd.selfplay import self_play
+    from as_cops_and_thieves_amd.selfplay.mappo import RoleConfig, TrainerConfig
+    rc = RoleConfig(learning_epochs=1, mini_batches=2)
+    try:
+        self_play.run_self_play("squarinth", 3, "/nonexistent", iterations=1, trainer_cfg=TrainerConfig(horizon=4, timesteps=8), role_cfg={"cop": rc, "thief": rc},
+                                env_factory=lambda n, s, off=0: None, log=lambda *a: None)
+        q.put((rank, "no error"))
+    except ValueError as exc:
+        q.put((rank, str(exc)))
+    dist.destroy_process_group()
+
+
+def test_a_shard_too_small_for_the_minibatches_is_refused_by_every_rank_together():
+    """3 envs over 2 ranks with two minibatches per update: rank 1's single env cannot fill them.  Every rank computes every rank's shard and raises
+    the same error before anything is built -- a rank failing alone would leave the other waiting in the trainer's first all-reduce."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_refusing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("fewer than the 2 minibatches" in msg for _, msg in got), got

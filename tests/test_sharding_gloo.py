@@ -51,8 +51,9 @@ def _worker(rank, world, port, total, ticks, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_shards_equal_one_batch():
-    total, ticks, world = 10, 40, 2
+@pytest.mark.parametrize("total,world", [(10, 2), (21, 8)])   # 8: the rank count of the node the driver's SCALE run uses (ragged shards of 3 and 2 envs)
+def test_rank_shards_equal_one_batch(total, world):
+    ticks = 40
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -75,7 +76,7 @@ def test_two_rank_shards_equal_one_batch():
         sim.reset(mask=out["terminated"].copy())
     pos = np.concatenate([g[2] for g in got]); obs = np.concatenate([g[3] for g in got])
     assert np.array_equal(pos, sim.get_state()["pos"]) and np.array_equal(obs, out["obs_distance"])
-    assert all(g[4] == 2.0 for g in got)          # MAX over ranks
+    assert all(g[4] == float(world) for g in got)          # MAX over ranks (rank r reported 1 + r)
     assert all(g[5] == total * ticks for g in got)  # whole-job env-steps
 
 
