@@ -14,7 +14,12 @@ ROOT = PKG.parent
 LIB_PATH = PKG / "libcat_sim.so"
 if os.environ.get("CAT_SIM_LIB"):          # diagnostic builds (tools/ab_kernel.sh): another build of the same source
     LIB_PATH = Path(os.environ["CAT_SIM_LIB"]).resolve()
-SRC = PKG / "csrc" / "cat_sim.hip"
+SRC = PKG / "csrc" / "cat_sim.hip"          # one translation unit: it includes csrc/cat_sim_*.h
+
+
+def sources():
+    """Every file of the env core's translation unit (what a rebuild depends on, what bench.py hashes into `profile_stale`)."""
+    return [SRC, *sorted((PKG / "csrc").glob("cat_sim_*.h")), ROOT / "include" / "cat_sim.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared"]
 
 OUT_FIELDS = ("obs_distance", "obs_type", "hit_shape", "shared_distance", "shared_type",
@@ -52,10 +57,7 @@ class NativeLibraryMissing(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP extension in-tree for gfx950 (works without a GPU: hipcc cross-compiles)."""
-    hdr = ROOT / "include" / "cat_sim.h"
-    stale = (not LIB_PATH.exists()
-             or LIB_PATH.stat().st_mtime < SRC.stat().st_mtime
-             or LIB_PATH.stat().st_mtime < hdr.stat().st_mtime)
+    stale = not LIB_PATH.exists() or any(LIB_PATH.stat().st_mtime < f.stat().st_mtime for f in sources())
     if force or stale:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, *HIPCC_FLAGS, f"-I{ROOT / 'include'}", "-o", str(LIB_PATH), str(SRC)]
@@ -108,6 +110,9 @@ def lib() -> C.CDLL:
     L.cat_device_errors.argtypes = [vp, vp, i32, vp]
     L.cat_arm_kernel_timing.argtypes = [vp, vp, vp]
     L.cat_num_agents.argtypes = [vp]
+    if hasattr(L, "cat_chunks_per_unit"):
+        L.cat_chunks_per_unit.argtypes = [vp, i32]
+        L.cat_chunks_per_unit.restype = i32
     L.cat_num_shapes.argtypes = [vp, i32]
     L.cat_selftest_arith.argtypes = [i32, vp, vp, vp, i32, i32, vp]
     L.cat_debug_grid_lookup.argtypes = [vp, i32, C.c_double, C.c_double, i32, vp, i32]
@@ -128,7 +133,7 @@ def lib() -> C.CDLL:
     return L
 
 
-EXPORTED_SYMBOLS = ("cat_abi_version", "cat_one_tick_kernel", "cat_rollout_kernel", "cat_last_error", "cat_create", "cat_destroy", "cat_reset",
+EXPORTED_SYMBOLS = ("cat_abi_version", "cat_one_tick_kernel", "cat_rollout_kernel", "cat_chunks_per_unit", "cat_last_error", "cat_create", "cat_destroy", "cat_reset",
                     "cat_reset_done", "cat_step", "cat_step_fused", "cat_rollout_fused", "cat_get_state", "cat_set_state", "cat_random_actions",
                     "cat_set_seed", "cat_device_errors", "cat_arm_kernel_timing", "cat_num_agents", "cat_num_shapes", "cat_selftest_arith", "cat_debug_grid_lookup",
                     "cat_grid_build_host", "cat_grid_lookup_host", "cat_grid_bytes_host", "cat_grid_free_host", "cat_map_wall_bb_depth_host")

@@ -109,6 +109,10 @@ class CatSim:
             return self._L.cat_rollout_kernel(self._h).decode()
         return "rollout_kernel"   # diagnostic builds of earlier sources
 
+    def chunks_per_unit(self, resident: bool) -> int:
+        """Chunk form of the ray fan: 64-ray chunks of a slot that one work unit traces with one shared item list (1 = chunk by chunk)."""
+        return int(self._L.cat_chunks_per_unit(self._h, int(resident))) if hasattr(self._L, "cat_chunks_per_unit") else 1
+
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 

@@ -217,7 +217,11 @@ def timed_rollout(sim, T: int, fence, hip: "HipEvents", first_tick: int, reps: i
 def source_sha16() -> str:
     """sha256 of the shipped env-core source, first 16 hex digits: what a committed profile must have been collected on to describe this build."""
     import hashlib
-    return hashlib.sha256((ROOT / "as_cops_and_thieves_amd" / "csrc" / "cat_sim.hip").read_bytes()).hexdigest()[:16]
+    h = hashlib.sha256()
+    csrc = ROOT / "as_cops_and_thieves_amd" / "csrc"
+    for f in [csrc / "cat_sim.hip", *sorted(csrc.glob("cat_sim_*.h"))]:    # the env core's one translation unit
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def compute_block(valu):
@@ -264,6 +268,24 @@ def replay_profile(entry: dict, wl: dict, kernel: str, ticks_per_launch: int = 1
         entry["compute"] = compute_block(prof["valu"])
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (the 5 PF headline figure includes 2:1 sparsity)
+
+
+def learner_flops(rays: int, agents: int, epochs: int) -> dict:
+    """FLOPs (2 per multiply-add) of the reference's LSTM pair per agent and sample, from its layer sizes (lstm_policy_net.py:28-53,
+    lstm_value_net.py:46-75; models.py): Conv1d(C->64,k5,s2) Conv1d(64->32,k5,s3) Linear(32*L2->256) LSTM(256->128, 1 or 2 layers) and the heads.
+    Collection = one forward of both networks per agent and env-step; the update = `epochs` passes of forward + backward (2x a forward: data and
+    weight gradients) over every stored sample."""
+    l1 = (rays - 5) // 2 + 1
+    l2 = (l1 - 5) // 3 + 1
+    trunk = lambda c: l1 * 64 * c * 5 + l2 * 32 * 64 * 5 + 32 * l2 * 256
+    policy = trunk(2) + 4 * 128 * (256 + 128) + (128 * 128 + 128 * 64 + 64 * 4)
+    value = trunk(4) + 4 * 128 * (256 + 128) + 4 * 128 * (128 + 128) + (128 * 256 + 256 * 128 + 128 * 64 + 64)
+    fwd = 2.0 * (policy + value) * agents
+    return {"forward_per_env_step": fwd, "collect_per_env_step": fwd, "update_per_env_step": 3.0 * fwd * epochs,
+            "policy_macs_per_sample": policy, "value_macs_per_sample": value}
+
+
 def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16, rank: int = 0, world: int = 1, reduce_device=None) -> dict:
     """SURVEY 8(f) rank 2 beside the headline: env-steps/s of the MAPPO trainer on the same env workload -- rollout
     collection (env tick + the six stacked LSTM networks per tick) plus the PPO update of ``CFG_AGENT`` (4 epochs x 4
@@ -293,6 +315,20 @@ def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16,
         out = {"value": steps / (tc + tu), "unit": "env-steps/s", "rounds": rounds, "horizon": tr.tcfg.horizon,
                "collect_ms": 1e3 * tc / rounds, "update_ms": 1e3 * tu / rounds, "dtype": "bf16",
                "graphs": bool(tr._graph is not None and all(rl._graphs for rl in tr.roles.values()))}
+        # MFMA roofline of the learner: the networks' FLOPs per env-step from their layer sizes against the time the two phases take
+        fl = learner_flops(rays, len(env.possible_agents), max(rl.cfg.learning_epochs for rl in tr.roles.values()))
+        per_round = tr.tcfg.horizon * n_envs           # env-steps of one rank's rollout
+        out["mfma_roofline"] = {
+            "bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "flops_per_env_step": fl["collect_per_env_step"] + fl["update_per_env_step"],
+            "collect_flops_per_env_step": fl["collect_per_env_step"], "update_flops_per_env_step": fl["update_per_env_step"],
+            "achieved": (fl["collect_per_env_step"] + fl["update_per_env_step"]) * per_round / ((tc + tu) / rounds) / 1e12,
+            "achieved_update": fl["update_per_env_step"] * per_round / (tu / rounds) / 1e12,
+            "achieved_collect": fl["collect_per_env_step"] * per_round / (tc / rounds) / 1e12,
+            "what": "per GPU; network FLOPs only (2 per multiply-add; update = epochs x (forward + 2x backward)); the collect phase also holds the env ticks"}
+        out["mfma_roofline"]["frac"] = out["mfma_roofline"]["achieved"] / MFMA_BF16_PEAK_TFLOPS
+        out["mfma_roofline"]["frac_update"] = out["mfma_roofline"]["achieved_update"] / MFMA_BF16_PEAK_TFLOPS
+        out["collect_us_per_tick"] = 1e6 * tc / rounds / tr.tcfg.horizon
         if world > 1:
             import torch.distributed as dist
             out.update({"ranks": world, "envs_per_gpu": n_envs, "allreduce_backend": dist.get_backend(),

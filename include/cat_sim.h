@@ -195,6 +195,9 @@ int cat_abi_version(void);
    counterpart. */
 const char *cat_one_tick_kernel(const cat_sim *sim);
 const char *cat_rollout_kernel(const cat_sim *sim);
+/* Chunk form of the ray fan (dense maps): how many 64-ray chunks of an env slot one work unit traces with one shared item list, in the resident launch
+   (resident != 0) or the one-tick launch; 1 = chunk by chunk.  A sim of two parts: the chunk-form part's figure.  No reference counterpart. */
+int cat_chunks_per_unit(const cat_sim *sim, int resident);
 int cat_num_agents(const cat_sim *sim);
 int cat_num_shapes(const cat_sim *sim, int map_index);
 /* Timing hook for bench.py: seconds spent in the last n recorded step launches are measured by

@@ -43,7 +43,8 @@ print("fault injection ok")
 
 
 def _build():
-    if LIB.exists() and LIB.stat().st_mtime >= SRC.stat().st_mtime:
+    from as_cops_and_thieves_amd import _native
+    if LIB.exists() and all(LIB.stat().st_mtime >= f.stat().st_mtime for f in _native.sources()):
         return
     LIB.parent.mkdir(parents=True, exist_ok=True)
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",

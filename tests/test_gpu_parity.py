@@ -347,6 +347,42 @@ def test_mixed_map_batch_in_two_parts_and_in_one(split, pool, monkeypatch):
     gpu.close()
 
 
+@pytest.mark.parametrize("item_cap,chunks,chunks_tick", [(None, None, None), (None, "3", "3"), ("200", "3", "3"), ("120", "3", "3"), ("48", None, None), (None, "2", "1"), (None, "1", "3")])
+def test_several_chunks_of_a_slot_in_one_work_unit_on_the_dense_map(item_cap, chunks, chunks_tick, monkeypatch):
+    """Chunk form (agh-map): the 64-ray chunks of a slot are traced as ONE work unit with one item list (fan_slot: shape queries of all chunks in shared rounds
+    of 64 items) instead of chunk by chunk.  Held against the oracle as cat_create sets it up for the dense map (two chunks per unit, a list of 240 items),
+    with all three chunks of a 2v1 slot in one unit (a second turn whenever they do not fit together), with shorter lists (200: two chunks + one; 120: one chunk
+    per turn), with a list no chunk fits (48: every chunk is handed back to fan_chunk), and with different unit spans per entry."""
+    import torch
+    from as_cops_and_thieves_amd.config import SimConfig
+    from as_cops_and_thieves_amd.maps import load_preset
+    from as_cops_and_thieves_amd.sim import CatSim
+    from oracle.cat_oracle import OracleSim
+    for k, v in (("CAT_ITEM_CAP", item_cap), ("CAT_SLOT_CHUNKS", chunks), ("CAT_SLOT_CHUNKS_TICK", chunks_tick)):
+        if v is not None:
+            monkeypatch.setenv(k, v)
+    N = 40
+    cfg = SimConfig(n_envs=N, n_rays=64, max_step_count=30, seed=31)
+    m = load_preset("agh-map").compile()
+    stats = _run(cfg, [m], np.zeros(N, np.int32), ticks=45, rng=np.random.default_rng(12), auto_reset=True)
+    assert stats["done"] >= N
+    gpu, cpu = CatSim(cfg, [m], device="cuda:0"), OracleSim(cfg, [m])
+    assert (gpu.chunks_per_unit(True), gpu.chunks_per_unit(False)) == (int(chunks or 2), int(chunks_tick or 2))   # fan_slot is what runs
+    gpu.reset(); cpu.reset()
+    rows = to_np(gpu.rollout_fused(50, None, tick=0, auto_reset=True))
+    torch.cuda.synchronize()
+    for t in range(50):
+        c = cpu.step(cpu.random_actions(t))
+        flags = {k: c[k].copy() for k in ("reward", "terminated", "truncated", "winner")}
+        cpu.reset(mask=c["terminated"].copy())
+        got = {k: v[t] for k, v in rows.items()}
+        assert_outputs_equal(got, cpu.out, keys=("obs_distance", "obs_type", "shared_distance", "shared_type", "team_positions"), ctx=f"resident tick {t}")
+        assert_outputs_equal(got, flags, keys=tuple(flags), ctx=f"resident tick {t}")
+    assert_state_equal(to_np(gpu.get_state()), cpu.get_state(), ctx="resident launch")
+    assert gpu.device_errors() == 0
+    gpu.close()
+
+
 def test_gate_off_parity():
     from as_cops_and_thieves_amd.config import SimConfig
     rng = np.random.default_rng(9)

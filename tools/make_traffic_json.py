@@ -32,6 +32,15 @@ reset_file = Path(a.from_reset) if a.from_reset else root / "profiles" / f"{tag}
 out_file = Path(a.out) if a.out else root / "profiles" / f"{tag}_traffic{suffix}.json"
 
 
+def source_sha16():
+    """sha256 over the env core's translation unit (cat_sim.hip + the cat_sim_*.h it includes), as bench.source_sha16 computes it."""
+    h = hashlib.sha256()
+    csrc = root / "as_cops_and_thieves_amd" / "csrc"
+    for f in [csrc / "cat_sim.hip", *sorted(csrc.glob("cat_sim_*.h"))]:
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def git_head():
     """The commit the profile is collected on: build/GIT_HEAD (tools/stamp_head.sh, written before the gpurun call -- the GPU box gets no .git), else git itself."""
     f = root / "build" / "GIT_HEAD"
@@ -76,7 +85,7 @@ out = {
     "workload_key": key,
     "kernel": a.kernel,
     "ticks_per_launch": T,
-    "source_sha16": hashlib.sha256((root / "as_cops_and_thieves_amd" / "csrc" / "cat_sim.hip").read_bytes()).hexdigest()[:16],   # bench.py: profile_stale
+    "source_sha16": source_sha16(),   # bench.py: profile_stale
     "git_head": git_head(),
     "regime": regime,
     "burn_in": a.burn_in,
