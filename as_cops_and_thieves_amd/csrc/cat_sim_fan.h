@@ -192,24 +192,32 @@ struct LateOut { float reward; unsigned tp16; };   // per-lane values stored at 
 
 // Per-agent setup, published in the env area: grid cell, walls the origin is "inside" (alpha = 0 rule),
 // cones of the other agents' circles; resets the per-agent minimum wanted-class distance.
+// lane i < A: grid cell of agent i (at positions pos[2A]) and the cell's packed contact row -- ONE global round trip for all agents.  The front requests it
+// before its termination check and actions (neither moves the tick-start positions the fan reads), so that the row has arrived when the setup looks at it.
+struct SetupRow { int cell; unsigned long long crow; };
+__device__ __forceinline__ SetupRow setup_row(const double *pos, const Params &p, const GridDesc &gd, int lane, int A)
+{
+    SetupRow r = {-1, 0ull};
+    if (lane < A) {
+        const double ax = pos[2 * lane], ay = pos[2 * lane + 1];
+        const int cx = (int)floor((ax - gd.x0) * gd.inv_cell), cy = (int)floor((ay - gd.y0) * gd.inv_cell);
+        if (cx >= 0 && cy >= 0 && cx < gd.nx && cy < gd.ny) {
+            r.cell = cy * gd.nx + cx;
+            r.crow = G(p.cgrid_rows)[gd.crow_base + r.cell];
+        }
+    }
+    return r;
+}
+
 template <class D>
-__device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, int lane)
+__device__ void agent_setup(const Lds &L, const Params &p, const GridDesc &gd, int lane, const SetupRow &row)
 {
     const int A = D::A(p), R = D::R(p);
     const double r2 = p.ray_radius;
     const double reach = p.ray_length + r2 + 1e-6;
     const double cone_m = p.gate ? 1e-6 : r2 + 1e-6;
-    int my_cell = -1, my_near0 = -1, my_near1 = -1, my_dk0 = 0, my_dcnt = 0;
-    // lane i < A: grid cell of agent i and the cell's packed contact row -- ONE global round trip for all agents
-    unsigned long long crow = 0ull;
-    if (lane < A) {
-        const double ax = L.fpos[2 * lane], ay = L.fpos[2 * lane + 1];
-        const int cx = (int)floor((ax - gd.x0) * gd.inv_cell), cy = (int)floor((ay - gd.y0) * gd.inv_cell);
-        if (cx >= 0 && cy >= 0 && cx < gd.nx && cy < gd.ny) {
-            my_cell = cy * gd.nx + cx;
-            crow = G(p.cgrid_rows)[gd.crow_base + my_cell];
-        }
-    }
+    int my_cell = row.cell, my_near0 = -1, my_near1 = -1, my_dk0 = 0, my_dcnt = 0;
+    const unsigned long long crow = row.crow;
     {   // lane = 8 i + q: is agent i's origin within the ray radius of the cell's q-th candidate wall?
         const int pi = lane >> 3, pq = lane & 7;
         const unsigned lo = (unsigned)__shfl((int)(unsigned)crow, pi), hi = (unsigned)__shfl((int)(unsigned)(crow >> 32), pi);
@@ -491,9 +499,9 @@ __device__ void fan_chunk(const Lds &L, const Params &p, const LaunchArgs &la, c
 // Several 64-ray chunks of one slot (chunks c0 .. c0 + nq - 1, nq <= kSlotChunks) as ONE work unit with ONE item list (dense maps, chunk form).  Chunk by
 // chunk the item rounds of fan_chunk run 64 + ~20 lanes wide (agh-map: 81 items per chunk, 5.9 rounds of 41 items per env-step): here every chunk's rays are
 // gated and packed first, each by its own lane as in fan_chunk, then the shape queries of ALL chunks run in rounds of 64 items, then every chunk's rays walk
-// their items and finish.  What a ray keeps between packing and walk is the bit mask of its live positions (kSlotPos bits per chunk in one register) -- its
-// items' indices follow from the ballots of those bits in packing order.  The per-ray arithmetic and the visiting rule are fan_chunk's (every position is
-// gated against the initial best alpha 1.0; the walk applies the sequential rule), so the results are identical.  The list holds Params::item_cap items;
+// their items and finish.  What a ray keeps between packing and walk is its candidate count and the offset of its items (kSlotPos bits per chunk in one
+// register).  The per-ray arithmetic and the visiting rule are fan_chunk's (every candidate gets an item with its gate value; the shape query runs where
+// the gate value is below the initial best alpha 1.0; the walk applies the sequential rule), so the results are identical.  The list holds Params::item_cap items;
 // chunks that do not fit together are traced in a second turn (a bound on a chunk's items -- the sum of its rays' candidate counts -- is known before it is
 // packed), and a chunk that alone exceeds the list is handed back to the caller for fan_chunk.
 // Requires (cat_create): one-word rows of id fields (row_id_bits != 0, row_words == 1), shape ids S + A <= 127, at most kSlotPos candidates per ray.
@@ -522,7 +530,7 @@ __device__ __forceinline__ unsigned fan_slot(const Lds &L, const Params &p, cons
         const size_t r = (cell < 0 || k >= R) ? 0 : (size_t)cell * R + k;
         return G(p.grid_rows)[gd.row_base + r];
     };
-    unsigned long long live_bits = 0ull;   // bit kSlotPos * q + jj: the ray's candidate at position jj of chunk q got an item
+    unsigned long long live_bits = 0ull;   // kSlotPos bits per chunk q: the ray's candidate count (4 bits) | the offset of its further candidates' items (10 bits)
     unsigned starts = 0u;                   // bits 10 * q ...: the first item of chunk q (wave-uniform)
     unsigned pending = (1u << nq) - 1u, legacy = 0u;
     while (pending) {   // (one turn, unless the chunks do not fit the list together)
@@ -557,33 +565,64 @@ __device__ __forceinline__ unsigned fan_slot(const Lds &L, const Params &p, cons
             const int kk = k < R ? k : 0;
             const double bx = ax + L.rayd[2 * kk], by = ay + L.rayd[2 * kk + 1];  // entity.py:191-193
             const double rdx = bx - ax, rdy = by - ay, rix = 1.0 / rdx, riy = 1.0 / rdy;
-            unsigned lb = 0u;
             starts = (starts & ~(1023u << (10 * q))) | ((unsigned)n_items << (10 * q));
-            for (int jj = 0; __ballot(cnt > jj) != 0ull; jj++) {
-                const bool has = cnt > jj;
-                int id = 0;
-                double tbb = 0.0;
-                if (has) {
-                    if (jj < cnt_w) id = (int)((w >> (idb * jj)) & ((1ull << idb) - 1ull)) - 1;
-                    else {
-                        unsigned dj = dynmask;
-                        for (int z = jj - cnt_w; z > 0; z--) dj &= dj - 1;
-                        id = S + __builtin_ctz(dj);
-                    }
-                    // the BBTree gate value, by the ray's own lane: a candidate whose t_bb is not below the initial best alpha can never be visited
-                    if (gate) tbb = bb_segment_query((id < S) ? (L.bb + kBB * id) : (L.fleaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy);
-                }
-                const bool live = has && tbb < 1.0;
-                const unsigned long long m = __ballot(live);
-                if (live) {
-                    const int t = n_items + __popcll(m & lt_mask);
-                    itm[t] = (unsigned short)(lane | (id << 6) | (q << 13));
-                    itbb[t] = tbb;
-                    lb |= 1u << jj;
-                }
-                n_items += __popcll(m);
+            // Candidate (ray, position) -> item, every candidate (the gate value goes with it; the shape query is skipped where it says "never visited"):
+            // position 0 by the ray's own lane -- every ray of a dense map has one --, the positions from 1 on FLATTENED over the lanes.  Position by position
+            // on the ray's own lane the loop runs to the longest list of the chunk (agh-map: five turns, 100 / 25 / 8 / 3 / 1 % of the lanes busy with the f64
+            // slab test); flattened, the ~22 further candidates of a chunk take one turn.
+            auto candidate_id = [&](unsigned long long row, unsigned dyn, int nw, int jj) -> int {
+                if (jj < nw) return (int)((row >> (idb * jj)) & ((1ull << idb) - 1ull)) - 1;
+                unsigned dj = dyn;
+                for (int z = jj - nw; z > 0; z--) dj &= dj - 1;
+                return S + __builtin_ctz(dj);
+            };
+            const unsigned long long m0 = __ballot(cnt > 0);
+            if (cnt > 0) {
+                const int id = candidate_id(w, dynmask, cnt_w, 0);
+                const int t = n_items + __popcll(m0 & lt_mask);
+                itm[t] = (unsigned short)(lane | (id << 6) | (q << 13));
+                // the BBTree gate value: a candidate whose t_bb is not below the initial best alpha can never be visited
+                itbb[t] = gate ? bb_segment_query((id < S) ? (L.bb + kBB * id) : (L.fleaf + 4 * (id - S)), ax, ay, rdx, rdy, rix, riy) : 0.0;
             }
-            live_bits = (live_bits & ~(0xFFFFull << (kSlotPos * q))) | ((unsigned long long)lb << (kSlotPos * q));
+            n_items += __popcll(m0);
+            const int ex = cnt > 1 ? cnt - 1 : 0;   // further candidates of this lane's ray
+            int pre = 0, n_ex = 0;                  // exclusive prefix over the lanes, total
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const unsigned long long mb = __ballot((ex >> b) & 1);
+                pre += __popcll(mb & lt_mask) << b; n_ex += __popcll(mb) << b;
+            }
+            if (n_ex) {
+                unsigned char *const own = reinterpret_cast<unsigned char *>(ialpha);   // [n_ex] flat index -> ray lane (the alpha array is idle until the shape queries)
+                for (int j = 0; __ballot(j < ex) != 0ull; j++)
+                    if (j < ex) own[pre + j] = (unsigned char)lane;
+                wave_sync();
+                const int rix_lo = (int)__double_as_longlong(rix), rix_hi = (int)(__double_as_longlong(rix) >> 32);
+                const int riy_lo = (int)__double_as_longlong(riy), riy_hi = (int)(__double_as_longlong(riy) >> 32);
+                for (int f0 = 0; f0 < n_ex; f0 += kLanes) {
+                    const int f = f0 + lane;
+                    const int r = f < n_ex ? (int)own[f] : 0;             // the ray (lane) this candidate belongs to; its row, cone mask and reciprocals by lane permute
+                    const int a4 = 4 * r;
+                    const int jj = f - __builtin_amdgcn_ds_bpermute(a4, pre) + 1;
+                    const unsigned long long rw = ((unsigned long long)(unsigned)__builtin_amdgcn_ds_bpermute(a4, (int)(w >> 32)) << 32) | (unsigned)__builtin_amdgcn_ds_bpermute(a4, (int)w);
+                    const unsigned rdyn = (unsigned)__builtin_amdgcn_ds_bpermute(a4, (int)dynmask);
+                    const double fix = __longlong_as_double(((long long)__builtin_amdgcn_ds_bpermute(a4, rix_hi) << 32) | (unsigned)__builtin_amdgcn_ds_bpermute(a4, rix_lo));
+                    const double fiy = __longlong_as_double(((long long)__builtin_amdgcn_ds_bpermute(a4, riy_hi) << 32) | (unsigned)__builtin_amdgcn_ds_bpermute(a4, riy_lo));
+                    if (f < n_ex) {
+                        const int kr = kb + r;   // (a ray with candidates lies inside the agent's R rays)
+                        const double fbx = ax + L.rayd[2 * kr], fby = ay + L.rayd[2 * kr + 1];
+                        const double fdx = fbx - ax, fdy = fby - ay;   // the same operands as on the ray's own lane: bit-identical
+                        const int id = candidate_id(rw, rdyn, row_count(rw), jj);
+                        const int t = n_items + f;
+                        itm[t] = (unsigned short)(r | (id << 6) | (q << 13));
+                        itbb[t] = gate ? bb_segment_query((id < S) ? (L.bb + kBB * id) : (L.fleaf + 4 * (id - S)), ax, ay, fdx, fdy, fix, fiy) : 0.0;
+                    }
+                }
+                n_items += n_ex;
+                wave_sync();   // the next chunk's `own` table goes over this one
+            }
+            // what the ray keeps for its walk: its candidate count and where its further candidates' items start
+            live_bits = (live_bits & ~(0xFFFFull << (kSlotPos * q))) | ((unsigned long long)((unsigned)cnt | ((unsigned)pre << 4)) << (kSlotPos * q));
             batch |= 1u << q;
         }
         wave_sync();
@@ -599,7 +638,7 @@ __device__ __forceinline__ unsigned fan_slot(const Lds &L, const Params &p, cons
                 const double cbx = o2.x + L.rayd[2 * k2], cby = o2.y + L.rayd[2 * k2 + 1];
                 double alpha = 2.0;   // 2.0 = no hit (never below a best alpha <= 1)
                 int feat = 0;
-                {
+                if (itbb[t] < 1.0) {   // (else: never visited, whatever the ray has found by then)
                     const bool wall = id < S;
                     const int j = wall ? 0 : id - S;
                     const bool inside = wall ? (id == L.anear[2 * ia] || id == L.anear[2 * ia + 1]) : ((((unsigned)L.adn[ia] >> j) & 1u) != 0u);
@@ -620,19 +659,19 @@ __device__ __forceinline__ unsigned fan_slot(const Lds &L, const Params &p, cons
             if (!((batch >> q) & 1u)) continue;
             const int c = c0 + q, i = c / cpa, kb = (c - i * cpa) * kLanes, k = kb + lane;
             const bool active = k < R;
-            const unsigned lb = (unsigned)(live_bits >> (kSlotPos * q)) & 0xFFFFu;
+            const unsigned kept = (unsigned)(live_bits >> (kSlotPos * q)) & 0xFFFFu;
+            const int cnt = (int)(kept & 15u), pre = (int)(kept >> 4);
             double best_a = 1.0;
             int best_fi = -1;   // id << 6 | feature of the accepted item
-            int base = (int)((starts >> (10 * q)) & 1023u);
-            for (int jj = 0; __ballot((lb >> jj) != 0u) != 0ull; jj++) {
-                const bool live = ((lb >> jj) & 1u) != 0u;
-                const unsigned long long m = __ballot(live);
-                if (live) {
-                    const int t = base + __popcll(m & lt_mask);
+            const int base = (int)((starts >> (10 * q)) & 1023u);
+            const unsigned long long m0 = __ballot(cnt > 0);
+            const int t_first = base + __popcll(m0 & lt_mask), t_more = base + __popcll(m0) + pre - 1;   // the item of position 0; of position jj >= 1: t_more + jj
+            for (int jj = 0; __ballot(jj < cnt) != 0ull; jj++) {
+                if (jj < cnt) {
+                    const int t = jj == 0 ? t_first : t_more + jj;
                     const double al = ialpha[t];
                     if (al < best_a && itbb[t] < best_a) { best_a = al; best_fi = itm[t]; }   // t_exit == best alpha
                 }
-                base += __popcll(m);
             }
             PHASE(pc, 7);
             const double ax = L.fpos[2 * i], ay = L.fpos[2 * i + 1];
@@ -910,11 +949,12 @@ __device__ void rewards_and_positions(const Lds &L, const Params &p, const Launc
         late.reward = r;
     }
     if (lane < 2 * A) late.tp16 = f64_to_f16(L.fpos[lane]);
-    // Wait for the LUT value HERE, while no store is in flight: a load still pending when the write-back stores
-    // start makes the compiler's (in-order) vmcnt waits sit on the acknowledgement of every store issued before
-    // them -- 18 k cycles per slot in the write-back before this line.
-    asm volatile("" : "+v"(late.reward));
 }
+// Wait for the LUT value of rewards_and_positions, while no store is in flight: a load still pending when the write-back stores
+// start makes the compiler's (in-order) vmcnt waits sit on the acknowledgement of every store issued before
+// them -- 18 k cycles per slot in the write-back before this wait existed.  (Called after the LDS-only staging of the shared
+// observations, which the lookup's round trip then overlaps.)
+__device__ __forceinline__ void await_reward(LateOut &late) { asm volatile("" : "+v"(late.reward)); }
 
 // LDS -> HBM copy of n bytes with the widest store both sides allow (LDS side is 16-byte aligned)
 __device__ __forceinline__ void wide_store(void *gdst, const void *lsrc, int n, int lane)
@@ -931,17 +971,12 @@ __device__ __forceinline__ void wide_store(void *gdst, const void *lsrc, int n, 
     }
 }
 
-// All output stores, issued at the very end of the kernel: the compiler's s_waitcnt vmcnt(0) (in-order
-// with stores, and forced by every flat access) would otherwise stall mid-kernel on HBM write latency.
+// get_shared_observations (observation_spaces.py:98-129) into the slot's staging (LDS only): first team member, roster order, with a non-EMPTY ray
+// supplies (type, distance); else EMPTY with the last member's distance.  Runs while the write-back's reward lookup is in flight.
 template <class D>
-__device__ __forceinline__ void emit_observations(const Lds &L, const Params &p, const LaunchArgs &la, long long env, int lane,
-                                                  int rew_mode, const LateOut &late)
+__device__ __forceinline__ void stage_shared_observations(const Lds &L, const Params &p, int lane)
 {
     const int A = D::A(p), R = D::R(p);
-    if (rew_mode && lane < A && la.out.reward) la.out.reward[(size_t)env * A + lane] = late.reward;
-    if (lane < 2 * A && la.out.team_positions) la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)late.tp16;
-    // get_shared_observations (observation_spaces.py:98-129): first team member, roster order,
-    // with a non-EMPTY ray supplies (type, distance); else EMPTY with the last member's distance
     for (int k = lane; k < R; k += kLanes) {
         for (int team = 0; team < 2; team++) {
             const int lo = team ? D::n_cops(p) : 0, hi = team ? A : D::n_cops(p);
@@ -953,6 +988,17 @@ __device__ __forceinline__ void emit_observations(const Lds &L, const Params &p,
         }
     }
     wave_sync();
+}
+
+// All output stores, issued at the very end of the kernel: the compiler's s_waitcnt vmcnt(0) (in-order
+// with stores, and forced by every flat access) would otherwise stall mid-kernel on HBM write latency.
+template <class D>
+__device__ __forceinline__ void emit_observations(const Lds &L, const Params &p, const LaunchArgs &la, long long env, int lane,
+                                                  int rew_mode, const LateOut &late)
+{
+    const int A = D::A(p), R = D::R(p);
+    if (rew_mode && lane < A && la.out.reward) la.out.reward[(size_t)env * A + lane] = late.reward;
+    if (lane < 2 * A && la.out.team_positions) la.out.team_positions[(size_t)env * A * 2 + lane] = (unsigned short)late.tp16;
     const size_t g0 = (size_t)env * A * R;   // Entity.get_observation outputs: [A*R] contiguous per env
     if (la.out.obs_distance) wide_store(la.out.obs_distance + g0, L.od, A * R * 2, lane);
     if (la.out.obs_type) wide_store(la.out.obs_type + g0, L.ot, A * R, lane);

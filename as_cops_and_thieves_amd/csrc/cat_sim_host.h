@@ -429,6 +429,14 @@ static LdsSizes lds_sizes(int A, int R, int maxS, int maxP, int maxPP, bool grou
     eb += (3 * A + 2 * A * A + A + A + 4) * 4;                     // acell, anear, dk0, dcnt, adn, dmin, flags
     eb = up(eb, 16) + up(A * R * 2, 16) + up(A * R, 16) + up(2 * R * 2, 16) + up(2 * R, 16);   // output staging
     z.env = up(eb, 16);
+    // The pooled rounds address env areas PER LANE (a round's rays come from several slots: origin, cached circles, "inside" walls, output staging of the
+    // lane's slot).  An area of a multiple of 256 bytes -- 2v1 at 64 rays: exactly 2048 -- puts the same field of every slot on the same LDS banks; with
+    // 16 A bytes more (the step between two agents' 16-byte fields) neighbouring slots' fields of any two agents fall on different banks.  CAT_ENV_PAD=0: off.
+    {
+        const char *e = getenv("CAT_ENV_PAD");
+        const int want = (16 * A) % 256;
+        if (!(e && atoi(e) == 0) && want != 0 && z.env % 256 != want) z.env += (want - z.env % 256 + 256) % 256;
+    }
     return z;
 }
 
@@ -828,8 +836,13 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
             const bool fixed_roster = !(getenv("CAT_GENERIC_KERNEL") && atoi(getenv("CAT_GENERIC_KERNEL")) != 0) && cfg->n_rays == 64 && ((A == 3 && cfg->n_cops == 2) || (A == 5 && cfg->n_cops == 3));
             // (fan_slot is carried by the chunk-form kernels of fixed dimensions only -- select_kernels: 2v1 and 3v2 at 64 rays; 2v1 / 1v1 at 90 rays and the generic
             //  kernels keep one chunk per unit: with run-time dimensions the unit needs scratch)
-            if (fan == 0 && fixed_roster && wide && grid_host.row_words == 1 && maxS + A <= 127 && nch >= 2 && grid_host.max_row + A - 1 <= kSlotPos) {
-                const size_t spare = (160 * 1024 - ls.total(wpb)) / (size_t)wpb;
+            if (fan == 0 && fixed_roster && wide && grid_host.row_words == 1 && maxS + A <= 127 && nch >= 2 && grid_host.max_row + A - 1 <= 15) {
+#ifdef CAT_PHASE_TIMING
+                const size_t budget = 160 * 1024 - 4096;   // (the diagnostic build keeps its cycle accumulators in static LDS)
+#else
+                const size_t budget = 160 * 1024;
+#endif
+                const size_t spare = ls.total(wpb) < budget ? (budget - ls.total(wpb)) / (size_t)wpb : 0;
                 int cap = (int)(((size_t)ls.uni + spare) / 18) & ~7;
                 if (cap > 768) cap = 768;
                 if (const char *e = getenv("CAT_ITEM_CAP")) { const int v = atoi(e); if (v >= 16 && v <= cap) cap = v & ~7; }   // tests: lists too short for the chunks of a slot
@@ -899,8 +912,14 @@ extern "C" int cat_create(const cat_config *cfg, const cat_tables *tab, const vo
             const int cpa = (cfg->n_rays + 63) / 64, gsz = cpa <= 2 ? 2 : 1;
             const int g_full = kLanes * std::min(4, std::min(A, gsz) * cpa), g_one = kLanes * std::min(4, cpa);
             const bool ok_dims = A <= 8 && cfg->n_rays <= 256 && wpb <= 16 && cpa <= 4;
+            // While the one-tick launch stays on the unit form, the ring may not take the group arrays below what that kernel's units want (rosters whose rays
+            // fill more than four chunks: as many agents as fill four -- group_agents_resident).  3v2 at 64 rays x8192, round 5: with the ring (units of
+            // 2 + 2 + 1 agents in the one-tick launch instead of 4 + 1) 102.5 us one-tick / 75.2 resident, without 95.9 - 97.4 / 76.1 - 77.6: the one-tick launch
+            // is the one this library is measured on, so the ring stays out (CAT_POOL=1 brings it in: both entries pooled).
+            const bool forced = getenv("CAT_POOL") != nullptr;
+            const int g_want = (!pool_step && !forced && A * cpa > 4) ? kLanes * 4 : 0;
             for (int attempt = 0; ok_dims && attempt < 3 && !pool_cap; attempt++) {
-                const int cap = attempt == 0 ? cap2 : cap_x, g2 = attempt < 2 ? g_full : g_one;
+                const int cap = attempt == 0 ? cap2 : cap_x, g2 = std::max(attempt < 2 ? g_full : g_one, g_want);
                 const LdsSizes l2 = lds_sizes(A, cfg->n_rays, maxS, maxP, maxPP, true, maxc, g2);
                 if (l2.total(wpb) + 16 + (size_t)cap * 8 <= 160 * 1024) { pool_cap = cap; grp_rays = g2; ls = l2; }
             }

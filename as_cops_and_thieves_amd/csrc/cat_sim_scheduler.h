@@ -227,6 +227,8 @@ __device__ __forceinline__ void slot_writeback(const Lds &Ls, const Params &p, c
 {
     LateOut late;
     rewards_and_positions<D>(Ls, p, la, lane, tick, captured2, timeout2, cop_lut, thief_lut, late);
+    stage_shared_observations<D>(Ls, p, lane);
+    await_reward(late);
     PHASE(pc, 17);
     const unsigned char term = (unsigned char)(captured2 || timeout2);
     if (lane == 0) {   // a slot that went through a reset (rcount >= 0) starts its new episode: base_env.py:350
@@ -428,9 +430,11 @@ __device__ __forceinline__ int slot_front(const Lds &L, ParamsK pk, const Launch
     // three sub-phases, each from a freshly laundered parameter pointer: what one has loaded does not stay alive through the next
     // (the rare auto-reset path inlines Space.step and the spawn sampling between the two common ones)
     int captured, timeout, step;
+    SetupRow row;
     {
         const Params &p = *(const Params *)launder(pk);
         const int S = md.S, A = D::A(p);
+        row = setup_row(L.pos, p, gd, lane, A);                             // the setup's global round trip, under the termination check and the actions
         step = uni(L.cnt[0]) + 1;                                           // :372
         captured = termination_captured<D>(L, p, S, lane);                     // :378
         timeout = (!captured && step >= p.max_step) ? 1 : 0;
@@ -472,11 +476,12 @@ __device__ __forceinline__ int slot_front(const Lds &L, ParamsK pk, const Launch
             wave_sync();
             copy_snapshot(L, D::A(p), lane);
             n_units -= 1; step_store = 0;
+            row = setup_row(L.fpos, p, gd, lane, D::A(p));           // the agents have moved to their spawn points
         }
     }
     {
         const Params &p = *(const Params *)launder(pk);
-        agent_setup<D>(L, p, gd, lane);                              // entity.py:143-144, :388-390 (setup part)
+        agent_setup<D>(L, p, gd, lane, row);                         // entity.py:143-144, :388-390 (setup part)
         PHASE(pc, 4);
     }
     if (lane == 0) { L.flags[0] = step_store; L.flags[1] = captured; L.flags[2] = timeout; L.flags[3] = rcount; }
@@ -1264,7 +1269,7 @@ __device__ __forceinline__ void reset_slot(const Lds &L, const Params &p, const 
     spawn_and_reset<D>(L, p, la, md, env, rc, lane);
     wave_sync();
     copy_snapshot(L, A, lane);   // fresh positions, stale circle caches and leaf bbs (Q1); overwrites the spawn points
-    agent_setup<D>(L, p, gd, lane);                                  // :334-344 (setup part)
+    agent_setup<D>(L, p, gd, lane, setup_row(L.fpos, p, gd, lane, A));   // :334-344 (setup part)
     if (lane == 0) { L.flags[0] = 0; L.flags[1] = 0; L.flags[2] = 0; L.flags[3] = (int)rc; }  // :350
     publish_slot(L, wave, lane, fan_units<D>(p));
 }

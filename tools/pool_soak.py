@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""GPU box: the pooled and the unit scheduler of the light-maps fan against each other at full batch size over a long run: N envs x TICKS ticks of
-the bench workload (400-tick episodes, in-kernel actions and auto-reset) through (a) one-tick launches of the pooled kernels, (b) resident launches of the
-pooled kernels (T ticks each), (c) one-tick launches of the unit form -- one process each (CAT_POOL is read at cat_create); prints a SHA-256 of the final
-state and of the last tick's outputs, the device error word, and the rate.  usage: tools/pool_soak.py [map] [envs] [ticks] [T]"""
+"""GPU box: the schedulers of one workload against each other at full batch size over a long run: N envs x TICKS ticks of the bench workload (400-tick
+episodes, in-kernel actions and auto-reset) through one-tick launches and through resident launches (T ticks each), under each scheduler choice -- one
+process each (the choices are read at cat_create); prints a SHA-256 of the final state and of the last tick's outputs, the device error word, and the rate.
+Light maps: CAT_POOL = 1 / 0 (pooled / unit form of the group fan; for 3v2 CAT_POOL=1 also brings the ring in).  "mixed" (the five maps): CAT_SPLIT = 1 / 0
+(two parts on two streams / one part on the chunk form).  All eight (four) hashes of a workload must be equal.
+usage: tools/pool_soak.py [map] [envs] [ticks] [T] [cops] [thieves]"""
 import hashlib, os, subprocess, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -11,11 +13,13 @@ name = sys.argv[1] if len(sys.argv) > 1 else "labyrinth"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 TICKS = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
 T = int(sys.argv[4]) if len(sys.argv) > 4 else 256
-if len(sys.argv) > 5:   # child: mode
+NC = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+NT = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+if len(sys.argv) > 7:   # child: mode
     import torch
     import bench
-    mode = sys.argv[5]
-    sim, cfg, cmap = bench.build_sim(name, 2, 1, N, 64, 0, torch.device("cuda", 0))
+    mode = sys.argv[7]
+    sim, cfg, cmap = bench.build_sim(name, NC, NT, N, 64, 0, torch.device("cuda", 0))
     sim.reset()
     torch.cuda.synchronize(); t0 = time.time()
     if mode == "resident":
@@ -32,11 +36,13 @@ if len(sys.argv) > 5:   # child: mode
     ho = hashlib.sha256()
     for k in sorted(out):
         if k != "hit_shape": ho.update(out[k].cpu().numpy().tobytes())
-    print(f"{mode:9s} kernel {sim.one_tick_kernel if mode != 'resident' else sim.rollout_kernel:22s} state {h.hexdigest()[:16]} outputs {ho.hexdigest()[:16]} "
+    print(f"{mode:9s} kernel {sim.one_tick_kernel if mode != 'resident' else sim.rollout_kernel:36s} state {h.hexdigest()[:16]} outputs {ho.hexdigest()[:16]} "
           f"device errors {sim.device_errors()}  {N * TICKS / dt / 1e6:.1f} M env-steps/s")
     sys.exit(0)
-print(f"{name} x{N}, {TICKS} ticks ({N * TICKS / 1e6:.1f} M env-steps per run), resident launches of {T} ticks")
-for mode, pool in (("one-tick", "1"), ("resident", "1"), ("one-tick", "0"), ("resident", "0")):
-    env = dict(os.environ, CAT_POOL=pool)
-    r = subprocess.run([sys.executable, __file__, name, str(N), str(TICKS), str(T), mode], env=env, capture_output=True, text=True, timeout=600)
-    print(f"CAT_POOL={pool}", (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1])
+print(f"{name} {NC}v{NT} x{N}, {TICKS} ticks ({N * TICKS / 1e6:.1f} M env-steps per run), resident launches of {T} ticks")
+switches = [("CAT_SPLIT", "1"), ("CAT_SPLIT", "0")] if name == "mixed" else [("CAT_POOL", "1"), ("CAT_POOL", "0")]
+for key, val in switches:
+    for mode in ("one-tick", "resident"):
+        env = dict(os.environ, **{key: val})
+        r = subprocess.run([sys.executable, __file__, name, str(N), str(TICKS), str(T), str(NC), str(NT), mode], env=env, capture_output=True, text=True, timeout=900)
+        print(f"{key}={val}", (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1])
