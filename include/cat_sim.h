@@ -142,8 +142,11 @@ int cat_reset_done(cat_sim *sim, const cat_outputs *out, void *stream);
 int cat_step(cat_sim *sim, const int32_t *actions, const cat_outputs *out, void *stream);
 
 /* Device-side error flags raised by the kernels since the last clear (synchronises `stream`); flags != 0 also sets
-   cat_last_error.  CAT_DEVERR_CONTACT_DROPPED: an agent touched more than CAT_WALL_CACHE walls in one step and a
-   contact got no constraint (Chipmunk's arbiter hash has no such limit). */
+   cat_last_error.  CAT_DEVERR_CONTACT_DROPPED: an agent touched more than CAT_WALL_CACHE walls in one step, or an env had
+   more simultaneous contacts than cat_create proved possible for its maps (agents x the deepest overlap of wall bounding
+   boxes one agent can reach, + agent pairs), and a contact got no constraint (Chipmunk's arbiter hash has no such limit).
+   The asynchronous entries cannot fail on these: a caller reads the word where it needs the results to be valid (the
+   reference raises at once: entity.py:126-134). */
 #define CAT_DEVERR_BAD_ACTION 1u
 #define CAT_DEVERR_CONTACT_DROPPED 2u
 #define CAT_DEVERR_SCHEDULER 4u   /* internal: a work item of the pooled ray fan never arrived (the launch left instead of hanging); results of that launch are invalid */
