@@ -298,8 +298,23 @@ def learner_throughput(map_name: str, n_envs: int, rays: int, horizon: int = 16,
         from as_cops_and_thieves_amd.selfplay.mappo import MAPPOTrainer, TrainerConfig
         # world > 1: every rank trains on its own env shard inside the job's process group -- the trainer all-reduces its
         # [G, P + 1] gradient | KL buffer every optimiser step (RCCL over xGMI when the group is nccl)
-        env = VecCopsEnv(load_preset(map_name), num_envs=n_envs, num_rays=rays, max_step_count=400, env_id_offset=rank * n_envs)
-        tr = MAPPOTrainer(env, None, TrainerConfig(horizon=horizon), seed=0)
+        env = tr = None
+        build_error = None
+        try:    # what can fail on ONE rank only (memory, a build problem, an unsupported shape) fails here, before the trainer's first collective
+            env = VecCopsEnv(load_preset(map_name), num_envs=n_envs, num_rays=rays, max_step_count=400, env_id_offset=rank * n_envs)
+            tr = MAPPOTrainer(env, None, TrainerConfig(horizon=horizon), seed=0)
+        except Exception as exc:   # noqa: BLE001
+            build_error = exc
+        if world > 1:   # every rank learns whether every rank is ready: all run the leg or all skip it (a rank missing from the all-reduces would hang the rest)
+            import torch.distributed as dist
+            ok = torch.tensor([0 if build_error else 1], dtype=torch.int32, device=reduce_device if reduce_device is not None else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if env is not None:
+                    env.close()
+                return {"value": None, "error": repr(build_error)[:200] if build_error else "another rank could not build its trainer"}
+        elif build_error is not None:
+            raise build_error
         for _ in range(3):
             tr.collect(); tr.update()
         torch.cuda.synchronize()
