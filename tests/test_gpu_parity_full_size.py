@@ -64,6 +64,33 @@ def test_every_slot_matches_the_oracle(label, names, cops, thieves, N, ticks, ma
         cat_oracle.lib().cato_set_threads(1)
 
 
+@pytest.mark.parametrize("label,names,cops,thieves,N,switch", [
+    ("configs[3] grandbyrinth 3v2 x8192 with the ring in (CAT_POOL=1: both entries pooled)", ["grandbyrinth"], 3, 2, 8192, ("CAT_POOL", "1")),
+    ("configs[4] five maps x16384 in two parts (CAT_SPLIT=1: one dispatch per fan form on two streams)", FIVE, 2, 1, 16384, ("CAT_SPLIT", "1")),
+])
+def test_the_optional_schedulers_at_full_size(label, names, cops, thieves, N, switch, monkeypatch):
+    """What cat_create does not choose by itself, at the BASELINE sizes: the pooled kernels for the 3v2 roster (the ring of exact capacity beside group arrays
+    for two agents) and the mixed batch cut into a pooled group-form part and a chunk-form part -- every slot, outputs and state, against the oracle through
+    one-tick launches, then one resident launch for the second half of the ticks."""
+    import torch
+    from oracle import cat_oracle
+    monkeypatch.setenv(*switch)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    cat_oracle.lib().cato_set_threads(threads)
+    try:
+        gpu, cpu = _full_pair(names, cops, thieves, N, 64, 25, seed=20261006)
+        want = {"CAT_POOL": ("step_kernel_pooled", "rollout_kernel_pooled"), "CAT_SPLIT": ("step_kernel_pooled+step_kernel", "rollout_kernel_pooled+rollout_kernel")}[switch[0]]
+        assert (gpu.one_tick_kernel, gpu.rollout_kernel) == want
+        g, c = gpu.reset(), cpu.reset()
+        torch.cuda.synchronize()
+        assert_outputs_equal(to_np(g), c, keys=OBS_KEYS, ctx=f"{label}: reset")
+        _lockstep(gpu, cpu, 60, set(range(0, 60, 6)) | {59}, label, resident_from=30)
+        assert int(cpu.get_state()["reset_count"].min()) >= 2
+        gpu.close()
+    finally:
+        cat_oracle.lib().cato_set_threads(1)
+
+
 def test_configs2_at_its_stated_size_and_a_shard_at_its_real_offset():
     """BASELINE configs[2] as stated: agh-map 2v1, 32768 envs.  (i) all of them in ONE batch on one GPU, 60 ticks of 25-tick episodes, every slot against the
     oracle; (ii) the shard rank 7 of an 8-GPU job owns -- 4096 slots at env_id_offset 28672, which key their Philox streams with the GLOBAL env ids -- run as
