@@ -65,6 +65,13 @@ for rep in range(3):
         for u in range(nu):
             q(s[:, 2 + 2 * u] - s[:, 1], f"unit {u}: wait publish -> start")
             q(s[:, 3 + 2 * u] - s[:, 2 + 2 * u], f"unit {u}: duration")
+        if nu < 5:   # the next unit exists on some slots only (Space.step: not where the front ran it for an auto-reset)
+            ok = (s[:, 3 + 2 * nu] > 0) & (s[:, 3 + 2 * nu] >= s[:, 2 + 2 * nu]) & (s[:, 2 + 2 * nu] > s[:, 1])
+            if ok.any():
+                q((s[:, 2 + 2 * nu] - s[:, 1])[ok], f"unit {nu} (on {ok.mean():.3f} of the slots): wait")
+                q((s[:, 3 + 2 * nu] - s[:, 2 + 2 * nu])[ok], f"unit {nu}: duration")
+                q((s[:, 3 + 2 * nu])[ok], f"unit {nu}: ends at")
+                q((s[:, 12] - s[:, 3 + 2 * nu])[ok], f"unit {nu} end -> write-back start")
         last_end = np.max(s[:, [3 + 2 * u for u in range(nu)]], axis=1)
         q(s[:, 12] - last_end, "last unit end -> write-back start")
         q(s[:, 13] - s[:, 12], "write-back duration")
@@ -79,7 +86,7 @@ for rep in range(3):
         # the same for the workgroup that ends the launch
         b = fin.max(1).argmax()
         c = wg[b, am[b]]
-        print("  the slot that ends the launch: front start %.2f, published %.2f, " % (c[0], c[1]) + ", ".join("unit %d %.2f -> %.2f" % (u, c[2 + 2 * u], c[3 + 2 * u]) for u in range(nu)) + ", write-back %.2f -> %.2f" % (c[12], c[13]))
+        print("  the slot that ends the launch: front start %.2f, published %.2f, " % (c[0], c[1]) + ", ".join("unit %d %.2f -> %.2f" % (u, c[2 + 2 * u], c[3 + 2 * u]) for u in range(min(nu + 1, 5))) + ", write-back %.2f -> %.2f" % (c[12], c[13]))
         print("  that workgroup's slots finish at:", np.round(np.sort(fin[b]), 1))
         # total work of a workgroup (sum of its slots' phase durations as measured, i.e. under the contention they ran in) against when it ended
         work = (s[:, 1] - s[:, 0]) + (s[:, 13] - s[:, 12])
