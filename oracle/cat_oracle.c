@@ -300,6 +300,31 @@ static void sort_cands(seg_cand *c, int n)
 static const uint8_t *g_wall_subset = NULL;
 void cato_set_wall_subset(const uint8_t *mask) { g_wall_subset = mask; }
 
+/* Diagnostic (tools/query_order_diff.py): how many queries have a result that can depend on the ORDER of the visits at all, whatever tree Chipmunk
+   builds.  With t the gate value and a the hit alpha of every candidate (t < 1) of one index, the candidate of the smallest alpha is visited under
+   EVERY order iff its t is below the second-smallest alpha (the best alpha so far can never be lower than that when its turn comes); otherwise the
+   order "second-smallest first" gates it out and "smallest first" does not.  Two equal smallest alphas make the winner's identity depend on the
+   order.  Counted per index (walls with best = 1 at the start; agents with best = the walls' result).  Relaxed atomics: the oracle steps on threads. */
+static int g_count_order = 0;
+static long long g_order_counts[4];   /* queries, queries with an order-dependent wall result, with an order-dependent agent result, ties among them */
+void cato_count_order_dependence(int on) { g_count_order = on; if (on) for (int i = 0; i < 4; i++) g_order_counts[i] = 0; }
+void cato_order_dependence(long long out[4]) { for (int i = 0; i < 4; i++) out[i] = __atomic_load_n(&g_order_counts[i], __ATOMIC_RELAXED); }
+/* alphas[i] (>= start = "no hit that could win") and gates[i] of the n candidates of one index: 1 = order-dependent, 2 = by a tie */
+static int order_dependent(const double *alphas, const double *gates, int n, double start)
+{
+    int arg = -1;
+    double a1 = start, a2 = start;
+    for (int i = 0; i < n; i++) {
+        if (alphas[i] < a1) { a2 = a1; a1 = alphas[i]; arg = i; }
+        else if (alphas[i] < a2) a2 = alphas[i];
+    }
+    if (arg < 0) return 0;                         /* nothing can win: the result is "no hit" (or the walls' hit) under every order */
+    int ties = 0;
+    for (int i = 0; i < n; i++) ties += alphas[i] == a1;
+    if (ties > 1) return 2;
+    return (a2 < start && !(gates[arg] < a2)) ? 1 : 0;
+}
+
 static int segment_query_first(const cato_sim *s, int env, int self, double ax, double ay,
                                double bx, double by, double r2, int los, seg_info *out)
 {
@@ -318,6 +343,19 @@ static int segment_query_first(const cato_sim *s, int env, int self, double ax, 
         if (tbb < 1.0 || !c->bbtree_gate) { cand[n].tbb = tbb; cand[n].id = sh; n++; }
     }
     if (!g_index_order) sort_cands(cand, n);
+    if (g_count_order && !los && c->bbtree_gate) {   /* diagnostic: every candidate's alpha, gated or not */
+        double al[256], gt[256];
+        for (int q = 0; q < n; q++) {
+            seg_info info = {0, 1.0, bx, by};
+            if (poly_point_distance(m, cand[q].id, c->wall_radius, ax, ay) <= r2) { info.hit = 1; info.alpha = 0.0; }
+            else poly_segment_query(m, cand[q].id, c->wall_radius, ax, ay, bx, by, r2, &info);
+            al[q] = info.hit ? info.alpha : 2.0; gt[q] = cand[q].tbb;
+        }
+        const int dep = order_dependent(al, gt, n, 1.0);
+        __atomic_fetch_add(&g_order_counts[0], 1, __ATOMIC_RELAXED);
+        if (dep) __atomic_fetch_add(&g_order_counts[1], 1, __ATOMIC_RELAXED);
+        if (dep == 2) __atomic_fetch_add(&g_order_counts[3], 1, __ATOMIC_RELAXED);
+    }
     for (int q = 0; q < n; q++) {
         const int sh = cand[q].id;
         if (c->bbtree_gate && !(cand[q].tbb < t_exit)) { if (g_index_order) continue; else break; }
@@ -340,6 +378,20 @@ static int segment_query_first(const cato_sim *s, int env, int self, double ax, 
             if (tbb < 1.0 || !c->bbtree_gate) { cand[n].tbb = tbb; cand[n].id = j; n++; }
         }
         if (!g_index_order) sort_cands(cand, n);
+        if (g_count_order && c->bbtree_gate && n > 1) {   /* diagnostic: the agents' index, entered with best = the walls' result */
+            double al[CATO_MAX_AGENTS], gt[CATO_MAX_AGENTS];
+            for (int q = 0; q < n; q++) {
+                const double *tc = TC(s, env, cand[q].id);
+                seg_info info = {0, 1.0, bx, by};
+                double ex = ax - tc[0], ey = ay - tc[1];
+                if (sqrt(ex * ex + ey * ey) - c->agent_radius <= r2) { info.hit = 1; info.alpha = 0.0; }
+                else circle_segment_query(tc[0], tc[1], c->agent_radius, ax, ay, bx, by, r2, &info);
+                al[q] = info.hit ? info.alpha : 2.0; gt[q] = cand[q].tbb;
+            }
+            const int dep = order_dependent(al, gt, n, out->alpha);
+            if (dep) __atomic_fetch_add(&g_order_counts[2], 1, __ATOMIC_RELAXED);
+            if (dep == 2) __atomic_fetch_add(&g_order_counts[3], 1, __ATOMIC_RELAXED);
+        }
         for (int q = 0; q < n; q++) {
             const int j = cand[q].id;
             if (c->bbtree_gate && !(cand[q].tbb < t_exit)) { if (g_index_order) continue; else break; }

@@ -113,6 +113,8 @@ int cato_set_state(cato_sim *s, const cato_state *src);
 int cato_random_actions(cato_sim *s, uint64_t tick, int32_t *actions);
 void cato_set_threads(int n);     /* OpenMP threads over envs; 1 = scalar port */
 void cato_set_index_order(int on);/* 1 (default): segment queries visit shapes in index order (D2); 0: nearest-bb-first (diagnostic) */
+void cato_count_order_dependence(int on);   /* diagnostic: start (and zero) / stop counting the queries whose result can depend on the visiting order at all */
+void cato_order_dependence(long long out[4]);/* queries, order-dependent among the walls, among the agents, of those: by a tie of the two smallest alphas */
 
 /* ---- elementary pieces, exported so tests can pin them individually ---- */
 uint16_t cato_f64_to_f16(double x);

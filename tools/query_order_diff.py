@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """CPU diagnostic: how many observations depend on the ORDER in which a segment query visits the shapes whose bb it enters
-(DESIGN D2): the oracle with nearest-bb-first order (the order Chipmunk's BBTree descent produces) against index order (the
-convention of rounds 1-2), same seeds, same actions, every ray of every tick compared.  usage: tools/query_order_diff.py [envs] [ticks]"""
+(DESIGN D2): the oracle with nearest-bb-first order (the order Chipmunk's BBTree descent produces for sibling leaves) against index order (the
+product's), same seeds, same actions, every ray of every tick compared; and, whatever tree Chipmunk builds, the BOUND: the queries whose result can
+depend on the visiting order at all (the candidate of the smallest alpha is gated out under some order, or the two smallest alphas tie --
+oracle/cat_oracle.c order_dependent).  usage: tools/query_order_diff.py [envs] [ticks]"""
+import ctypes
 import sys
 from pathlib import Path
 
@@ -23,6 +26,7 @@ for name in ("labyrinth", "agh-map", "squarinth", "lbirinth", "grandbyrinth"):
     L.cato_set_index_order(0); a.reset()
     L.cato_set_index_order(1); b.reset()
     rays = diff_shape = diff_obs = 0
+    L.cato_count_order_dependence(1)
     for t in range(T):
         acts = a.random_actions(t)
         before = a.get_state()                       # same state on both sides every tick: only the query order differs
@@ -35,4 +39,9 @@ for name in ("labyrinth", "agh-map", "squarinth", "lbirinth", "grandbyrinth"):
         diff_shape += int((oa["hit_shape"] != ob["hit_shape"]).sum())
         diff_obs += int(((oa["obs_type"] != ob["obs_type"]) | (oa["obs_distance"] != ob["obs_distance"])).sum())
     L.cato_set_index_order(1)
-    print(f"{name}: {rays} rays, winning shape differs on {diff_shape}, observation (class or f16 distance) differs on {diff_obs}")
+    dep = (ctypes.c_longlong * 4)()
+    L.cato_order_dependence(dep)
+    L.cato_count_order_dependence(0)
+    print(f"{name}: {rays} rays, winning shape differs on {diff_shape}, observation (class or f16 distance) differs on {diff_obs};  "
+          f"order-dependent at all: {dep[1] + dep[2]} of {dep[0]} queries = {100.0 * (dep[1] + dep[2]) / max(dep[0], 1):.4f} % "
+          f"(walls {dep[1]}, agents {dep[2]}; {dep[3]} of them ties of the two smallest alphas)")
