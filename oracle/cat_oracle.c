@@ -46,6 +46,8 @@ typedef struct {
     double *start;    /* [A][2] */
     double *regions;  /* [Rg][4] */
     int32_t *first, *count, *region_off;
+    struct bbt_node *tree;   /* diagnostic (cato_set_index_order(2)): Chipmunk's static BBTree over the walls, restated */
+    int tree_root;
 } cato_map;
 
 struct cato_sim {
@@ -269,10 +271,56 @@ typedef struct {
 static inline const double *TC(const cato_sim *s, int env, int j) { return s->tc + 2 * ((size_t)env * s->A + j); }
 static inline const double *LEAF(const cato_sim *s, int env, int j) { return s->leaf_bb + 4 * ((size_t)env * s->A + j); }
 
+/* ---- DIAGNOSTIC: Chipmunk's static spatial index restated ([CP cpBBTree.c]; Chipmunk2D 7.0.x as Pymunk 6 vendors it).  Not what the product or the
+   default oracle do (D2: index order) -- cato_set_index_order(2) makes the wall part of a segment query descend THIS tree the way
+   [CP SubtreeSegmentQuery] does, so that tools/query_order_diff.py can count the observations on which the two orders differ.  The tree is what
+   [CP cpBBTreeInsert] builds when the walls are added in index order ([REF map.py populate_space] adds them in file order): [CP SubtreeInsert]
+   descends into the child with the smaller cost  area(other child) + merged area(this child, leaf)  ([CP cpBBProximity] on equal costs; B only if
+   strictly cheaper), a new inner node takes the NEW leaf as A and the subtree it met as B, and every node on the way is merged with the leaf's bb.
+   Static leaves carry the plain shape bb (the static index has no velocity function).  Nothing reorders the static tree afterwards. */
+struct bbt_node { double bb[4]; int a, b, obj; };   /* obj >= 0: a leaf (wall id) */
+static double bbt_area(const double *x) { return (x[2] - x[0]) * (x[3] - x[1]); }
+static double bbt_merged_area(const double *x, const double *y)
+{
+    return (fmax2(x[2], y[2]) - fmin2(x[0], y[0])) * (fmax2(x[3], y[3]) - fmin2(x[1], y[1]));
+}
+static double bbt_proximity(const double *x, const double *y) { return fabs(x[0] + x[2] - y[0] - y[2]) + fabs(x[1] + x[3] - y[1] - y[3]); }
+static void bbt_merge(double *d, const double *x, const double *y)
+{
+    d[0] = fmin2(x[0], y[0]); d[1] = fmin2(x[1], y[1]); d[2] = fmax2(x[2], y[2]); d[3] = fmax2(x[3], y[3]);
+}
+static int bbt_insert(struct bbt_node *n, int *count, int subtree, int leaf)
+{
+    if (subtree < 0) return leaf;
+    if (n[subtree].obj >= 0) {   /* [CP NodeNew(tree, leaf, subtree)] */
+        const int k = (*count)++;
+        n[k].a = leaf; n[k].b = subtree; n[k].obj = -1;
+        bbt_merge(n[k].bb, n[leaf].bb, n[subtree].bb);
+        return k;
+    }
+    const double *A = n[n[subtree].a].bb, *B = n[n[subtree].b].bb, *Lf = n[leaf].bb;
+    double cost_a = bbt_area(B) + bbt_merged_area(A, Lf), cost_b = bbt_area(A) + bbt_merged_area(B, Lf);
+    if (cost_a == cost_b) { cost_a = bbt_proximity(A, Lf); cost_b = bbt_proximity(B, Lf); }
+    if (cost_b < cost_a) n[subtree].b = bbt_insert(n, count, n[subtree].b, leaf);
+    else n[subtree].a = bbt_insert(n, count, n[subtree].a, leaf);
+    double merged[4];
+    bbt_merge(merged, n[subtree].bb, Lf);
+    memcpy(n[subtree].bb, merged, sizeof merged);
+    return subtree;
+}
+static void bbt_build(cato_map *m)
+{
+    m->tree = (struct bbt_node *)calloc((size_t)(2 * m->S + 1), sizeof(struct bbt_node));
+    int count = m->S, root = -1;
+    for (int s = 0; s < m->S; s++) { memcpy(m->tree[s].bb, m->bb + 4 * (size_t)s, 32); m->tree[s].a = m->tree[s].b = -1; m->tree[s].obj = s; }
+    for (int s = 0; s < m->S; s++) root = bbt_insert(m->tree, &count, root, s);
+    m->tree_root = root;
+}
+
 /* one candidate of a segment query: its spatial-index gate value and its place in the shape list */
 typedef struct { double tbb; int id; } seg_cand;
 
-static int g_index_order = 1;   /* 1 = visit in index order (D2, what the HIP kernels do); 0 = nearest-bb-first (diagnostic) */
+static int g_index_order = 1;   /* 1 = visit in index order (D2, what the HIP kernels do); diagnostics: 0 = nearest-bb-first, 2 = the walls by Chipmunk's own tree descent */
 void cato_set_index_order(int on) { g_index_order = on; }
 
 /* ascending (tbb, id): insertion sort, the lists are short and nearly sorted */
@@ -299,6 +347,35 @@ static void sort_cands(seg_cand *c, int n)
    in index order as always.  Never set by a stepping sim; single-threaded use. */
 static const uint8_t *g_wall_subset = NULL;
 void cato_set_wall_subset(const uint8_t *mask) { g_wall_subset = mask; }
+
+/* one wall's [CP SegmentQueryFirst]: the shape query, and the result kept if its alpha is below the best so far */
+typedef struct { const cato_map *m; const cato_config *c; double ax, ay, bx, by, dx, dy, idx, idy, r2; seg_info *out; int best; } seg_ctx;
+static double visit_wall(seg_ctx *x, int sh)
+{
+    seg_info info = {0, 1.0, x->bx, x->by};
+    /* [CP cpShapeSegmentQuery]: start point within `radius` of the shape -> alpha 0, point stays at the segment end */
+    if (poly_point_distance(x->m, sh, x->c->wall_radius, x->ax, x->ay) <= x->r2) { info.hit = 1; info.alpha = 0.0; }
+    else poly_segment_query(x->m, sh, x->c->wall_radius, x->ax, x->ay, x->bx, x->by, x->r2, &info);
+    if (info.hit && info.alpha < x->out->alpha) { *x->out = info; x->best = sh; }
+    return x->out->alpha;
+}
+/* DIAGNOSTIC [CP SubtreeSegmentQuery]: the child whose bb the segment enters first is descended first; a child is entered only if its entry lies
+   before the best alpha so far (the gate of D3's slab test, as everywhere in this file) */
+static double bbt_query(seg_ctx *x, int node, double t_exit)
+{
+    const struct bbt_node *n = x->m->tree + node;
+    if (n->obj >= 0) return visit_wall(x, n->obj);
+    const double t_a = bb_segment_query(x->m->tree[n->a].bb, x->ax, x->ay, x->dx, x->dy, x->idx, x->idy);
+    const double t_b = bb_segment_query(x->m->tree[n->b].bb, x->ax, x->ay, x->dx, x->dy, x->idx, x->idy);
+    if (t_a < t_b) {
+        if (t_a < t_exit) t_exit = fmin2(t_exit, bbt_query(x, n->a, t_exit));
+        if (t_b < t_exit) t_exit = fmin2(t_exit, bbt_query(x, n->b, t_exit));
+    } else {
+        if (t_b < t_exit) t_exit = fmin2(t_exit, bbt_query(x, n->b, t_exit));
+        if (t_a < t_exit) t_exit = fmin2(t_exit, bbt_query(x, n->a, t_exit));
+    }
+    return t_exit;
+}
 
 /* Diagnostic (tools/query_order_diff.py): how many queries have a result that can depend on the ORDER of the visits at all, whatever tree Chipmunk
    builds.  With t the gate value and a the hit alpha of every candidate (t < 1) of one index, the candidate of the smallest alpha is visited under
@@ -356,20 +433,17 @@ static int segment_query_first(const cato_sim *s, int env, int self, double ax, 
         if (dep) __atomic_fetch_add(&g_order_counts[1], 1, __ATOMIC_RELAXED);
         if (dep == 2) __atomic_fetch_add(&g_order_counts[3], 1, __ATOMIC_RELAXED);
     }
+    seg_ctx ctx = {m, c, ax, ay, bx, by, dx, dy, idx, idy, r2, out, -1};
+    if (g_index_order == 2 && c->bbtree_gate && !g_wall_subset && m->tree_root >= 0) {   /* diagnostic: Chipmunk's own descent of its static tree */
+        t_exit = fmin2(t_exit, bbt_query(&ctx, m->tree_root, t_exit));
+        n = 0;
+    }
     for (int q = 0; q < n; q++) {
         const int sh = cand[q].id;
         if (c->bbtree_gate && !(cand[q].tbb < t_exit)) { if (g_index_order) continue; else break; }
-        seg_info info = {0, 1.0, bx, by};
-        /* [CP cpShapeSegmentQuery]: start point within `radius` of the shape -> alpha 0,
-           point stays at the segment end */
-        if (poly_point_distance(m, sh, c->wall_radius, ax, ay) <= r2) {
-            info.hit = 1; info.alpha = 0.0;
-        } else {
-            poly_segment_query(m, sh, c->wall_radius, ax, ay, bx, by, r2, &info);
-        }
-        if (info.hit && info.alpha < out->alpha) { *out = info; best = sh; }
-        t_exit = fmin2(t_exit, out->alpha);
+        t_exit = fmin2(t_exit, visit_wall(&ctx, sh));
     }
+    best = ctx.best;
     if (!los) {
         n = 0;
         for (int j = 0; j < s->A; j++) {
@@ -938,6 +1012,7 @@ static int parse_blob(const void *blob, size_t size, cato_map *m)
     m->bb = f + 2; m->planes = m->bb + 4 * (size_t)m->S; m->start = m->planes + 8 * (size_t)m->P;
     m->regions = m->start + 2 * (size_t)m->A;
     m->first = iv; m->count = iv + m->S; m->region_off = iv + 2 * (size_t)m->S;
+    bbt_build(m);
     return 0;
 }
 
@@ -1018,7 +1093,7 @@ int cato_create(const cato_config *cfg, const cato_tables *tab, const void *cons
 void cato_destroy(cato_sim *s)
 {
     if (!s) return;
-    for (int i = 0; i < s->n_maps; i++) { free(s->maps[i].bb - 2); free(s->maps[i].first); }
+    for (int i = 0; i < s->n_maps; i++) { free(s->maps[i].bb - 2); free(s->maps[i].first); free(s->maps[i].tree); }
     free(s->maps); free(s->slot_map); free(s->ray_dx); free(s->ray_dy); free(s->cop_lut); free(s->thief_lut);
     free(s->pos); free(s->vel); free(s->vbias); free(s->tc); free(s->leaf_bb); free(s->wall_shape);
     free(s->wall_age); free(s->wall_jn); free(s->pair_age); free(s->pair_jn); free(s->step_count);
