@@ -40,12 +40,17 @@ class PymunkScene:
         rings = host.map_rings(map_data)
         if scale is not None:
             rings = [[(x * scale[0], y * scale[1]) for x, y in r] for r in rings]
+        self.shape_ids = {}                                                             # shape -> its place in the oracle's shape list (walls in file order, then agents)
         for ring in rings:                                                              # REF maps/map.py:124-128 populate_space
-            self.space.add(pymunk.Poly(self.space.static_body, ring, radius=1))
+            wall = pymunk.Poly(self.space.static_body, ring, radius=1)
+            self.shape_ids[wall] = len(self.shape_ids)
+            self.space.add(wall)
+        self.n_walls = len(self.shape_ids)
         n_cops, n_thieves, starts, _ = host.agent_tables(map_data, roster, start_positions, None)
         self.n_cops, self.n_thieves, self.A = n_cops, n_thieves, n_cops + n_thieves
         self.R, self.max_step_count, self.dt = n_rays, max_step_count, dt
         self.step_count = 0
+        self.last_hit_shape = {}
         self.bodies, self.shapes, self.ray_filters, self.categories = [], [], [], []
         group = itertools.count(1)                                                      # base_env.py:89: cops first, then thieves
         for i, xy in enumerate(starts):
@@ -58,6 +63,7 @@ class PymunkScene:
             circle.filter = pymunk.ShapeFilter(group=g, categories=cat)                 # entity.py:118
             self.ray_filters.append(pymunk.ShapeFilter(group=g, categories=cat))        # entity.py:120-123
             self.space.add(body, circle)                                                # entity.py:124
+            self.shape_ids[circle] = self.n_walls + i
             self.bodies.append(body); self.shapes.append(circle); self.categories.append(cat)
         self.force = {0: pymunk.Vec2d(-host.UNIT_VELOCITY, 0), 1: pymunk.Vec2d(0, host.UNIT_VELOCITY),
                       2: pymunk.Vec2d(host.UNIT_VELOCITY, 0), 3: pymunk.Vec2d(0, -host.UNIT_VELOCITY)}   # entity.py:76-81
@@ -84,6 +90,8 @@ class PymunkScene:
         hits = [self.space.segment_query_first(origin, pm.Vec2d(*end), 1, self.ray_filters[i]) for end in endpoints]
         distances = np.full(self.R, host.RAY_LENGTH, dtype=np.float16)
         types = np.full(self.R, EMPTY, dtype=np.uint8)
+        # which shape each ray's query returned (the oracle's `hit_shape`): what pins the ORDER of Chipmunk's visits (DESIGN D2)
+        self.last_hit_shape[i] = np.array([-1 if h is None else self.shape_ids.get(h.shape, -2) for h in hits], dtype=np.int32)
         idx = [k for k, h in enumerate(hits) if h is not None]
         if idx:
             pts = np.array([hits[k].point for k in idx], dtype=np.float16)

@@ -82,3 +82,41 @@ def test_oracle_agrees_with_pymunk(name):
             if contacts > 1 or want["terminated"]:
                 break
     assert compared >= 100, f"{name}: only {compared} ticks could be compared"
+
+
+@pytest.mark.parametrize("name", sorted(MAPS))
+def test_winning_shapes_follow_the_restated_bbtree_descent(name):
+    """DESIGN D2 against the engine: WHICH shape a ray's ``segment_query_first`` returns depends on the order of Chipmunk's visits.  The oracle's
+    diagnostic order 2 restates that order for the walls (cpBBTreeInsert in file order, nearer child first): with it the winning shape of every ray
+    must be Pymunk's own; with the product's index order the rays that differ are counted and reported (``tools/query_order_diff.py`` predicts
+    0.0001 % on the labyrinth ... 0.5 % on lbirinth).  Static scenes only: the agents stand where they were put, nothing is stepped."""
+    from oracle import cat_oracle
+    roster, starts, scale = MAPS[name]
+    data = host.raw_map(name)
+    R = 90
+    rng = np.random.default_rng(abs(hash(name)) % (1 << 31) + 7)
+    L = cat_oracle.lib()
+    rays = differ_index = 0
+    try:
+        for ep in range(40):
+            scene = PymunkScene(data, n_rays=R, max_step_count=150, roster=roster, start_positions=starts, scale=scale)
+            blob = host.compile_blob(data, roster, starts, None, scale)
+            cfg = _Cfg(n_envs=1, n_cops=scene.n_cops, n_thieves=scene.n_thieves, n_rays=R, max_step_count=150, seed=ep + 1)
+            window = tuple(data["window"].values())
+            pos = _free_positions(scene, rng, window, scene.A)
+            scene.reset(pos)
+            for i in range(scene.A):
+                scene.observe(i)
+            want = np.stack([scene.last_hit_shape[i] for i in range(scene.A)])
+            got = {}
+            for mode in (2, 1):
+                cpu = OracleSim(cfg, [blob])
+                L.cato_set_index_order(mode)
+                out = cpu.reset(positions=np.asarray(pos, np.float64).reshape(1, scene.A, 2))
+                got[mode] = out["hit_shape"][0].reshape(scene.A, R)
+            assert np.array_equal(got[2], want), f"{name} scene {ep}: the restated tree descent returns another shape than Pymunk on {int((got[2] != want).sum())} rays"
+            rays += want.size
+            differ_index += int((got[1] != want).sum())
+    finally:
+        L.cato_set_index_order(1)
+    print(f"{name}: index order (the product's) returns another shape than Pymunk on {differ_index} of {rays} rays")
